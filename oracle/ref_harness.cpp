@@ -1,0 +1,161 @@
+// ref_harness.cpp -- thin C-API shim over the *real* reference (xp3i4/linear).
+//
+// TEST INFRASTRUCTURE.  Compiled by oracle/Makefile together with the
+// reference's own translation units, in place under /root/reference, into
+// oracle/_ref/libref_linear.so (git-ignored; never committed, never shipped
+// with the product).  It mirrors the C API of oracle/lnr_oracle.cpp so the
+// tests and tools/make_golden.py can run the reference and the restatement
+// side by side on identical inputs.  Own code: it only *calls* the reference
+// (createIndexDynamic index_util.h:297, createFeatures pmpfinder.h:196,
+// getDIndexMatchAll pmpfinder.cpp:1856, apxMap pmpfinder.h:213).
+#include "base.h"
+#include "cords.h"
+#include "shape_extend.h"
+#include "index_util.h"
+#include "cluster_util.h"
+#include "pmpfinder.h"
+#include <omp.h>
+#include <vector>
+#include <cstring>
+
+using namespace seqan;
+
+// external-linkage functions of pmpfinder.cpp that have no header declaration
+unsigned getDIndexMatchAll(DIndex &index, String<Dna5> &read, String<uint64_t> &set, uint64_t read_str, uint64_t read_end, PMPParms &pm_pmp);
+uint64_t filterAnchors(Anchors &anchors, uint64_t shape_len, uint64_t thd_anchor_accept_density, uint64_t thd_anchor_accept_min,
+                       unsigned thd_anchor_err_bit, uint64_t thd_max_anchors_num, uint64_t thd_anchor_accept_err, int alg_type);
+int chainAnchorsHits(String<uint64_t> &anchors, String<uint64_t> &hits, String<int> &hits_chains_score, PMPParms &pm_pmp);
+
+namespace {
+const size_t PAD = 64;
+
+// Build a String<Dna5> whose allocator slack behind end() is zero ('A'), so the
+// reference's reads past the end (shape_extend.cpp:294, pmpfinder.cpp:637-647)
+// are deterministic and equal to the pin documented in lnr_oracle.cpp.
+void assign_padded(String<Dna5> &s, const uint8_t *p, uint64_t n) {
+    resize(s, n + PAD, Dna5(0));
+    for (uint64_t i = 0; i < n; i++) s[i] = Dna5(p[i]);
+    for (uint64_t i = n; i < n + PAD; i++) s[i] = Dna5(0);
+    resize(s, n);   // shrinking keeps the storage (and the zeroed slack)
+}
+
+struct RefCtx {
+    StringSet<String<Dna5> > g;
+    IndexDynamic *idx;
+    StringSet<FeaturesDynamic> f2;
+    unsigned T;
+    // per-read scratch (mapper.cpp:423-433)
+    Anchors anchors;
+    String<uint64_t> hit;
+    String<UPair> gaps;
+    String<Dna5> com;
+    StringSet<FeaturesDynamic> f1;
+    PMPParms pm;
+    GlobalParms pg;
+    String<uint64_t> cs, ce;
+};
+}  // namespace
+
+extern "C" {
+
+void *ref_create(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T) {
+    RefCtx *c = new RefCtx();
+    c->T = T ? T : 1;
+    omp_set_num_threads(c->T);
+    resize(c->g, nseq);
+    for (uint32_t i = 0; i < nseq; i++) assign_padded(c->g[i], seqs[i], lens[i]);
+    createFeatures(c->g, c->f2, 2, c->T);                     // linear.cpp:76 (process3)
+    c->idx = new IndexDynamic(c->g);
+    c->idx->setIndexType(1);                                  // -i 1 -> DIndex
+    createIndexDynamic(c->g, *c->idx, 0, length(c->g), c->T, false);
+    c->pm.pm_cah.thd_stop_chain_len_ratio = 0;                // default preset -p 1 (mapper.cpp:181-185)
+    resize(c->f1, 2);
+    c->f1[0].init(2);
+    c->f1[1].init(2);
+    return c;
+}
+void ref_destroy(void *h) { RefCtx *c = (RefCtx *)h; delete c->idx; delete c; }
+uint64_t ref_dir_len(void *h) { return length(((RefCtx *)h)->idx->dindex.getDir()); }
+uint64_t ref_hs_len(void *h) { return length(((RefCtx *)h)->idx->dindex.getHs()); }
+const int32_t *ref_dir(void *h) { return (const int32_t *)&(((RefCtx *)h)->idx->dindex.getDir()[0]); }
+const uint64_t *ref_hs(void *h) { RefCtx *c = (RefCtx *)h; return length(c->idx->dindex.getHs()) ? &(c->idx->dindex.getHs()[0]) : nullptr; }
+uint64_t ref_f2_len(void *h, uint32_t id) { return length(((RefCtx *)h)->f2[id].fs2_48); }
+const int32_t *ref_f2(void *h, uint32_t id) { return (const int32_t *)&(((RefCtx *)h)->f2[id].fs2_48[0]); }
+
+uint64_t ref_read_features(const uint8_t *read, uint64_t len, int strand, int32_t *out, uint64_t cap) {
+    String<Dna5> r, com;
+    assign_padded(r, read, len);
+    FeaturesDynamic f(2);
+    if (strand) {
+        _compltRvseStr(r, com);
+        createFeatures(begin(com), end(com), f);
+    } else createFeatures(begin(r), end(r), f);
+    uint64_t n = length(f.fs2_48);
+    if (n && cap) memcpy(out, &f.fs2_48[0], (n < cap ? n : cap) * 12);
+    return n;
+}
+
+uint64_t ref_seed_lookup(void *h, const uint8_t *read, uint64_t len, uint64_t read_str, uint64_t read_end, int alpha,
+                         uint64_t *out, uint64_t cap, uint64_t *stats4) {
+    RefCtx *c = (RefCtx *)h;
+    String<Dna5> r;
+    assign_padded(r, read, len);
+    String<uint64_t> set;
+    appendValue(set, 0);
+    PMPParms pm;
+    pm.pm_gdima.thd_alpha = alpha;
+    getDIndexMatchAll(c->idx->dindex, r, set, read_str, read_end, pm);
+    uint64_t n = length(set);
+    if (out && n) memcpy(out, &set[0], (n < cap ? n : cap) * 8);
+    if (stats4) { stats4[0] = stats4[1] = stats4[2] = 0; stats4[3] = n - 1; }
+    return n;
+}
+
+uint64_t ref_map_read(void *h, const uint8_t *read, uint64_t len) {
+    RefCtx *c = (RefCtx *)h;
+    String<Dna5> r;
+    assign_padded(r, read, len);
+    clear(c->cs);
+    clear(c->ce);
+    if (len <= 200) return 0;                                 // mapper.cpp:430,440
+    String<CordInfo> ci;
+    _compltRvseStr(r, c->com);
+    // keep the slack behind the reverse complement deterministic as well
+    { uint64_t n = length(c->com); resize(c->com, n + PAD, Dna5(0)); resize(c->com, n); }
+    createFeatures(begin(r), end(r), c->f1[0]);
+    createFeatures(begin(c->com), end(c->com), c->f1[1]);
+    apxMap(*c->idx, r, c->anchors, c->hit, c->f1, c->f2, c->gaps, c->cs, c->ce, ci, 1, c->pg, c->pm);
+    return length(c->cs);
+}
+void ref_get_cords(void *h, uint64_t *cords_str, uint64_t *cords_end) {
+    RefCtx *c = (RefCtx *)h;
+    uint64_t n = length(c->cs);
+    if (n) { memcpy(cords_str, &c->cs[0], n * 8); memcpy(cords_end, &c->ce[0], n * 8); }
+}
+
+// stage dumps reproduced by calling the reference's own stage functions in apxMap_'s order
+// (pmpfinder.cpp:2646-2652, 2520-2526): 0 raw anchors, 1 filtered anchors, 2 x-desc sorted anchors, 3 hits after anchor chaining
+uint64_t ref_stage(void *h, const uint8_t *read, uint64_t len, int stage, uint64_t *out, uint64_t cap) {
+    RefCtx *c = (RefCtx *)h;
+    String<Dna5> r;
+    assign_padded(r, read, len);
+    Anchors anchors;
+    anchors.init(1);
+    PMPParms pm;
+    pm.pm_cah.thd_stop_chain_len_ratio = 0;
+    getDIndexMatchAll(c->idx->dindex, r, anchors.set, 0, len, pm);
+    String<uint64_t> *res = &anchors.set;
+    String<uint64_t> hits;
+    String<int> hits_score;
+    if (stage >= 1) filterAnchors(anchors, c->pg.shape_len, 1, 2, 2, 5, 2500, 2);
+    if (stage >= 2) {
+        initHits(hits);
+        initHitsScore(hits_score);
+        chainAnchorsHits(anchors.set, hits, hits_score, pm);   // sorts anchors.set in place
+        if (stage == 3) res = &hits;
+    }
+    uint64_t n = length(*res);
+    if (out && n) memcpy(out, &(*res)[0], (n < cap ? n : cap) * 8);
+    return n;
+}
+}  // extern "C"
