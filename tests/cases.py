@@ -1,0 +1,75 @@
+"""Seeded parity cases shared by tools/make_golden.py (which runs the REAL reference
+through oracle/_ref and stores its outputs under tests/golden/) and by the tests
+(which regenerate the same inputs from the seeds and compare).
+
+A case = (reference sequences, reads, index layout T).  ``T`` is the reference's
+``-t``: the DIndex content depends on it.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from linear_amd import synth
+
+
+def _reads_list(reads, off):
+    return [reads[int(off[i]):int(off[i + 1])] for i in range(off.size - 1)]
+
+
+def case_c1():
+    """BASELINE config 1 (scaled): error-free 5 kb reads vs 1 Mb random reference, odd reads reverse-complemented."""
+    ref = synth.random_ref(1_000_000, 12345)
+    reads, off, _ = synth.sample_reads([ref], 250, 5000, 0.0, 777, "odd")
+    return [ref], reads, off
+
+
+def case_ont():
+    """ONT-profile 10 kb reads (10 % errors, 40/30/30 sub/del/ins) vs 2 Mb random reference."""
+    ref = synth.random_ref(2_000_000, 4242)
+    reads, off, _ = synth.sample_reads([ref], 120, 10000, 0.10, 778, "random")
+    return [ref], reads, off
+
+
+def case_rep():
+    """Repeat-rich reference: exercises bucket omission, tie-sensitive sorts, both traceback algorithms."""
+    rep = synth.repeat_ref(1_000_000, 99)
+    reads, off, _ = synth.sample_reads([rep], 80, 10000, 0.10, 779, "random")
+    return [rep], reads, off
+
+
+def case_edge():
+    """Three reference sequences with N runs + edge-case reads (short, junk -> remap loop, N, chimeras, sequence ends)."""
+    r0 = synth.add_n_runs(synth.random_ref(600_000, 5), 6, n_runs=4, max_run=3000, lead=5000, trail=3000)
+    r1 = synth.add_n_runs(synth.repeat_ref(400_000, 7), 8, n_runs=2, max_run=500)
+    r2 = synth.random_ref(30_000, 9)
+    refs = [r0, r1, r2]
+    er = synth.edge_reads(refs, 11)
+    reads2, off2, _ = synth.sample_reads(refs, 60, 8000, 0.08, 780, "random", len_jitter=0.5)
+    reads, off = synth.pack_reads(er + _reads_list(reads2, off2))
+    return refs, reads, off
+
+
+CASES = {
+    # name: (builder, [T layouts])
+    "c1": (case_c1, [1]),
+    "ont": (case_ont, [1, 4]),
+    "rep": (case_rep, [1, 8]),
+    "edge": (case_edge, [1, 3]),
+}
+
+N_STAGE_READS = 6   # reads per case whose per-stage outputs are stored
+
+
+def input_digest(refs, reads, off) -> str:
+    h = hashlib.sha256()
+    for r in refs:
+        h.update(np.ascontiguousarray(r).tobytes())
+    h.update(np.ascontiguousarray(reads).tobytes())
+    h.update(np.ascontiguousarray(off).tobytes())
+    return h.hexdigest()
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (oracle/_ref, built from
+/root/reference by oracle/Makefile) on the seeded cases of tests/cases.py.
+
+Only runs where /root/reference exists.  The stored vectors are data (inputs are
+regenerated from seeds; outputs are the reference's words), never reference source.
+
+Per (case, T):
+  digest            sha256 of the regenerated inputs (guards against generator drift)
+  dir_sha/hs_sha    sha256 of the DIndex arrays, hs_len, dir_nonempty
+  hs_head           first 4096 hs entries (spot check with readable diffs)
+  f2_sha[k]/f2_len  genome window features per sequence (last element excluded: SURVEY App. C.5)
+  cord_off, cords_str, cords_end   CSR of the final cords of every read (the parity surface)
+  stage reads: raw anchors, filtered anchors, x-sorted anchors, chained hits, read features
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import pyorc  # noqa: E402
+from tests import cases  # noqa: E402
+
+
+def main():
+    pyorc.build(ref=True)
+    assert pyorc.have_ref(), "oracle/_ref not built (no /root/reference?)"
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    for name, (builder, layouts) in cases.CASES.items():
+        refs, reads, off = builder()
+        n = off.size - 1
+        for T in layouts:
+            r = pyorc.Checker("ref", refs, T)
+            d = {"digest": cases.input_digest(refs, reads, off), "T": T, "n_reads": n}
+            dir_, hs = r.dir(), r.hs()
+            d["dir_sha"], d["hs_sha"], d["hs_len"] = cases.sha(dir_), cases.sha(hs), hs.size
+            d["dir_nonempty"] = int((np.diff(dir_.astype(np.int64)) > 0).sum())
+            d["hs_head"] = hs[:4096]
+            d["f2_len"] = np.array([r.f2(k).shape[0] for k in range(len(refs))])
+            d["f2_sha"] = np.array([cases.sha(r.f2(k)[:-1]) for k in range(len(refs))])
+            coff = np.zeros(n + 1, np.uint64)
+            cs_l, ce_l = [], []
+            for i in range(n):
+                rd = reads[int(off[i]):int(off[i + 1])]
+                cs, ce = r.map_read(rd)
+                cs_l.append(cs)
+                ce_l.append(ce)
+                coff[i + 1] = coff[i] + cs.size
+            d["cord_off"] = coff
+            d["cords_str"] = np.concatenate(cs_l) if cs_l else np.zeros(0, np.uint64)
+            d["cords_end"] = np.concatenate(ce_l) if ce_l else np.zeros(0, np.uint64)
+            # stage dumps on reads long enough to be mapped
+            idx = [i for i in range(n) if int(off[i + 1] - off[i]) > 200][: cases.N_STAGE_READS]
+            # for the edge case take a spread of the edge reads as well
+            if name == "edge":
+                idx = [i for i in range(n) if int(off[i + 1] - off[i]) > 200][:16]
+            d["stage_reads"] = np.array(idx)
+            for k, i in enumerate(idx):
+                rd = reads[int(off[i]):int(off[i + 1])]
+                for s, nm in enumerate(("raw", "filt", "xsort", "hits")):
+                    d[f"st{k}_{nm}"] = r.stage(rd, s)
+                d[f"st{k}_f1fwd"] = r.read_features(rd, 0)
+                d[f"st{k}_f1rev"] = r.read_features(rd, 1)
+                a7, _ = r.seed_lookup(rd, 100, rd.size - 50, 7)
+                d[f"st{k}_raw7"] = a7
+            path = os.path.join(outdir, f"{name}_T{T}.npz")
+            np.savez_compressed(path, **d)
+            print(f"{path}: reads {n} cords {int(coff[-1])} hs {hs.size} size {os.path.getsize(path) / 1024:.0f} kB")
+            r.close()
+
+
+if __name__ == "__main__":
+    main()
