@@ -1,0 +1,939 @@
+// lnr_hd.h -- stage logic of the filter hot path as __host__ __device__ code over raw arrays.
+//
+// This is PRODUCT code: the HIP kernels in lnr_kernels.hip call these functions on the
+// device.  It is written host/device-neutral only so that tests/ can also compile it with
+// g++ and check every stage against the oracle on a machine without a GPU
+// (tests/host_shim.cpp); the shipped library contains no host execution path for it.
+//
+// Reference behaviour restated here (xp3i4/linear, paths relative to the reference root):
+//   cords.cpp (bit words), shape_extend.cpp:86-348 (gapped minimizer, in closed form, see
+//   seed_sample), pmpfinder.cpp:1979-2091 (anchor filter), cluster_util.cpp:53-462 (chain DP
+//   + traceback), pmpfinder.cpp:1484-1530,2366-2446 + cluster_util.cpp:469-732 (hit blocks),
+//   pmpfinder.cpp:680-722,883-945,1079-1178,1309-1445 (window extension),
+//   pmpfinder.cpp:1537-1667 + cluster_util.cpp:774-1102 (cord blocks), pmpfinder.cpp:2709-2804.
+#pragma once
+#include <stdint.h>
+#include <limits.h>
+#include "ref_sort.h"
+
+namespace lnr {
+
+typedef uint64_t u64;
+typedef int64_t i64;
+typedef uint32_t u32;
+typedef int32_t i32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+struct UP { u64 first, second; };   // UPair
+
+// ------------------------------------------------------------------ cords ----
+static const u64 ANCHOR_ZERO = 1ULL << 20;
+static const u64 F_END = 1ULL << 60, F_STRAND = 1ULL << 61, F_RECD = 1ULL << 62, F_MAIN = 1ULL << 63;
+static const u64 VALUE_MASK_DSTR = ((1ULL << 60) - 1) | F_STRAND;
+static const u64 MAX_CORD_ID = (1ULL << 10) - 1, MAX_CORD_X = (1ULL << 30) - 1;
+
+LNR_HD inline u64 cord_x(u64 v) { return (v >> 20) & ((1ULL << 30) - 1); }
+LNR_HD inline u64 cord_y(u64 v) { return v & 0xfffffULL; }
+LNR_HD inline u64 cord_strand(u64 v) { return (v >> 61) & 1ULL; }
+LNR_HD inline u64 cord_id(u64 v) { return (v >> 50) & 1023ULL; }
+LNR_HD inline u64 cord_x40(u64 v) { return (v >> 20) & 0xffffffffffULL; }
+LNR_HD inline u64 mk_cord(u64 idx, u64 y, u64 s) { return (idx << 20) + y + (s << 61); }
+LNR_HD inline u64 create_cord(u64 id, u64 x, u64 y, u64 s) { return mk_cord((id << 30) + x, y, s); }
+LNR_HD inline u64 shift_cord(u64 v, i64 x, i64 y) { return x < 0 ? v - ((u64)(-x) << 20) + (u64)y : v + ((u64)x << 20) + (u64)y; }
+LNR_HD inline bool is_end(u64 v) { return (v & F_END) != 0; }
+LNR_HD inline u64 hit2cord(u64 a) { return ((a + ((a & 0xfffffULL) << 20) - (ANCHOR_ZERO << 20)) & VALUE_MASK_DSTR) & ~(1ULL << 62); }
+LNR_HD inline u64 anchor_x(u64 a) { return cord_x(hit2cord(a)); }
+LNR_HD inline i64 labs64(i64 v) { return v < 0 ? -v : v; }
+LNR_HD inline i64 max64(i64 a, i64 b) { return a > b ? a : b; }
+LNR_HD inline i64 min64(i64 a, i64 b) { return a < b ? a : b; }
+LNR_HD inline u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
+LNR_HD inline u64 umax64(u64 a, u64 b) { return a > b ? a : b; }
+LNR_HD inline int consecutive(u64 c1, u64 c2, u64 thd) {
+    u64 x1 = cord_x(c1), x2 = cord_x(c2), y1 = cord_y(c1), y2 = cord_y(c2);
+    return !cord_strand(c1 ^ c2) && x1 <= x2 && y1 <= y2 && x2 - x1 < thd && y2 - y1 < thd;
+}
+LNR_HD inline UP forward_y(UP se, u64 L) {
+    UP r;
+    if (cord_strand(se.first)) { r.first = L - cord_y(se.second) - 1; r.second = L - cord_y(se.first) - 1; }
+    else { r.first = cord_y(se.first); r.second = cord_y(se.second); }
+    return r;
+}
+
+// bounded vector view over caller-provided storage; overflow is recorded, never written past cap
+template <class T>
+struct Vec {
+    T *p; u32 n, cap; int *ovf;
+    LNR_HD void init(T *p_, u32 cap_, int *ovf_) { p = p_; n = 0; cap = cap_; ovf = ovf_; }
+    LNR_HD void push(const T &v) { if (n < cap) p[n++] = v; else *ovf = 1; }
+    LNR_HD T &operator[](u32 i) { return p[i]; }
+    LNR_HD T &back() { return p[n - 1]; }
+};
+struct Arena {
+    char *base; u64 off, cap; int ovf;
+    LNR_HD void init(void *b, u64 c) { base = (char *)b; off = 0; cap = c; ovf = 0; }
+    template <class T> LNR_HD T *get(u64 n) {
+        u64 bytes = (n * sizeof(T) + 15) & ~15ULL;
+        if (off + bytes > cap) { ovf = 1; return (T *)base; }
+        T *r = (T *)(base + off); off += bytes; return r;
+    }
+};
+// bytes of per-job scratch needed by job_process for a job with `cap` anchor slots
+LNR_HD inline u64 job_scratch_bytes(u64 cap) { return cap * 176 + 4096; }
+LNR_HD inline u64 tail_scratch_bytes(u64 cap) { return cap * 240 + 8192; }
+
+// --------------------------------------------------------- minimizer shape ----
+// Closed form of hashInit/hashNexth/hashNextX (shape_extend.cpp:86-116,173-184,245-348)
+// for span 21, weight 13.  `s` points at a zero-padded sequence; the rolling state of
+// the reference at position k after starting the roll at k0 (hashInit having run at
+// s+init_at with N-skip ks) is reproduced from the bases alone:
+//   x_k   = C + 2*sum(s[k..k+20]),  C = -63 + 2*sum(s[init_at+ks .. +19]) - 2*sum(s[k0..k0+19])
+//   h_k   = sum VW[p]*4^(20-p) mod 2^42 (N=4 carries), crh_k = sum ((3-VW[p])&3) << 2p
+//   VW[p] = s[k+p], except while fewer than 21 bases have been rolled in (n=k-k0+1<21):
+//           the first 21-n slots still hold the tail of the hashInit window.
+struct SeedOut { u32 X; u32 Y; u32 strand; };
+
+LNR_HD inline int shape_init_skip(const u8 *s) {   // N-skip of hashInit (shape_extend.cpp:95-105)
+    u64 k = 0, count = 0;
+    while (count < 21) {
+        if (s[k + count] == 4) { k += count + 1; count = 0; }
+        else count++;
+    }
+    return (int)k;
+}
+LNR_HD inline int shape_const(const u8 *s, u64 init_at, int ks, u64 k0) {
+    int a = 0, b = 0;
+    for (int i = 0; i < 20; i++) { a += s[init_at + ks + i]; b += s[k0 + i]; }
+    return -63 + 2 * a - 2 * b;
+}
+LNR_HD inline SeedOut seed_sample(const u8 *s, u64 k, u64 k0, u64 init_at, int ks, int C) {
+    u64 h = 0, crh = 0;
+    int W = 0;
+    u64 n = k - k0 + 1;
+    int stale = n < 21 ? (int)(21 - n) : 0;
+    for (int p = 0; p < 21; p++) {
+        u64 real = s[k + p];
+        W += (int)real;
+        u64 v = p < stale ? (u64)s[init_at + ks + n - 1 + p] : real;
+        h = (h << 2) + v;
+        crh |= ((3 - v) & 3) << (2 * p);
+    }
+    int x = C + 2 * W;
+    u64 v2 = x > 0 ? (h & ((1ULL << 42) - 1)) : crh;
+    u64 X = (1ULL << 42) - 1, t = 0;
+    for (unsigned kk = 22; kk <= 38; kk += 2) {
+        u64 v1 = v2 << kk >> 38;
+        if (X > v1) { X = v1; t = kk; }
+    }
+    u64 Y = 0;
+    if (x > 0) {
+        i64 d = (i64)(t >> 1) + 2;
+        for (i64 i = d; i < d + 4; i++) { u64 val = s[k + i]; Y = val > 3 ? (Y << 2) : (Y << 2) + val; }
+    } else {
+        i64 d = 18 - (i64)(t >> 1);
+        for (i64 i = d; i > d - 4; i--) { i64 val = 3 - (i64)s[(i64)k + i]; Y = val < 0 ? (Y << 2) : (Y << 2) + (u64)val; }
+    }
+    SeedOut o; o.X = (u32)X; o.Y = (u32)Y; o.strand = x > 0 ? 0 : 1;
+    return o;
+}
+LNR_HD inline bool y_match(u64 hs_y, u64 Y) {   // pmpfinder.cpp:1893-1894, ctz(0) pinned to "match"
+    u64 v = hs_y ^ Y;
+    if (v == 0) return true;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int tz = __ffsll((unsigned long long)v) - 1;
+#else
+    int tz = __builtin_ctzll(v);
+#endif
+    return (v >> tz) < 4;
+}
+LNR_HD inline u64 val2anchor(u64 e, u64 y, u64 L, u64 shape_strand) {   // index_util.cpp:1509-1520
+    if (cord_strand(e) ^ shape_strand) {
+        u64 cy = L - 1 - y;
+        return (e - (cy << 20) + cy - cord_y(e)) | F_STRAND;
+    }
+    return (e - (y << 20) + y - cord_y(e)) & ~F_STRAND;
+}
+// number of samples getDIndexMatchAll takes on [read_str, read_end) with step alpha (pmpfinder.cpp:1874-1880)
+LNR_HD inline u32 seed_num_samples(u64 read_str, u64 read_end, u32 alpha) {
+    u64 k_first = read_str + 21 + alpha - 1;
+    if (read_end < 21 || k_first >= read_end - 21) return 0;
+    return (u32)((read_end - 21 - k_first + alpha - 1) / alpha);
+}
+
+// Genome chunking of createDIndex (index_util.cpp:1654-1666): sequence of length len split for T layout threads.
+LNR_HD inline void chunk_bounds(u64 len, u32 T, u32 t, i64 &t_str, i64 &t_end) {
+    i64 b0 = (i64)(len / T * t);
+    i64 b1 = t + 1 < T ? (i64)(len / T * (t + 1)) : (i64)len - 21;
+    t_str = b0 + 21;
+    t_end = b1 - 21;
+}
+// samples of a chunk sit at j = t_str + 8 + 9m < t_end (count > thd_min_step = 8, index_util.cpp:1677)
+LNR_HD inline u64 chunk_num_samples(i64 t_str, i64 t_end) {
+    if (t_end - t_str <= 8) return 0;
+    return (u64)((t_end - t_str - 8 + 8) / 9);
+}
+LNR_HD inline u64 genome_feature_count(u64 len) { return len < 48 ? 0 : ((len - 48) >> 4) + 1; }   // pmpfinder.cpp:596
+
+// ---------------------------------------------------------------- features ----
+struct F96 { i32 v0, v1, v2, pad; };   // int96 + pad: one 16-byte load per entry
+struct FeatView { const F96 *p; u32 n; };
+
+// 2-mer -> (word, bit) table of pmpfinder.cpp:543-548 folded into arithmetic: pairs (a,b) with
+// a,b<4 and not TT map to bit 6*((4a+b)%5) of word (4a+b)/5; anything else adds nothing.
+LNR_HD inline void add2mer(i32 &w0, i32 &w1, i32 &w2, u32 a, u32 b) {
+    if (a > 3 || b > 3) return;
+    u32 c = 4 * a + b;
+    if (c == 15) return;
+    i32 add = 1 << (6 * (c % 5));
+    u32 w = c / 5;
+    if (w == 0) w0 += add; else if (w == 1) w1 += add; else w2 += add;
+}
+LNR_HD inline u32 read_feature_count(u64 L) {   // length of createFeatures2_48's result (pmpfinder.cpp:556-588)
+    if (L < 50) return 0;
+    return (u32)(1 + (L - 50) / 16);
+}
+LNR_HD inline i64 script_dist(i32 s1, i32 s2) {   // pmpfinder.cpp:497-506
+    const i32 mxu31 = (31 << 24) + (31 << 18) + (31 << 12) + (31 << 6) + 31;
+    i32 d = s1 + mxu31 - s2;
+    i32 a0 = ((d >> 24) & 63) - 31, a1 = ((d >> 18) & 63) - 31, a2 = ((d >> 12) & 63) - 31, a3 = ((d >> 6) & 63) - 31, a4 = (d & 63) - 31;
+    return (i64)((a0 < 0 ? -a0 : a0) + (a1 < 0 ? -a1 : a1) + (a2 < 0 ? -a2 : a2) + (a3 < 0 ? -a3 : a3) + (a4 < 0 ? -a4 : a4));
+}
+LNR_HD inline i64 window_dist(const F96 *a, const F96 *b) {   // _windowDist2_48 pmpfinder.cpp:523-533
+    F96 a0 = a[0], a3 = a[3], b0 = b[0], b3 = b[3];
+    return script_dist(a0.v0, b0.v0) + script_dist(a0.v1, b0.v1) + script_dist(a0.v2, b0.v2) +
+           script_dist(a3.v0, b3.v0) + script_dist(a3.v1, b3.v1) + script_dist(a3.v2, b3.v2);
+}
+LNR_HD inline u32 wdist_checked(FeatView f1, FeatView f2, u64 x1, u64 x2) {   // _windowDist pmpfinder.cpp:680-695
+    if (x1 + 4 < f1.n && x2 + 4 < f2.n) return (u32)window_dist(f1.p + x1, f2.p + x2);
+    return 1000;
+}
+LNR_HD inline u32 wdist_raw(FeatView f1, FeatView f2, u64 x1, u64 x2) {   // __windowDist pmpfinder.cpp:655-663; out of range pinned to abort score
+    if (x1 + 3 < f1.n && x2 + 3 < f2.n) return (u32)window_dist(f1.p + x1, f2.p + x2);
+    return 1000;
+}
+
+// -------------------------------------------------------------- parameters ----
+struct JobParm { i32 alpha; i32 score_type; };   // PMPParms::toggle (pmpfinder.cpp:21-29,1778-1784,2493-2503)
+LNR_HD inline JobParm job_parm(int mode) { JobParm p; p.alpha = mode ? 7 : 15; p.score_type = mode ? 1 : 0; return p; }
+
+// ------------------------------------------------------------ anchor filter ----
+// binningFilter pmpfinder.cpp:1979-2012, serial form (the kernel has a wave-parallel twin).
+// `bins` holds nbins zeroed u16 counters and is returned zeroed.  Counters saturate at 0xffff
+// (only "> 10" is tested).  Quirk kept: if nothing survives, everything is kept (:2007-2010).
+LNR_HD inline u32 binning_filter_serial(u64 *a, u32 n, u16 *bins, u32 nbins) {
+    for (u32 i = 0; i < n; i++) { u32 b = (u32)(cord_x(a[i]) / 30000); if (b < nbins && bins[b] != 0xffff) bins[b]++; }
+    u32 ii = 0;
+    for (u32 i = 0; i < n; i++) { u32 b = (u32)(cord_x(a[i]) / 30000); if (b < nbins && bins[b] > 10) a[ii++] = a[i]; }
+    for (u32 b = 0; b < nbins; b++) bins[b] = 0;
+    return ii ? ii : n;
+}
+// filterAnchorsList scan (pmpfinder.cpp:2034-2066) over the ascending-sorted anchors with a[0]==0;
+// accepted ranges are compacted in place; returns the new length (filterAnchors1 :2073-2091)
+LNR_HD inline u32 filter_anchor_list(u64 *a, u32 n) {
+    const u64 density = 1, accept_min = 2;
+    const unsigned err_bit = 2;
+    if (n <= 1) return n;
+    u64 ak2 = a[1];
+    u64 block_str = 1, count_anchors = 0;
+    u64 min_y = ~0ULL, max_y = 0;
+    u32 ii = 0;
+    for (u32 i = 1; i < n; i++) {
+        u64 anc_y = cord_y(a[i]);
+        u64 dy2 = (u64)labs64((i64)(anc_y - cord_y(ak2)));
+        int f_cont = cord_x40(a[i] - ak2) < (dy2 >> err_bit);
+        if (f_cont) {
+            if (min_y > anc_y) min_y = anc_y;
+            if (max_y < anc_y) max_y = anc_y;
+            ak2 = a[(block_str + i) >> 1];
+            ++count_anchors;
+        }
+        if (!f_cont || i == n - 1) {
+            u64 thd = umax64(((max_y - min_y) * density >> 10), accept_min);
+            if (count_anchors > thd) {
+                // ranges are emitted in increasing order and ii <= block_str, so in-place forward copy is safe;
+                // ak2 for later blocks is re-read from a[i] (i >= block end), which is not yet overwritten
+                for (u64 j = block_str; j < i; j++) a[ii++] = a[j];
+            }
+            block_str = i;
+            ak2 = a[i];
+            min_y = anc_y; max_y = anc_y;
+            count_anchors = 1;
+        }
+    }
+    return ii;
+}
+
+// ------------------------------------------------------------ chain scoring ----
+LNR_HD inline int chain_score0(u32 x1, u32 y1, u32 x2, u32 y2) {   // getApxChainScore0 cluster_util.cpp:337-385 (effective values)
+    i64 dy = (i64)y1 - (i64)y2;
+    if (dy < 5) return -10000;
+    i64 dx = (i64)x1 - (i64)x2;
+    i64 da = labs64(dx - dy);
+    i64 derr = (100 * da) / max64(max64(labs64(dy), labs64(dx)), 50);
+    if (derr >= 100) return -1000;
+    if (da < 30) return (int)(100 - dy);
+    return (int)(100 - dy - da);
+}
+LNR_HD inline int chain_score(u32 x1, u32 y1, u32 x2, u32 y2) {   // getApxChainScore cluster_util.cpp:387-443
+    i64 dy = (i64)y1 - (i64)y2;
+    if (dy < 10) return -10000;
+    i64 dx = (i64)x1 - (i64)x2;
+    i64 da = labs64(dx - dy);
+    i64 derr = (100 * da) / max64(max64(labs64(dy), labs64(dx)), 50);
+    int score_derr;
+    if (derr < 5) score_derr = (int)(4 * derr);
+    else if (derr < 10) score_derr = (int)(6 * derr - 10);
+    else if (derr < 100) score_derr = (int)(derr * derr - 5 * derr);
+    else return -1000;
+    int score_dy;
+    dy /= 15;
+    if (dy < 150) score_dy = (int)(dy / 5);
+    else if (dy < 10000) score_dy = (int)(dy * dy / 200 + 20);
+    else score_dy = 10000;
+    if (da < 10) return 100 - score_dy;
+    return 100 - score_dy - score_derr;
+}
+
+struct Rec { i32 *score, *score2, *len, *p2, *root, *leaf; };   // ChainsRecord as SoA
+
+// getBestChains cluster_util.cpp:53-111, serial form.  xs/ys = getAnchorX / y of the x-descending anchors.
+LNR_HD inline void best_chains_serial(const u32 *xs, const u32 *ys, u32 n, Rec r, int score_type, u64 *pair_evals) {
+    u32 p300 = 0;   // smallest j with xs[j]-xs[i] < 300 (non-decreasing in i)
+    for (u32 i = 0; i < n; i++) {
+        int j_str = (int)i - 20 < 0 ? 0 : (int)i - 20;
+        while (p300 < i && xs[p300] - xs[i] >= 300) p300++;
+        int j_lo = (int)p300 < j_str ? (int)p300 : j_str;
+        int max_j = (int)i, best = -1;
+        for (int j = (int)i - 1; j >= j_lo; j--) {
+            int sc = score_type ? chain_score0(xs[j], ys[j], xs[i], ys[i]) : chain_score(xs[j], ys[j], xs[i], ys[i]);
+            if (sc > 0 && sc + r.score[j] >= best) { max_j = j; best = sc + r.score[j]; }
+        }
+        if (pair_evals) *pair_evals += (u64)((int)i - j_lo);
+        if (best > 0) {
+            r.p2[i] = max_j; r.score[i] = best; r.len[i] = r.len[max_j] + 1; r.score2[i] = best;
+            r.root[i] = r.root[max_j]; r.leaf[i] = 1; r.leaf[max_j] = 0;
+        } else {
+            r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = (i32)i; r.leaf[i] = 1;
+        }
+    }
+}
+
+// Chain sinks: traceback hands over finished chains element by element.
+struct AnchorSink {      // chainAnchorsHits pmpfinder.cpp:2472-2479: chains -> hits (+ scores), block end after each
+    const u64 *anchors; Vec<u64> *hits; Vec<i32> *hscore; u32 first_len, nchains;
+    LNR_HD void emit(const i32 *idx, const i32 *sc, u32 n) {
+        for (u32 k = 0; k < n; k++) { hits->push(hit2cord(anchors[idx[k]])); hscore->push(sc[k]); }
+        hits->back() |= F_END;
+        if (nchains == 0) first_len = n;
+        nchains++;
+    }
+};
+struct BlockSink {       // chains of blocks (StringSet<String<UPair>>) flattened: el[off[c]..off[c+1])
+    const UP *elements; UP *el; i32 *off; u32 nchains, nel, cap; int *ovf; u32 first_len;
+    LNR_HD void emit(const i32 *idx, const i32 *sc, u32 n) {
+        (void)sc;
+        if (nel + n > cap) { *ovf = 1; return; }
+        for (u32 k = 0; k < n; k++) el[nel + k] = elements[idx[k]];
+        nel += n;
+        if (nchains == 0) first_len = n;
+        nchains++;
+        off[nchains] = (i32)nel;
+    }
+};
+
+// traceBackChains0 cluster_util.cpp:121-205
+template <class Sink>
+LNR_HD inline void traceback0(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, int min_len, int abort_score, int bestn, float stop_ratio) {
+    const int delete_score = -1000;
+    int search_times = bestn < 50 ? bestn : 50;
+    for (int it = 0; it < search_times; it++) {
+        bool f_done = true;
+        int max_2nd = -1, max_score = -1, max_str = -1, max_len = 0;
+        for (u32 j = 0; j < n; j++) {
+            if (r.score[j] > max_score) { max_2nd = max_score; max_str = (int)j; max_score = r.score[j]; max_len = r.len[j]; f_done = false; }
+        }
+        if (sink.nchains) { if ((float)max_len > (float)sink.first_len * stop_ratio) f_done = false; }
+        if (f_done || max_score == 0) break;
+        if (max_len > min_len && max_score / (max_len - 1) > abort_score) {
+            u32 cn = 0;
+            for (int j = max_str; j != -1; j = r.p2[j]) {
+                if (r.score[j] != delete_score) { chain[cn] = j; chain_sc[cn] = r.score2[j]; cn++; r.score[j] = delete_score; }
+                else {
+                    int infix = r.score2[j];
+                    if (max_score - infix < max_2nd) {
+                        for (int k = max_str; k != j; k = r.p2[k]) r.score[k] = r.score2[k] - infix;
+                        cn = 0;
+                    }
+                    break;
+                }
+            }
+            if (cn) sink.emit(chain, chain_sc, cn);
+        }
+        if (max_str != -1) r.score[max_str] = delete_score;
+    }
+}
+// traceBackChains1 cluster_util.cpp:213-304 (at most 50 trees reach this function)
+template <class Sink>
+LNR_HD inline void traceback1(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, int min_len, int abort_score, int bestn, float stop_ratio) {
+    i32 l_root[64], l_score[64], l_len[64], l_leaf[64];
+    int nl = 0;
+    for (u32 j = 0; j < n; j++) {
+        if (r.leaf[j]) {
+            int f_new = 1;
+            for (int k = 0; k < nl; k++) {
+                if (l_root[k] == r.root[j]) {
+                    if (r.score[j] > l_score[k]) { l_score[k] = r.score[j]; l_len[k] = r.len[j]; l_leaf[k] = (i32)j; }
+                    f_new = 0;
+                }
+            }
+            if (f_new && nl < 64) { l_root[nl] = r.root[j]; l_score[nl] = r.score[j]; l_len[nl] = r.len[j]; l_leaf[nl] = (i32)j; nl++; }
+        }
+    }
+    u64 ranks[64];   // (tree index, score) pairs; std::sort by score desc with ties (cluster_util.cpp:269)
+    for (int i = 0; i < nl; i++) ranks[i] = ((u64)(u32)l_score[i] << 32) | (u32)i;
+    ref_sort(ranks, (long)nl, [](const u64 &a, const u64 &b) { return (i32)(a >> 32) > (i32)(b >> 32); });
+    int lim = bestn < nl ? bestn : nl;
+    for (int i = 0; i < lim; i++) {
+        int t = (int)(u32)ranks[i];
+        int max_score = l_score[t], max_len = l_len[t], max_str = l_leaf[t];
+        int mean = max_len > 1 ? max_score / (max_len - 1) : abort_score + 1;
+        if (max_len > min_len && mean > abort_score) {
+            u32 cn = 0;
+            for (int j = max_str; j != -1; j = r.p2[j]) { chain[cn] = j; chain_sc[cn] = r.score2[j]; cn++; }
+            if (cn) {
+                if (sink.nchains && (float)cn / (float)sink.first_len < stop_ratio) break;   // f_stop: nothing is emitted afterwards
+                sink.emit(chain, chain_sc, cn);
+            }
+        }
+    }
+}
+// traceBackChains cluster_util.cpp:306-335; cnt = n zeroed ints of scratch
+template <class Sink>
+LNR_HD inline void traceback(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int min_len, int abort_score, int bestn, float stop_ratio) {
+    u32 root_num = 0;
+    for (u32 i = 0; i < n; i++) cnt[i] = 0;
+    for (u32 i = 0; i < n; i++) { if (cnt[r.root[i]] == 0) root_num++; cnt[r.root[i]] = 1; }
+    if (root_num > 50) traceback0(r, n, sink, chain, chain_sc, min_len, abort_score, bestn, stop_ratio);
+    else traceback1(r, n, sink, chain, chain_sc, min_len, abort_score, bestn, stop_ratio);
+}
+
+// ------------------------------------------------------------------ blocks ----
+// gather_blocks_ pmpfinder.cpp:1484-1530.  str_ends may be null (not needed by the caller).
+LNR_HD inline void gather_blocks(u64 *cords, u32 ncords, Vec<UP> *str_ends, Vec<UP> &sep, u64 str_, u64 end_, u64 L, u64 large_gap, u64 cord_size, int f_set_end) {
+    if (str_ends) str_ends->n = 0;
+    if (ncords < 2) return;
+    u64 dmax = cord_size / 2, d;
+    u32 p_str = (u32)str_;
+    for (u32 i = (u32)str_ + 1; i < end_; i++) {
+        if (is_end(cords[i - 1]) || !consecutive(cords[i - 1], cords[i], large_gap)) {
+            d = umin64(L - cord_y(cords[p_str]) - 1, dmax);
+            u64 b_str = shift_cord(cords[p_str], (i64)d, (i64)d);
+            d = umin64(L - cord_y(cords[i - 1]) - 1, dmax);
+            u64 b_end = shift_cord(cords[i - 1], (i64)d, (i64)d);
+            if (str_ends) { UP u; u.first = b_str; u.second = b_end; str_ends->push(u); }
+            UP q; q.first = p_str; q.second = i; sep.push(q);
+            if (f_set_end) cords[i - 1] |= F_END;
+            p_str = i;
+        }
+    }
+    d = umin64(L - cord_y(cords[ncords - 1]) - 1, dmax);
+    u64 b_str = shift_cord(cords[p_str], (i64)d, (i64)d);
+    u64 b_end = shift_cord(cords[ncords - 1], (i64)d, (i64)d);
+    if (str_ends) { UP u; u.first = b_str; u.second = b_end; str_ends->push(u); }
+    UP q; q.first = p_str; q.second = ncords; sep.push(q);
+}
+
+// preFilterChains2 pmpfinder.cpp:2366-2446 with getCordXY = get_cord_y.  sep is replaced.
+LNR_HD inline void prefilter_chains2(u64 *hits, u32 nhits, Vec<UP> &sep, u64 *cuts, u64 *xy_strs, Vec<UP> &tmp) {
+    const u64 mask = 1ULL << 62;
+    u32 nb = sep.n;
+    for (u32 i = 0; i < nb; i++) { cuts[2 * i] = sep[i].first; cuts[2 * i + 1] = (sep[i].second - 1) | mask; xy_strs[i] = sep[i].first; }
+    const u64 *h = hits;
+    ref_sort(cuts, (long)(2 * nb), [h, mask](const u64 &a, const u64 &b) { return cord_y(h[a & ~mask]) < cord_y(h[b & ~mask]); });
+    tmp.n = 0;
+    for (u32 i = 0; i < 2 * nb; i++) {
+        u64 cuty = cord_y(hits[cuts[i] & ~mask]);
+        for (u32 j = 0; j < nb && xy_strs[j] < nhits; j++) {
+            if (cuty < cord_y(hits[xy_strs[j]])) continue;
+            for (u64 k = xy_strs[j]; k < sep[j].second; k++) {
+                u64 ky = cord_y(hits[k]);
+                u64 upper;
+                bool cut;
+                if (cuts[i] & mask) {
+                    if (ky == cuty) { upper = k + 1; cut = true; }
+                    else if (ky > cuty) { upper = k; cut = true; }
+                    else cut = false;
+                } else {
+                    if (ky >= cuty) { upper = k; cut = true; }
+                    else cut = false;
+                }
+                if (cut) {
+                    u64 lower = xy_strs[j];
+                    if (lower != upper) { UP u; u.first = lower; u.second = upper; tmp.push(u); xy_strs[j] = upper; }
+                    break;
+                }
+            }
+        }
+    }
+    sep.n = 0;
+    for (u32 i = 0; i < tmp.n; i++) sep.push(tmp[i]);
+    ref_sort(sep.p, (long)sep.n, [](const UP &a, const UP &b) { return a.second < b.second; });
+    for (u32 i = 0; i < sep.n; i++) hits[sep[i].second - 1] |= F_END;
+}
+
+LNR_HD inline int block_score2(u64 c11, u64 c22) {   // getApxChainScore2 cluster_util.cpp:586-631
+    i64 dy = (i64)(cord_y(c11) - cord_y(c22));
+    i64 dx = (i64)(cord_x(c11) - cord_x(c22));
+    if (dx < 0 || dy < 0 || cord_strand(c11 ^ c22) || dx > 20000 || dy > 20000) return INT_MIN;
+    i64 da = labs64(dx - dy);
+    i64 derr = (100 * da) / max64(max64(labs64(dy), 100), labs64(dx));
+    if (da > 100 || derr > 50) {
+        if (dx < dy) return (int)(100 - 30 - dy / 1000 - dx / 100);
+        return (int)(100 - 30 - dy / 100 - dx / 1000);
+    }
+    return (int)(100 - dy / 95);
+}
+LNR_HD inline int block_score3(u64 c11, u64 c12, u64 c21, u64 c22, u64 L, int strand) {   // getApxChainScore3 + getChainBlockDxDy cluster_util.cpp:774-863
+    i64 dx, dy;
+    if (cord_strand(c11) != (u64)strand) {
+        if (cord_strand(c22) != (u64)strand) { dy = (i64)(cord_y(c21) - cord_y(c12)); dx = (i64)(cord_x(c21) - cord_x(c12)); }
+        else { dy = (i64)(L - cord_y(c12) - 1 - cord_y(c22)); dx = (i64)(cord_x(c11) - cord_x(c22)); }
+    } else {
+        if (cord_strand(c22) != (u64)strand) { dy = (i64)(cord_y(c11) - L + 1 + cord_y(c21)); dx = (i64)(cord_x(c11) - cord_x(c22)); }
+        else { dy = (i64)(cord_y(c11) - cord_y(c22)); dx = (i64)(cord_x(c11) - cord_x(c22)); }
+    }
+    int f_type = (int)cord_strand(c11 ^ c22);
+    i64 thd_min_dx = -(i64)L;
+    i64 thd_max_dy = (i64)((float)L * 1.0f);
+    i64 dx_ = labs64(dx), dy_ = labs64(dy), da = dx - dy;
+    int score = 0;
+    if (dy < -80 || dy > thd_max_dy || dx < thd_min_dx || dx_ > 15000) score = INT_MIN;
+    else {
+        i64 sdy = dy_ > 2000 ? min64(dy_ / 25 - 50, 70) : dy_ / 40;
+        i64 sdx = dx_ > 2000 ? min64(dx_ / 25 - 50, 70) : dx_ / 40;
+        if (f_type == 1) { if (dx > thd_min_dx) score = (int)(75 - sdy); }
+        else if (da < -max64(dx_ / 4, 50)) { if (dx > -50) score = (int)(80 - sdx); else score = (int)(80 - sdy); }
+        else if (da > max64(dy / 4, 50)) score = (int)(80 - sdy);
+        else score = (int)(100 - sdy);
+    }
+    return score;
+}
+// getBestChains2 cluster_util.cpp:469-526.  which: 2 -> getApxChainScore2, 3 -> getApxChainScore3(strand)
+LNR_HD inline void best_chains2(const u64 *hits, const UP *sep, const i32 *sep_score, u32 nb, Rec r, u64 L, int which, int strand) {
+    for (u32 i = 0; i < nb; i++) {
+        int j_str = (int)i - 20 < 0 ? 0 : (int)i - 20;
+        int max_j = (int)i, best = -1;
+        for (u32 j = (u32)j_str; j < i; j++) {
+            int sc = which == 2 ? block_score2(hits[sep[j].first], hits[sep[i].second - 1])
+                                : block_score3(hits[sep[j].first], hits[sep[j].second - 1], hits[sep[i].first], hits[sep[i].second - 1], L, strand);
+            if (sc > 0 && sc + r.score[j] + sep_score[i] >= best) { max_j = (int)j; best = sc + r.score[j] + sep_score[i]; }
+        }
+        if (best > 0) {
+            r.p2[i] = max_j; r.score[i] = best; r.len[i] = (i32)(sep[i].second - sep[i].first) + r.len[max_j]; r.score2[i] = best;
+            r.root[i] = r.root[max_j]; r.leaf[i] = 1; r.leaf[max_j] = 0;
+        } else {
+            r.p2[i] = -1; r.score[i] = sep_score[i]; r.len[i] = (i32)(sep[i].second - sep[i].first); r.score2[i] = r.score[i];
+            r.root[i] = (i32)i; r.leaf[i] = 1;
+        }
+    }
+}
+struct BlockScratch { u32 *ptr; UP *sep_tmp; i32 *score_tmp; Rec rec; i32 *chain, *chain_sc, *cnt; };
+// chainBlocksBase cluster_util.cpp:533-577
+LNR_HD inline void chain_blocks_base(BlockSink &sink, const u64 *records, const UP *sep, const i32 *sep_score, u32 nb, u64 L, int which, int strand,
+                                     int f_sort, BlockScratch s) {
+    if (nb < 2) return;
+    for (u32 i = 0; i < nb; i++) s.ptr[i] = i;
+    if (f_sort) ref_sort(s.ptr, (long)nb, [records, sep](const u32 &a, const u32 &b) { return cord_x40(records[sep[a].first]) > cord_x40(records[sep[b].first]); });
+    for (u32 i = 0; i < nb; i++) { s.sep_tmp[i] = sep[s.ptr[i]]; s.score_tmp[i] = sep_score[s.ptr[i]]; }
+    best_chains2(records, s.sep_tmp, s.score_tmp, nb, s.rec, L, which, strand);
+    sink.elements = s.sep_tmp;
+    traceback(s.rec, nb, sink, s.chain, s.chain_sc, s.cnt, 1, 0, 3, 0.7f);
+}
+// _filterBlocksHits cluster_util.cpp:633-719: rewrites hits from the chained blocks (note: the dummy hits[0] is dropped)
+LNR_HD inline u32 filter_blocks_hits(const BlockSink &ch, const u64 *hits, u64 *out) {
+    if (ch.nchains == 0) return 0xffffffffu;   // untouched
+    u32 n = 0;
+    u64 len_current = 0;
+    for (i32 i = ch.off[0]; i < ch.off[1]; i++) {
+        for (u64 j = ch.el[i].first; j < ch.el[i].second; j++) out[n++] = hits[j] & ~F_END;
+        len_current += ch.el[i].second - ch.el[i].first;
+    }
+    out[n - 1] |= F_END;
+    float bound = 0.8 * len_current;
+    u32 major_n = 1;
+    for (u32 c = 1; c < ch.nchains; c++) {
+        len_current = 0;
+        for (i32 j = ch.off[c]; j < ch.off[c + 1]; j++) len_current += ch.el[j].second - ch.el[j].first;
+        bool f_append = false;
+        if (major_n < 5 && (float)len_current > bound) { f_append = true; ++major_n; }
+        // the reference's third branch needs a chain of zero hits and is unreachable
+        if (f_append) {
+            for (i32 j = ch.off[c]; j < ch.off[c + 1]; j++)
+                for (u64 k = ch.el[j].first; k < ch.el[j].second; k++) out[n++] = hits[k] & ~F_END;
+            out[n - 1] |= F_END;
+        }
+        out[n - 1] |= F_END;
+    }
+    return n;
+}
+
+// ----------------------------------------------------------------- windows ----
+LNR_HD inline u64 previous_window(FeatView f1, FeatView f2, u64 cord) {   // pmpfinder.cpp:883-945
+    u64 gid = cord_id(cord), strand = cord_strand(cord);
+    u64 x_suf = cord_x(cord) >> 4, y_suf = cord_y(cord) >> 4, x_min = 0;
+    if (y_suf < 5 || x_suf < 6) return 0;
+    u64 y = y_suf - 5;
+    u32 mn = ~0u;
+    for (u64 x = x_suf - 6; x < x_suf - 3; x++) { u32 t = wdist_raw(f1, f2, y, x); if (t < mn) { mn = t; x_min = x; } }
+    if (mn > 36) return 0;
+    if (x_suf - x_min > 5) return mk_cord((gid << 30) + ((x_suf - 5) << 4), (x_suf - x_min - 5 + y) << 4, strand);
+    return mk_cord((gid << 30) + (x_min << 4), y << 4, strand);
+}
+LNR_HD inline u64 next_window(FeatView f1, FeatView f2, u64 cord) {   // pmpfinder.cpp:1079-1150
+    u64 gid = cord_id(cord), strand = cord_strand(cord);
+    u64 x_pre = cord_x(cord) >> 4, y_pre = cord_y(cord) >> 4, x_min = 0;
+    if (y_pre + 12 > f1.n || x_pre + 12 > f2.n) return 0;
+    u64 y = y_pre + 5;
+    u32 mn = ~0u;
+    for (u64 x = x_pre + 3; x < x_pre + 6; x++) { u32 t = wdist_raw(f1, f2, y, x); if (t < mn) { mn = t; x_min = x; } }
+    if (mn > 36) return 0;
+    if (x_min - x_pre > 5) return mk_cord((gid << 30) + ((x_pre + 5) << 4), (x_pre + 5 - x_min + y) << 4, strand);
+    return mk_cord((gid << 30) + (x_min << 4), y << 4, strand);
+}
+LNR_HD inline void extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 cordy_str, u64 cordy_end) {   // pmpfinder.cpp:1152-1178
+    u32 p_str = cords.n - 1;
+    u64 nc;
+    while ((nc = previous_window(f1, f2, cords.back())) && cord_y(nc) >= cordy_str) { if (cords.n >= cords.cap) { *cords.ovf = 1; return; } cords.push(nc); }
+    u32 p_end = cords.n;
+    for (u32 k = p_str; k < (p_str + p_end) / 2; k++) rs_swap(cords[k], cords[cords.n - k + p_str - 1]);
+    while ((nc = next_window(f1, f2, cords.back())) && cord_y(nc) + 96 < cordy_end) { if (cords.n >= cords.cap) { *cords.ovf = 1; return; } cords.push(nc); }
+}
+struct GenomeFeat { const F96 *base; const u64 *off; u32 nseq; };   // f2 of all sequences, off[nseq+1] in entries
+LNR_HD inline FeatView f2_view(GenomeFeat g, u64 id) {
+    FeatView v;
+    if (id >= g.nseq) { v.p = g.base; v.n = 0; return v; }
+    v.p = g.base + g.off[id]; v.n = (u32)(g.off[id + 1] - g.off[id]);
+    return v;
+}
+LNR_HD inline u32 filter_hits(u64 *hits, u32 nhits, const FeatView f1[2], GenomeFeat g) {   // _filterHits pmpfinder.cpp:1417-1445
+    u32 mv = 0;
+    for (u32 it = 1; it < nhits; it++) {
+        u32 dist = wdist_checked(f1[cord_strand(hits[it])], f2_view(g, cord_id(hits[it])), cord_y(hits[it]) >> 4, cord_x(hits[it]) >> 4);
+        if (dist < 50) hits[it - mv] = hits[it];
+        else mv++;
+        if (is_end(hits[it])) hits[it - mv] |= F_END;
+    }
+    return nhits - mv;
+}
+LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], GenomeFeat g, Vec<u64> &cords, u64 read_str, u64 read_end, u64 L) {   // pmpfinder.cpp:1309-1410
+    i64 hitBegin = 1, hitEnd = (i64)nhits;
+    if (hitBegin >= hitEnd - 1) return;
+    if (cords.n == 0) cords.push(F_END);   // initCords
+    u64 ready_str, ready_end, cordy_str = 0, cordy_end = 0;
+    bool f_sp_l, f_sp_r = false, f_block_end = false, f_append;
+    i64 itt_next = hitBegin + 1, itt_first = hitBegin;
+    for (i64 itt = hitBegin; itt < hitEnd; itt = itt_next++) {
+        u64 hi = hits[itt];
+        bool first_i = is_end(hits[itt - 1]);
+        ready_str = cord_strand(hi) ? L - read_end : read_str;
+        ready_end = cord_strand(hi) ? L - read_str + 1 : read_end;
+        i64 da_l = first_i ? 0 : labs64((i64)(cord_x(hi) - cord_x(hits[itt - 1]) - cord_y(hi) + cord_y(hits[itt - 1])));
+        f_sp_l = (da_l > 80) || cord_strand(hi ^ hits[itt - 1]);
+        while (1) {
+            if (itt_next >= hitEnd || is_end(hits[itt_next - 1])) { f_block_end = true; itt_first = itt_next; break; }
+            u64 hn = hits[itt_next], hp = hits[itt_next - 1];
+            i64 da_r = labs64((i64)(cord_x(hn) - cord_x(hp) - cord_y(hn) + cord_y(hp)));
+            f_sp_r = (da_r > 80) || cord_strand(hn ^ hp);
+            if ((cord_y(hi) + 96 < cord_y(hn) && cord_x(hi) + 96 < cord_x(hn)) || f_sp_r) break;
+            itt_next++;
+        }
+        f_append = false;
+        if (!f_sp_r && !f_block_end) {
+            cordy_str = f_sp_l ? hi : (first_i ? ready_str : cord_y(cords.back()));
+            cordy_end = cord_y(hits[itt_next]);
+            cords.push(hi & ~F_END);
+            f_append = true;
+        } else {
+            u64 hl = hits[itt_next - 1];
+            if (!f_sp_l && cord_y(hl) >= 96 && cord_x(hl) >= 96) {
+                u64 nc = shift_cord(hl, -96, -96);
+                cordy_str = first_i ? read_str : cord_y(nc);
+                cordy_end = cord_y(hl);
+                cords.push(nc & ~F_END);
+                f_append = true;
+            }
+        }
+        if (is_end(hi) || f_block_end) { f_block_end = true; cordy_end = ready_end; }
+        if (*cords.ovf) return;
+        if (f_append) extend_window(f1[cord_strand(hi)], f2_view(g, cord_id(hi)), cords, cordy_str, cordy_end);
+        if (f_block_end) cords.back() |= F_END;
+        itt_next = f_block_end ? itt_first : itt_next;
+        f_sp_r = false; f_block_end = false;
+    }
+}
+
+// -------------------------------------------------------------- cord blocks ----
+LNR_HD inline u32 clean_blocks(u64 *cords, u32 n, u64 drop_len) {   // clean_blocks_ pmpfinder.cpp:1537-1581 (thd_map_error 50)
+    if (n == 0) return 0;
+    u64 ptr = 1, len = 0;
+    for (u32 i = 1; i < n; i++) {
+        len++;
+        if (!is_end(cords[i - 1])) {
+            i64 dx = (i64)(cord_x(cords[i]) - cord_x(cords[ptr - 1]));
+            i64 dy = (i64)(cord_y(cords[i]) - cord_y(cords[ptr - 1]));
+            if ((dx < 0 || dy < 0) && labs64(dx) < 50 && labs64(dy) < 50) { --len; --ptr; }
+            else cords[ptr] = cords[i];
+        } else cords[ptr] = cords[i];
+        if (is_end(cords[i])) {
+            ptr = len < drop_len ? ptr - len : ptr;
+            len = 0;
+            cords[ptr] |= F_END;
+        }
+        ptr++;
+    }
+    return (u32)ptr;
+}
+// gather_gaps_y_ pmpfinder.cpp:1592-1667; str_ends is sorted in place; gaps = forward-y intervals
+LNR_HD inline int gather_gaps_y(UP *str_ends, u32 ns, Vec<UP> &gaps, u64 L, u64 gap_size) {
+    u64 cord_frt = 0, cord_end = L - 1;
+    int sum = 0;
+    UP u;
+    if (ns == 0) { u.first = cord_frt; u.second = cord_end; gaps.push(u); sum += (int)(cord_y(cord_end) - cord_y(cord_frt)); return sum; }
+    ref_sort(str_ends, (long)ns, [L](const UP &i, const UP &j) {
+        u64 y1 = cord_strand(i.first) ? L - cord_y(i.second) - 1 : cord_y(i.first);
+        u64 y2 = cord_strand(j.first) ? L - cord_y(j.second) - 1 : cord_y(j.first);
+        return y1 < y2;
+    });
+    u64 f_cover = 0, cordy1 = 0, cordy2 = 0;
+    UP y1 = forward_y(str_ends[0], L), y2 = y1;
+    if (y1.first > gap_size) {
+        cordy2 = cord_y(y1.first);
+        u.first = cord_frt; u.second = cordy2; gaps.push(u);
+        sum += (int)(cord_y(u.second) - cord_y(u.first));
+    }
+    for (u32 i = 1; i < ns; i++) {
+        if (!f_cover) { y1 = forward_y(str_ends[i - 1], L); cordy1 = cord_y(y1.second); }
+        y2 = forward_y(str_ends[i], L);
+        cordy2 = cord_y(y2.first);
+        if (y1.second > y2.second) f_cover = 1;
+        else {
+            if (y2.first > y1.second && y2.first - y1.second > gap_size) {
+                u.first = cordy1; u.second = cordy2; gaps.push(u);
+                sum += (int)(cord_y(u.second) - cord_y(u.first));
+            }
+            f_cover = 0;
+        }
+    }
+    u64 max_y_end = f_cover ? y1.second : y2.second;
+    if (L - max_y_end > gap_size) {
+        u.first = max_y_end; u.second = cord_end; gaps.push(u);
+        sum += (int)(cord_y(u.second) - cord_y(u.first));
+    }
+    return sum;
+}
+
+// chainBlocksSingleStrand cluster_util.cpp:936-975: sorts sep (in place), scores, chains
+LNR_HD inline void chain_blocks_single_strand(const u64 *cords, UP *sep, u32 nb, i32 *sep_score, BlockSink &sink, int strand, u64 L, BlockScratch s) {
+    if (strand)
+        ref_sort(sep, (long)nb, [cords, L](const UP &a, const UP &b) {
+            u64 y1 = !cord_strand(cords[a.first]) ? L - 1 - cord_y(cords[a.second - 1]) : cord_y(cords[a.first]);
+            u64 y2 = !cord_strand(cords[b.first]) ? L - 1 - cord_y(cords[b.second - 1]) : cord_y(cords[b.first]);
+            return y1 > y2;
+        });
+    else
+        ref_sort(sep, (long)nb, [cords, L](const UP &a, const UP &b) {
+            u64 y1 = cord_strand(cords[a.first]) ? L - 1 - cord_y(cords[a.second - 1]) : cord_y(cords[a.first]);
+            u64 y2 = cord_strand(cords[b.first]) ? L - 1 - cord_y(cords[b.second - 1]) : cord_y(cords[b.first]);
+            return y1 > y2;
+        });
+    for (u32 i = 0; i < nb; i++) sep_score[i] = (i32)((sep[i].second - sep[i].first) * 16);
+    chain_blocks_base(sink, cords, sep, sep_score, nb, L, 3, strand, 0, s);
+}
+LNR_HD inline int best_strand(const BlockSink &c1, const BlockSink &c2) {   // getChainBlocksBestStrand cluster_util.cpp:979-1019
+    u32 n = c1.nchains < c2.nchains ? c1.nchains : c2.nchains;
+    int l1 = 0, l2 = 0;
+    for (u32 i = 0; i < n; i++) {
+        for (i32 j = c1.off[i]; j < c1.off[i + 1]; j++) l1 += (int)(c1.el[j].second - c1.el[j].first);
+        for (i32 j = c2.off[i]; j < c2.off[i + 1]; j++) l2 += (int)(c2.el[j].second - c2.el[j].first);
+        if (l1 < l2) return 1;
+        else if (l1 > l2) return 0;
+    }
+    return 0;
+}
+LNR_HD inline void revert_chain_block_strand(BlockSink &cc, const u64 *cords, int strand) {   // cluster_util.cpp:1023-1063
+    u64 f_strand = strand ? 1 : 0;
+    for (u32 c = 0; c < cc.nchains; c++) {
+        UP *el = cc.el + cc.off[c];
+        u32 len = (u32)(cc.off[c + 1] - cc.off[c]) + 1;   // with the appended sentinel
+        u64 swap_str = 0, pre = 0, cur = 0;
+        for (u32 j = 0; j < len; j++) {
+            if (j == len - 1 || cord_strand(cords[el[j].first]) == f_strand) cur = 0;
+            else cur = 1;
+            if (cur && !pre) swap_str = j;
+            if (!cur && pre)
+                for (u32 k = (u32)swap_str; k < (swap_str + j) / 2; k++) rs_swap(el[k], el[swap_str + j - 1 - k]);
+            pre = cur;
+        }
+    }
+}
+LNR_HD inline u32 filter_blocks_cords(const BlockSink &ch, const u64 *hits, u64 *out, u64 major_limit) {   // _filterBlocksCords cluster_util.cpp:865-931 (f_header 1)
+    if (ch.nchains == 0) return 0xffffffffu;
+    u32 n = 0;
+    u64 len_current = 0;
+    out[n++] = hits[0];
+    for (i32 i = ch.off[0]; i < ch.off[1]; i++) {
+        for (u64 j = ch.el[i].first; j < ch.el[i].second; j++) out[n++] = hits[j] & ~F_END;
+        len_current += ch.el[i].second - ch.el[i].first;
+    }
+    out[n - 1] |= F_END;
+    float bound = 0.8 * len_current;
+    u32 major_n = 1;
+    for (u32 c = 1; c < ch.nchains && major_n < major_limit; c++) {
+        len_current = 0;
+        for (i32 j = ch.off[c]; j < ch.off[c + 1]; j++) len_current += ch.el[j].second - ch.el[j].first;
+        if ((float)len_current > bound) {
+            ++major_n;
+            for (i32 j = ch.off[c]; j < ch.off[c + 1]; j++)
+                for (u64 k = ch.el[j].first; k < ch.el[j].second; k++) out[n++] = hits[k] & ~F_END;
+            out[n - 1] |= F_END;
+        }
+    }
+    return n;
+}
+
+// ===================================================================== job ====
+// One seeding job = apxMap_ on [read_str, read_end) of one read (pmpfinder.cpp:2632-2707)
+// minus the seed lookup itself, which produced `a[0..n)` (a[0] is the dummy 0).
+struct JobCtx {
+    u64 L, read_str, read_end;
+    int mode;
+    FeatView f1[2];
+    GenomeFeat g;
+    u16 *bins; u32 nbins;
+    u64 *pair_evals;
+};
+// Everything after the ascending sort.  `a` = sorted anchors (n), scratch from `ar`.
+// Output: cords appended to `cords`.  Returns 0, or 1 on scratch/capacity overflow.
+struct JobDebug { u64 *filt; u32 *nfilt; u64 *xsort; u32 *nxsort; u64 *hits_chain; u32 *nhits_chain; u64 *hits_blocks; u32 *nhits_blocks; };
+
+LNR_HD inline int job_after_sort(u64 *a, u32 n_sorted, u32 cap, Arena &ar, const JobCtx &c, Vec<u64> &cords, JobDebug *dbg) {
+    int ovf = 0;
+    u32 m = n_sorted > 1 ? filter_anchor_list(a, n_sorted) : 0;   // filterAnchors1: n<=1 -> unchanged; see below
+    if (n_sorted <= 1) m = n_sorted;
+    if (dbg && dbg->filt) { for (u32 i = 0; i < m; i++) dbg->filt[i] = a[i]; *dbg->nfilt = m; }
+    // chainAnchorsHits pmpfinder.cpp:2448-2481
+    Vec<u64> hits; hits.init(ar.get<u64>(cap + 2), cap + 2, &ovf);
+    Vec<i32> hscore; hscore.init(ar.get<i32>(cap + 2), cap + 2, &ovf);
+    hits.push(F_END);     // initHits
+    hscore.push(0);       // initHitsScore
+    ref_sort(a, (long)m, [](const u64 &p, const u64 &q) { return anchor_x(p) > anchor_x(q); });
+    if (dbg && dbg->xsort) { for (u32 i = 0; i < m; i++) dbg->xsort[i] = a[i]; *dbg->nxsort = m; }
+    Rec rec;
+    rec.score = ar.get<i32>(cap + 2); rec.score2 = ar.get<i32>(cap + 2); rec.len = ar.get<i32>(cap + 2);
+    rec.p2 = ar.get<i32>(cap + 2); rec.root = ar.get<i32>(cap + 2); rec.leaf = ar.get<i32>(cap + 2);
+    i32 *chain = ar.get<i32>(cap + 2), *chain_sc = ar.get<i32>(cap + 2), *cnt = ar.get<i32>(cap + 2);
+    u32 *xs = ar.get<u32>(cap + 2), *ys = ar.get<u32>(cap + 2);
+    if (ar.ovf) return 1;
+    JobParm pm = job_parm(c.mode);
+    if (m >= 2) {
+        for (u32 i = 0; i < m; i++) { xs[i] = (u32)anchor_x(a[i]); ys[i] = (u32)cord_y(a[i]); }
+        best_chains_serial(xs, ys, m, rec, pm.score_type, c.pair_evals);
+        AnchorSink sink; sink.anchors = a; sink.hits = &hits; sink.hscore = &hscore; sink.first_len = 0; sink.nchains = 0;
+        traceback(rec, m, sink, chain, chain_sc, cnt, 1, 45, 50, 0.0f);
+    }
+    if (dbg && dbg->hits_chain) { for (u32 i = 0; i < hits.n; i++) dbg->hits_chain[i] = hits[i]; *dbg->nhits_chain = hits.n; }
+    // getAnchorHitsChains pmpfinder.cpp:2535-2545
+    Vec<UP> sep; sep.init(ar.get<UP>(cap + 2), cap + 2, &ovf);
+    gather_blocks(hits.p, hits.n, nullptr, sep, 1, hits.n, c.L, 600, 0, 0);
+    u64 *cuts = ar.get<u64>(2 * (u64)cap + 4), *xy_strs = ar.get<u64>(cap + 2);
+    Vec<UP> tmp; tmp.init(ar.get<UP>(cap + 2), cap + 2, &ovf);
+    if (ar.ovf) return 1;
+    prefilter_chains2(hits.p, hits.n, sep, cuts, xy_strs, tmp);
+    i32 *sep_score = ar.get<i32>(cap + 2);
+    for (u32 i = 0; i < sep.n; i++) sep_score[i] = hscore[(u32)sep[i].first] - hscore[(u32)sep[i].second - 1];
+    // chainBlocksHits cluster_util.cpp:721-732
+    BlockSink bs; bs.el = tmp.p; bs.off = chain; bs.nchains = 0; bs.nel = 0; bs.cap = cap + 2; bs.ovf = &ovf; bs.first_len = 0; bs.off[0] = 0;
+    BlockScratch s; s.ptr = xs; s.sep_tmp = (UP *)cuts; s.score_tmp = (i32 *)ys; s.rec = rec; s.chain = chain_sc; s.chain_sc = (i32 *)xy_strs; s.cnt = cnt;
+    chain_blocks_base(bs, hits.p, sep.p, sep_score, sep.n, c.L, 2, 0, 1, s);
+    u64 *hits2 = a;   // anchors are dead by now: reuse as the rewritten hits (cap+? slots: hits never exceed m+1 <= cap)
+    u32 nh2 = filter_blocks_hits(bs, hits.p, hits2);
+    u64 *H; u32 nH;
+    if (nh2 == 0xffffffffu) { H = hits.p; nH = hits.n; } else { H = hits2; nH = nh2; }
+    if (dbg && dbg->hits_blocks) { for (u32 i = 0; i < nH; i++) dbg->hits_blocks[i] = H[i]; *dbg->nhits_blocks = nH; }
+    if (ovf) return 1;
+    // path_dst alg 2 (pmpfinder.cpp:1447-1469)
+    if (nH >= 2) {
+        nH = filter_hits(H, nH, c.f1, c.g);
+        path_dst_2(H, nH, c.f1, c.g, cords, c.read_str, c.read_end, c.L);
+    }
+    return (ovf || *cords.ovf) ? 1 : 0;
+}
+
+// ==================================================================== tails ====
+// Tail A = apxMap between the first apxMap_ and the remap loop (pmpfinder.cpp:2744-2749):
+// clean, gather (sets block ends), gaps.  Returns the number of remap gaps written (0 = no remap).
+LNR_HD inline u32 drop_len_of(u64 L) { i64 d = (i64)((double)L * 0.05 / 96); return (u32)(d < 2 ? d : 2); }
+
+LNR_HD inline int tail_a(u64 *cords, u32 &ncords, u64 L, Arena &ar, UP *gaps_out, u32 gaps_cap, u32 &ngaps, u32 &remap) {
+    int ovf = 0;
+    ncords = clean_blocks(cords, ncords, drop_len_of(L));
+    u32 cap = ncords + 2;
+    Vec<UP> str_ends; str_ends.init(ar.get<UP>(cap), cap, &ovf);
+    Vec<UP> sep; sep.init(ar.get<UP>(cap), cap, &ovf);
+    if (ar.ovf) return 1;
+    gather_blocks(cords, ncords, &str_ends, sep, 1, ncords, L, 1000, 96, 1);
+    Vec<UP> gaps; gaps.init(gaps_out, gaps_cap, &ovf);
+    int sum = gather_gaps_y(str_ends.p, str_ends.n, gaps, L, 1000);
+    ngaps = gaps.n;
+    remap = ((float)sum / (float)L >= 0.7f) ? 1 : 0;
+    return ovf;
+}
+// Tail B = rest of apxMap (pmpfinder.cpp:2764-2801): re-gather, chain cord blocks on both strands, clean, flags.
+// out_str/out_end receive the final cords; returns count through nout.
+LNR_HD inline int tail_b(u64 *cords, u32 ncords, u64 L, Arena &ar, u64 *out_str, u64 *out_end, u32 out_cap, u32 &nout) {
+    int ovf = 0;
+    u32 cap = ncords + 2;
+    Vec<UP> sep; sep.init(ar.get<UP>(cap), cap, &ovf);
+    gather_blocks(cords, ncords, nullptr, sep, 1, ncords, L, 1000, 96, 1);
+    // chainBlocksCords cluster_util.cpp:1068-1102
+    u32 nb = sep.n;
+    UP *sep1 = ar.get<UP>(cap), *sep2 = ar.get<UP>(cap);
+    i32 *score1 = ar.get<i32>(cap), *score2 = ar.get<i32>(cap);
+    for (u32 i = 0; i < nb; i++) { sep1[i] = sep[i]; sep2[i] = sep[i]; }
+    BlockSink c1, c2;
+    c1.el = ar.get<UP>(cap + 1); c1.off = ar.get<i32>(cap + 2); c1.nchains = 0; c1.nel = 0; c1.cap = cap; c1.ovf = &ovf; c1.first_len = 0; c1.off[0] = 0;
+    c2.el = ar.get<UP>(cap + 1); c2.off = ar.get<i32>(cap + 2); c2.nchains = 0; c2.nel = 0; c2.cap = cap; c2.ovf = &ovf; c2.first_len = 0; c2.off[0] = 0;
+    BlockScratch s;
+    s.ptr = ar.get<u32>(cap); s.sep_tmp = ar.get<UP>(cap); s.score_tmp = ar.get<i32>(cap);
+    s.rec.score = ar.get<i32>(cap); s.rec.score2 = ar.get<i32>(cap); s.rec.len = ar.get<i32>(cap); s.rec.p2 = ar.get<i32>(cap); s.rec.root = ar.get<i32>(cap); s.rec.leaf = ar.get<i32>(cap);
+    s.chain = ar.get<i32>(cap); s.chain_sc = ar.get<i32>(cap); s.cnt = ar.get<i32>(cap);
+    UP *sep_tmp2 = ar.get<UP>(cap);
+    u64 *tmp_cords = ar.get<u64>(cap + 2);
+    if (ar.ovf) return 1;
+    chain_blocks_single_strand(cords, sep1, nb, score1, c1, 0, L, s);
+    // chains of strand 0 reference s.sep_tmp through copies in c1.el, so the scratch can be reused
+    BlockScratch s2 = s; s2.sep_tmp = sep_tmp2;
+    chain_blocks_single_strand(cords, sep2, nb, score2, c2, 1, L, s2);
+    int bst = best_strand(c1, c2);
+    BlockSink &cc = bst == 0 ? c1 : c2;
+    revert_chain_block_strand(cc, cords, bst);
+    u32 n2 = filter_blocks_cords(cc, cords, tmp_cords, 2);
+    u64 *C; u32 nC;
+    if (n2 == 0xffffffffu) { C = cords; nC = ncords; } else { C = tmp_cords; nC = n2; }
+    nC = clean_blocks(C, nC, drop_len_of(L));
+    if (nC > out_cap) { nout = 0; return 1; }
+    int seg = 0;
+    const u64 d = (96ULL << 20) + 96ULL;
+    for (u32 i = 0; i < nC; i++) {
+        u64 v = C[i];
+        if (seg) v |= F_RECD; else v &= ~F_RECD;
+        v |= F_MAIN;
+        if (is_end(v)) seg = 1 - seg;
+        out_str[i] = v;
+        out_end[i] = v + d;
+    }
+    nout = nC;
+    return ovf;
+}
+
+}  // namespace lnr

@@ -1,0 +1,247 @@
+// host_shim.cpp -- TEST-ONLY host build of the product's stage logic (linear_amd/csrc/lnr_hd.h,
+// ref_sort.h) so that the device code can be checked against the oracle on a machine
+// without a GPU.  It is compiled by tests/ into tests/_build/libhost_shim.so and is never
+// part of the shipped library: the product path runs these same functions inside HIP
+// kernels only (linear_amd/csrc/lnr_kernels.hip).
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include "../linear_amd/csrc/lnr_hd.h"
+
+using namespace lnr;
+
+namespace {
+const size_t PAD = 64;
+struct Shim {
+    std::vector<std::vector<u8>> seqs;
+    std::vector<u64> lens;
+    u32 T;
+    std::vector<i32> dir;
+    std::vector<u64> hs;
+    std::vector<F96> f2;
+    std::vector<u64> f2_off;
+    std::vector<u64> cs, ce;
+    u64 stats[5] = {0, 0, 0, 0, 0};
+    std::vector<u64> dbg[4];
+};
+
+void features_closed(const u8 *s, u64 n_entries, F96 *out) {
+    for (u64 m = 0; m < n_entries; m++) {
+        i32 w0 = 0, w1 = 0, w2 = 0;
+        for (u64 j = 16 * m; j < 16 * m + 48; j++) add2mer(w0, w1, w2, s[j], s[j + 1]);
+        out[m].v0 = w0; out[m].v1 = w1; out[m].v2 = w2; out[m].pad = 0;
+    }
+}
+
+void build_index(Shim &c) {
+    const size_t full = ((size_t)1 << 26) + 1;
+    std::vector<u32> Xs;
+    std::vector<u64> vals;
+    for (size_t i = 0; i < c.seqs.size(); i++) {
+        const u8 *s = c.seqs[i].data();
+        for (u32 t = 0; t < c.T; t++) {
+            i64 t_str, t_end;
+            chunk_bounds(c.lens[i], c.T, t, t_str, t_end);
+            if (t_str >= t_end) continue;
+            u64 ns = chunk_num_samples(t_str, t_end);
+            if (!ns) continue;
+            int ks = shape_init_skip(s + t_str);
+            int C = shape_const(s, (u64)t_str, ks, (u64)t_str);
+            u64 run_start = 0;
+            u32 prevX = 0;
+            for (u64 m = 0; m < ns; m++) {
+                u64 j = (u64)t_str + 8 + 9 * m;
+                SeedOut o = seed_sample(s, j, (u64)t_str, (u64)t_str, ks, C);
+                if (m == 0 || o.X != prevX) run_start = m;
+                prevX = o.X;
+                bool rec = ((m - run_start) & 1) == 0;   // recorded iff even position inside its run of equal minimizers
+                if (rec) { Xs.push_back(o.X); vals.push_back(create_cord(i, j + ANCHOR_ZERO, o.Y, o.strand)); }
+            }
+        }
+    }
+    c.dir.assign(full, 0);
+    for (u32 x : Xs) c.dir[x]++;
+    i64 sum = 0;
+    for (size_t i = 0; i < full; i++) {
+        if (c.dir[i] > 400) c.dir[i] = 0;
+        sum += c.dir[i];
+        c.dir[i] = (i32)(sum - c.dir[i]);
+    }
+    c.hs.assign((size_t)sum, 0);
+    std::vector<i32> fill(full, 0);
+    for (size_t k = 0; k < Xs.size(); k++) {
+        u32 x = Xs[k];
+        if (c.dir[x + 1] - c.dir[x]) c.hs[c.dir[x] + fill[x]++] = vals[k];
+    }
+    for (size_t i = 0; i + 1 < full; i++)
+        if (c.dir[i + 1] > c.dir[i]) std::sort(c.hs.begin() + c.dir[i], c.hs.begin() + c.dir[i + 1]);
+}
+
+void seed_lookup(Shim &c, const u8 *read, u64 L, u64 read_str, u64 read_end, int alpha, std::vector<u64> &a) {
+    int ks = shape_init_skip(read);
+    u64 k0 = read_str + 21;
+    int C = shape_const(read, 0, ks, k0);
+    u32 ns = seed_num_samples(read_str, read_end, (u32)alpha);
+    u32 xprev = 0;
+    for (u32 s = 0; s < ns; s++) {
+        u64 k = k0 + alpha - 1 + (u64)alpha * s;
+        SeedOut o = seed_sample(read, k, k0, 0, ks, C);
+        c.stats[0]++;
+        if (o.X != xprev) {
+            c.stats[1]++;
+            c.stats[2] += (u64)(c.dir[o.X + 1] - c.dir[o.X]);
+            for (i32 i = c.dir[o.X]; i < c.dir[o.X + 1]; i++)
+                if (y_match(cord_y(c.hs[i]), o.Y)) { a.push_back(val2anchor(c.hs[i], k, L, o.strand)); c.stats[3]++; }
+        }
+        xprev = o.X;
+    }
+}
+
+int run_job(Shim &c, const u8 *read, u64 L, u64 read_str, u64 read_end, int mode, const FeatView f1[2], Vec<u64> &cords, bool dbg) {
+    std::vector<u64> a;
+    a.push_back(0);
+    seed_lookup(c, read, L, read_str, read_end, job_parm(mode).alpha, a);
+    if (dbg) c.dbg[0] = a;
+    u32 n = (u32)a.size();
+    u32 cap = n + 2;
+    a.resize(cap);
+    u64 maxlen = 0;
+    for (u64 l : c.lens) maxlen = std::max(maxlen, l);
+    u32 nbins = (u32)((maxlen + (2ULL << 20)) / 30000 + 2);
+    std::vector<u16> bins(nbins, 0);
+    n = binning_filter_serial(a.data(), n, bins.data(), nbins);
+    if (n > 1) { a[0] = 0; std::sort(a.begin(), a.begin() + n); }
+    std::vector<char> scratch(job_scratch_bytes(cap));
+    Arena ar; ar.init(scratch.data(), scratch.size());
+    JobCtx jc;
+    jc.L = L; jc.read_str = read_str; jc.read_end = read_end; jc.mode = mode;
+    jc.f1[0] = f1[0]; jc.f1[1] = f1[1];
+    jc.g.base = c.f2.data(); jc.g.off = c.f2_off.data(); jc.g.nseq = (u32)c.seqs.size();
+    jc.bins = bins.data(); jc.nbins = nbins; jc.pair_evals = &c.stats[4];
+    JobDebug jd; memset(&jd, 0, sizeof(jd));
+    std::vector<u64> d1(cap), d2(cap), d3(cap + 2);
+    u32 n1 = 0, n2 = 0, n3 = 0;
+    if (dbg) { jd.filt = d1.data(); jd.nfilt = &n1; jd.xsort = d2.data(); jd.nxsort = &n2; jd.hits_chain = d3.data(); jd.nhits_chain = &n3; }
+    int rc = job_after_sort(a.data(), n, cap, ar, jc, cords, dbg ? &jd : nullptr);
+    if (dbg) { c.dbg[1].assign(d1.begin(), d1.begin() + n1); c.dbg[2].assign(d2.begin(), d2.begin() + n2); c.dbg[3].assign(d3.begin(), d3.begin() + n3); }
+    return rc;
+}
+
+int map_read(Shim &c, const u8 *read_in, u64 L, bool dbg) {
+    c.cs.clear(); c.ce.clear();
+    for (auto &d : c.dbg) d.clear();
+    if (L <= 200) return 0;
+    std::vector<u8> rd(L + PAD, 0), rc(L + PAD, 0);
+    memcpy(rd.data(), read_in, L);
+    static const u8 cpl[5] = {3, 2, 1, 0, 4};
+    for (u64 k = 0; k < L; k++) rc[k] = cpl[rd[L - 1 - k]];
+    u32 nf = read_feature_count(L);
+    std::vector<F96> f1a(nf), f1b(nf);
+    features_closed(rd.data(), nf, f1a.data());
+    features_closed(rc.data(), nf, f1b.data());
+    FeatView f1[2];
+    f1[0].p = f1a.data(); f1[0].n = nf; f1[1].p = f1b.data(); f1[1].n = nf;
+    u32 cap_c = (u32)(16 * (L / 64) + 256);
+    std::vector<u64> cords(cap_c);
+    int ovf = 0;
+    Vec<u64> cv; cv.init(cords.data(), cap_c, &ovf);
+    if (run_job(c, rd.data(), L, 0, L, 0, f1, cv, dbg)) return -1;
+    std::vector<char> scratch(tail_scratch_bytes(cap_c));
+    Arena ar; ar.init(scratch.data(), scratch.size());
+    std::vector<UP> gaps(cap_c);
+    u32 ngaps = 0, remap = 0, nc = cv.n;
+    if (tail_a(cords.data(), nc, L, ar, gaps.data(), cap_c, ngaps, remap)) return -2;
+    cv.n = nc;
+    if (remap) {
+        for (u32 i = 0; i < ngaps; i++) {
+            UP y = forward_y(gaps[i], L);
+            if (run_job(c, rd.data(), L, y.first, y.second, 1, f1, cv, false)) return -3;
+        }
+    }
+    ar.init(scratch.data(), scratch.size());
+    std::vector<u64> os(cap_c), oe(cap_c);
+    u32 nout = 0;
+    if (tail_b(cords.data(), cv.n, L, ar, os.data(), oe.data(), cap_c, nout)) return -4;
+    c.cs.assign(os.begin(), os.begin() + nout);
+    c.ce.assign(oe.begin(), oe.begin() + nout);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+void *hs_create(const u8 *const *seqs, const u64 *lens, u32 nseq, u32 T) {
+    Shim *c = new Shim();
+    c->T = T ? T : 1;
+    c->f2_off.push_back(0);
+    for (u32 i = 0; i < nseq; i++) {
+        c->seqs.emplace_back(lens[i] + PAD, 0);
+        memcpy(c->seqs.back().data(), seqs[i], lens[i]);
+        c->lens.push_back(lens[i]);
+        c->f2_off.push_back(c->f2_off.back() + genome_feature_count(lens[i]));
+    }
+    c->f2.resize(c->f2_off.back());
+    for (u32 i = 0; i < nseq; i++) features_closed(c->seqs[i].data(), c->f2_off[i + 1] - c->f2_off[i], c->f2.data() + c->f2_off[i]);
+    build_index(*c);
+    return c;
+}
+void hs_destroy(void *h) { delete (Shim *)h; }
+u64 hs_dir_len(void *h) { return ((Shim *)h)->dir.size(); }
+u64 hs_hs_len(void *h) { return ((Shim *)h)->hs.size(); }
+const i32 *hs_dir(void *h) { return ((Shim *)h)->dir.data(); }
+const u64 *hs_hs(void *h) { return ((Shim *)h)->hs.data(); }
+u64 hs_f2_len(void *h, u32 id) { Shim *c = (Shim *)h; return c->f2_off[id + 1] - c->f2_off[id]; }
+void hs_f2(void *h, u32 id, i32 *out) {
+    Shim *c = (Shim *)h;
+    for (u64 k = c->f2_off[id]; k < c->f2_off[id + 1]; k++) { *out++ = c->f2[k].v0; *out++ = c->f2[k].v1; *out++ = c->f2[k].v2; }
+}
+u64 hs_read_features(const u8 *read, u64 L, int strand, i32 *out, u64 cap) {
+    std::vector<u8> s(L + PAD, 0);
+    static const u8 cpl[5] = {3, 2, 1, 0, 4};
+    if (strand) for (u64 k = 0; k < L; k++) s[k] = cpl[read[L - 1 - k]];
+    else memcpy(s.data(), read, L);
+    u32 nf = read_feature_count(L);
+    std::vector<F96> f(nf);
+    features_closed(s.data(), nf, f.data());
+    for (u32 k = 0; k < nf && k < cap; k++) { out[3 * k] = f[k].v0; out[3 * k + 1] = f[k].v1; out[3 * k + 2] = f[k].v2; }
+    return nf;
+}
+u64 hs_seed_lookup(void *h, const u8 *read, u64 L, u64 read_str, u64 read_end, int alpha, u64 *out, u64 cap, u64 *stats4) {
+    Shim *c = (Shim *)h;
+    std::vector<u8> s(L + PAD, 0);
+    memcpy(s.data(), read, L);
+    std::vector<u64> a;
+    a.push_back(0);
+    memset(c->stats, 0, sizeof(c->stats));
+    seed_lookup(*c, s.data(), L, read_str, read_end, alpha, a);
+    if (out) memcpy(out, a.data(), std::min<u64>(a.size(), cap) * 8);
+    if (stats4) for (int i = 0; i < 4; i++) stats4[i] = c->stats[i];
+    return a.size();
+}
+long hs_map_read(void *h, const u8 *read, u64 L, int dbg) {
+    Shim *c = (Shim *)h;
+    int rc = map_read(*c, read, L, dbg != 0);
+    if (rc) return rc;
+    return (long)c->cs.size();
+}
+void hs_get_cords(void *h, u64 *cs, u64 *ce) {
+    Shim *c = (Shim *)h;
+    if (!c->cs.empty()) { memcpy(cs, c->cs.data(), c->cs.size() * 8); memcpy(ce, c->ce.data(), c->ce.size() * 8); }
+}
+u64 hs_debug_get(void *h, int stage, u64 *out, u64 cap) {
+    Shim *c = (Shim *)h;
+    if (stage < 0 || stage > 3) return 0;
+    if (out) memcpy(out, c->dbg[stage].data(), std::min<u64>(c->dbg[stage].size(), cap) * 8);
+    return c->dbg[stage].size();
+}
+void hs_get_stats(void *h, u64 *out5) { memcpy(out5, ((Shim *)h)->stats, 40); }
+
+// fuzz hook for ref_sort: sorts keys (compare on the high 32 bits only, descending when desc != 0)
+void hs_ref_sort_hi32(u64 *a, u64 n, int desc) {
+    if (desc) ref_sort(a, (long)n, [](const u64 &x, const u64 &y) { return (x >> 32) > (y >> 32); });
+    else ref_sort(a, (long)n, [](const u64 &x, const u64 &y) { return (x >> 32) < (y >> 32); });
+}
+void hs_std_sort_hi32(u64 *a, u64 n, int desc) {
+    if (desc) std::sort(a, a + n, [](const u64 &x, const u64 &y) { return (x >> 32) > (y >> 32); });
+    else std::sort(a, a + n, [](const u64 &x, const u64 &y) { return (x >> 32) < (y >> 32); });
+}
+}

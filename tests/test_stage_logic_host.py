@@ -1,0 +1,66 @@
+"""CPU: the product's stage logic (linear_amd/csrc/lnr_hd.h + ref_sort.h -- the code the HIP
+kernels execute) compiled for the host, against the oracle and the reference's goldens.
+Bit-exact (integer words)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases, shimlib
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+PARAMS = [(n, T) for n, (_, Ts) in cases.CASES.items() for T in Ts]
+
+
+def test_ref_sort_equals_libstdcxx_sort_with_ties():
+    """ref_sort must reproduce std::sort's permutation for tied keys."""
+    shimlib.build()
+    lib = C.CDLL(shimlib.SO)
+    p = C.POINTER(C.c_uint64)
+    rng = np.random.default_rng(7)
+    for it in range(400):
+        n = int(rng.integers(0, 60)) if it % 3 == 0 else int(rng.integers(0, 5000))
+        if it % 97 == 0:
+            n = 150_000
+        keys = int(rng.integers(1, 12)) if it % 2 else int(rng.integers(1, 2000))
+        a = (rng.integers(0, keys, size=n).astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        if it % 4 == 1:
+            a.sort()
+        if it % 4 == 2:
+            a = np.sort(a)[::-1].copy()
+        for desc in (0, 1):
+            b, c = a.copy(), a.copy()
+            lib.hs_ref_sort_hi32(b.ctypes.data_as(p), C.c_uint64(n), desc)
+            lib.hs_std_sort_hi32(c.ctypes.data_as(p), C.c_uint64(n), desc)
+            assert np.array_equal(b, c), f"n={n} keys={keys} desc={desc}"
+
+
+@pytest.mark.parametrize("name,T", PARAMS)
+def test_stage_logic_matches_golden(case_inputs, name, T):
+    refs, reads, off = case_inputs(name)
+    g = np.load(os.path.join(GOLD, f"{name}_T{T}.npz"))
+    s = shimlib.Shim(refs, T)
+    # closed-form minimizer sampling + "even position in run" rule == the reference's rolling two-pass build
+    assert cases.sha(s.dir()) == str(g["dir_sha"])
+    assert cases.sha(s.hs()) == str(g["hs_sha"])
+    for k in range(len(refs)):
+        f2 = s.f2(k)
+        assert f2.shape[0] == int(g["f2_len"][k]) and cases.sha(f2[:-1]) == str(g["f2_sha"][k])
+    for k, i in enumerate(g["stage_reads"]):
+        rd = reads[int(off[i]):int(off[i + 1])]
+        a, _ = s.seed_lookup(rd)
+        assert np.array_equal(a, g[f"st{k}_raw"])
+        a7, _ = s.seed_lookup(rd, 100, rd.size - 50, 7)
+        assert np.array_equal(a7, g[f"st{k}_raw7"])
+        assert np.array_equal(s.read_features(rd, 0), g[f"st{k}_f1fwd"])
+        assert np.array_equal(s.read_features(rd, 1), g[f"st{k}_f1rev"])
+        s.map_read(rd, dbg=True)
+        for st, nm in ((1, "filt"), (2, "xsort"), (3, "hits")):
+            assert np.array_equal(s.stage(st), g[f"st{k}_{nm}"]), f"stage {nm} read {i}"
+    coff = g["cord_off"]
+    for i in range(off.size - 1):
+        cs, ce = s.map_read(reads[int(off[i]):int(off[i + 1])])
+        assert np.array_equal(cs, g["cords_str"][int(coff[i]):int(coff[i + 1])]), f"read {i}"
+        assert np.array_equal(ce, g["cords_end"][int(coff[i]):int(coff[i + 1])]), f"read {i}"
+    s.close()
