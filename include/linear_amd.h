@@ -1,0 +1,149 @@
+/* linear_amd.h -- C ABI of the MI355X-native `linear filter` hot path.
+ *
+ * Drop-in boundary for the compute path of xp3i4/linear's `Mapper` (reference paths are
+ * relative to the reference root):
+ *
+ *   reference entry point                                     replaced by
+ *   --------------------------------------------------------  --------------------------
+ *   createFeatures(genomes, f2, type, T)  pmpfinder.h:196-197  \
+ *   Mapper::createIndex -> createIndexDynamic(seqs, index,      } lnr_index_build
+ *       gstr, gend, threads, efficient)   index_util.h:297-302 /
+ *   body of the `for j` loop in Mapper::p_calRecords            lnr_filter_batch
+ *       (mapper.cpp:438-462): _compltRvseStr + createFeatures
+ *       (read) x2 + apxMap(...)           pmpfinder.h:213-225
+ *   getDIndexMatchAll (stage a7)          pmpfinder.cpp:1856    lnr_seed_lookup_batch
+ *
+ * Sequences are SeqAn `Dna5` ordinals, one byte per base (A,C,G,T,N = 0..4): exactly the
+ * storage of `String<Dna5>` (begin pointer + length), so `&read[0]` / `length(read)` bind
+ * directly.  Results are the reference's 64-bit cord words
+ * (main[63] recd[62] strand[61] blockEnd[60] id[50..59] x[20..49] y[0..19], cords.h:24-39),
+ * `cords_str[j]` and `cords_end[j]` of every read in CSR form.
+ *
+ * Plain C: pointers and sizes only.  No exceptions cross this boundary; every call returns
+ * LNR_OK (0) or a negative lnr_status.  A context is single-threaded and owns one GPU; use
+ * one context per GPU / per process (reads shard across contexts, the index is identical).
+ * The library has no CPU execution path: without a HIP device lnr_create fails with
+ * LNR_ERR_NO_DEVICE.
+ */
+#ifndef LINEAR_AMD_H
+#define LINEAR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lnr_ctx lnr_ctx;
+
+typedef enum lnr_status {
+    LNR_OK = 0,
+    LNR_ERR_ARG = -1,         /* bad argument (null pointer, base value > 4, >= 1024 sequences, ...) */
+    LNR_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    LNR_ERR_HIP = -3,         /* a HIP runtime call failed; see lnr_last_error */
+    LNR_ERR_NOMEM = -4,       /* device or host allocation failed */
+    LNR_ERR_NO_INDEX = -5,    /* filter/seed call before lnr_index_build / lnr_index_adopt */
+    LNR_ERR_LIMIT = -6,       /* input exceeds a format limit (read >= 2^20, sequence >= 2^30 - 2^20; cords.cpp:13-15) */
+    LNR_ERR_UNSUPPORTED = -7, /* option outside this build (index_type != 1, feature_type != 2, gap_len != 0) */
+    LNR_ERR_INTERNAL = -8     /* device-side capacity overflow that retries could not resolve */
+} lnr_status;
+
+/* Options = the subset of the reference's `Options` (base.cpp:26-54) that reaches this path. */
+typedef struct lnr_opts {
+    int32_t device;            /* HIP device ordinal; -1 = current device */
+    uint32_t index_type;       /* -i : 1 = DIndex (reference default).  2 (HIndex) not built yet */
+    uint32_t feature_type;     /* -f : 2 = 2-mer/48 window features (reference default) */
+    uint32_t preset;           /* -p : 1 (reference default: chain stop ratio 0) */
+    uint32_t gap_len;          /* -g : must be 0 here (apxMap only; gap re-mapper is next tier) */
+    uint32_t reserved0;
+    uint64_t scratch_budget;   /* max bytes of per-read device scratch in flight (0 = default 24 GiB) */
+} lnr_opts;
+
+typedef struct lnr_index_info {
+    uint32_t nseq;
+    uint32_t layout_threads;   /* the reference's -t the index layout reproduces */
+    uint64_t genome_bytes;     /* padded device copy of the sequences */
+    uint64_t dir_len;          /* int32 entries (4^13 + 1) */
+    uint64_t hs_len;           /* uint64 entries */
+    uint64_t f2_len;           /* 16-byte feature entries over all sequences */
+    uint64_t n_samples;        /* genome minimizer samples examined */
+    double build_ms;           /* device time of the last build */
+} lnr_index_info;
+
+/* CSR result of a batch.  Host arrays owned by the context, valid until the next
+ * lnr_filter_batch / lnr_seed_lookup_batch on the same context or lnr_destroy. */
+typedef struct lnr_cords {
+    uint32_t n_reads;
+    uint64_t n_cords;
+    const uint64_t *cord_off;   /* n_reads + 1 */
+    const uint64_t *cords_str;  /* n_cords */
+    const uint64_t *cords_end;  /* n_cords */
+} lnr_cords;
+
+/* Same, device resident (for callers that keep results on the GPU, and for benchmarking). */
+typedef struct lnr_cords_dev {
+    uint32_t n_reads;
+    uint64_t n_cords;
+    const uint64_t *d_cord_off;
+    const uint64_t *d_cords_str;
+    const uint64_t *d_cords_end;
+} lnr_cords_dev;
+
+typedef struct lnr_anchors {    /* stage a7 output: raw anchors per read, each list led by the dummy 0 */
+    uint32_t n_reads;
+    uint64_t n_anchors;
+    const uint64_t *anchor_off; /* n_reads + 1 */
+    const uint64_t *anchors;
+} lnr_anchors;
+
+/* Counters and device timings of the last batch call (deterministic functions of index + reads,
+ * except the *_ms fields).  seed_bytes is SURVEY.md 8(d)'s algorithmic byte count
+ * sum(ceil(L/4)) + lookups*8 + bucket_entries*8 + anchors*8. */
+typedef struct lnr_stats {
+    uint64_t reads, bases, jobs, samples, lookups, bucket_entries, anchors, remap_reads, cords;
+    uint64_t seed_bytes;
+    double prep_ms, seed_count_ms, seed_gather_ms, job_ms, tail_ms, total_ms;
+    uint32_t seed_count_launches, seed_gather_launches, job_launches;
+} lnr_stats;
+
+void lnr_opts_default(lnr_opts *o);
+lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out);
+void lnr_destroy(lnr_ctx *ctx);
+const char *lnr_strerror(lnr_status s);
+const char *lnr_last_error(const lnr_ctx *ctx);   /* detail of the last failure on this context */
+
+/* Index + genome features from host sequences.  layout_threads = the reference's -t whose
+ * DIndex layout is to be reproduced (index content depends on it: index_util.cpp:1652-1700). */
+lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64_t *len, uint32_t nseq, uint32_t layout_threads);
+lnr_status lnr_index_info_get(const lnr_ctx *ctx, lnr_index_info *info);
+/* Copy the index to host arrays (any pointer may be NULL).  f2 is written as 3 x int32 per entry. */
+lnr_status lnr_index_export(lnr_ctx *ctx, int32_t *dir, uint64_t *hs, int32_t *f2, uint64_t *f2_off /* nseq+1 */);
+
+/* Multi-GPU: the packed index is built on one rank and broadcast (RCCL) to the others.
+ * lnr_index_blob_* expose the device buffers that make up the index so the host framework can
+ * broadcast them in place: rank 0 calls lnr_index_build, every rank exchanges lnr_index_info +
+ * the sequence lengths, the receiving ranks call lnr_index_alloc, then all ranks broadcast each
+ * blob (ptr, bytes) and the receivers finish with lnr_index_adopt. */
+#define LNR_INDEX_BLOBS 4       /* genome bytes, dir, hs, f2 */
+lnr_status lnr_index_alloc(lnr_ctx *ctx, const lnr_index_info *info, const uint64_t *seq_len /* nseq */);
+lnr_status lnr_index_blob(lnr_ctx *ctx, uint32_t which, void **d_ptr, uint64_t *bytes);
+lnr_status lnr_index_adopt(lnr_ctx *ctx);
+
+/* The hot path.  reads_concat = bases of all reads back to back, off[n+1] = start offsets.
+ * Host-buffer form (copies in and out over PCIe): */
+lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads_concat, const uint64_t *off, uint32_t n, lnr_cords *out);
+/* Device-buffer form: d_reads_concat / d_off already in HBM; results stay in HBM. */
+lnr_status lnr_filter_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads_concat, const uint64_t *d_off, uint32_t n, lnr_cords_dev *out);
+/* Copy the last device result to the context's host arrays. */
+lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out);
+
+/* Stage a7 only (seed lookup on [0, L) with sampling step 15), for parity tests and the roofline measurement. */
+lnr_status lnr_seed_lookup_batch(lnr_ctx *ctx, const uint8_t *reads_concat, const uint64_t *off, uint32_t n, lnr_anchors *out);
+lnr_status lnr_seed_lookup_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads_concat, const uint64_t *d_off, uint32_t n);
+
+lnr_status lnr_last_stats(const lnr_ctx *ctx, lnr_stats *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

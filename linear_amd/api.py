@@ -1,0 +1,205 @@
+"""Python binding (ctypes) of the C ABI in include/linear_amd.h.
+
+Thin plumbing only: numpy / torch buffers in, the reference's cord words out.  There is no
+Python or CPU implementation of the path here; if liblinear_amd.so is missing or no GPU is
+usable, construction raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "liblinear_amd.so")
+
+_u8p, _u64p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+
+
+class LnrOpts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("index_type", C.c_uint32), ("feature_type", C.c_uint32), ("preset", C.c_uint32),
+                ("gap_len", C.c_uint32), ("reserved0", C.c_uint32), ("scratch_budget", C.c_uint64)]
+
+
+class LnrIndexInfo(C.Structure):
+    _fields_ = [("nseq", C.c_uint32), ("layout_threads", C.c_uint32), ("genome_bytes", C.c_uint64), ("dir_len", C.c_uint64),
+                ("hs_len", C.c_uint64), ("f2_len", C.c_uint64), ("n_samples", C.c_uint64), ("build_ms", C.c_double)]
+
+
+class LnrCords(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_cords", C.c_uint64), ("cord_off", _u64p), ("cords_str", _u64p), ("cords_end", _u64p)]
+
+
+class LnrCordsDev(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_cords", C.c_uint64), ("d_cord_off", C.c_void_p), ("d_cords_str", C.c_void_p), ("d_cords_end", C.c_void_p)]
+
+
+class LnrAnchors(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_anchors", C.c_uint64), ("anchor_off", _u64p), ("anchors", _u64p)]
+
+
+class LnrStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("reads", "bases", "jobs", "samples", "lookups", "bucket_entries", "anchors", "remap_reads", "cords", "seed_bytes")] + \
+               [(k, C.c_double) for k in ("prep_ms", "seed_count_ms", "seed_gather_ms", "job_ms", "tail_ms", "total_ms")] + \
+               [(k, C.c_uint32) for k in ("seed_count_launches", "seed_gather_launches", "job_launches")]
+
+
+class LnrError(RuntimeError):
+    def __init__(self, status: int, msg: str, detail: str = ""):
+        super().__init__(f"linear_amd: {msg} (status {status}){': ' + detail if detail else ''}")
+        self.status = status
+
+
+EXPORTS = ["lnr_opts_default", "lnr_create", "lnr_destroy", "lnr_strerror", "lnr_last_error", "lnr_index_build", "lnr_index_info_get",
+           "lnr_index_export", "lnr_index_alloc", "lnr_index_blob", "lnr_index_adopt", "lnr_filter_batch", "lnr_filter_batch_dev",
+           "lnr_cords_to_host", "lnr_seed_lookup_batch", "lnr_seed_lookup_batch_dev", "lnr_last_stats"]
+
+
+def load_library() -> C.CDLL:
+    if not os.path.exists(SO):
+        raise LnrError(-2, "liblinear_amd.so is not built (run linear_amd.build.build()); there is no fallback path")
+    lib = C.CDLL(SO)
+    lib.lnr_strerror.restype = C.c_char_p
+    lib.lnr_strerror.argtypes = [C.c_int]
+    lib.lnr_last_error.restype = C.c_char_p
+    lib.lnr_last_error.argtypes = [C.c_void_p]
+    lib.lnr_opts_default.argtypes = [C.POINTER(LnrOpts)]
+    lib.lnr_create.argtypes = [C.POINTER(LnrOpts), C.POINTER(C.c_void_p)]
+    lib.lnr_destroy.argtypes = [C.c_void_p]
+    lib.lnr_index_build.argtypes = [C.c_void_p, C.POINTER(_u8p), _u64p, C.c_uint32, C.c_uint32]
+    lib.lnr_index_info_get.argtypes = [C.c_void_p, C.POINTER(LnrIndexInfo)]
+    lib.lnr_index_export.argtypes = [C.c_void_p, _i32p, _u64p, _i32p, _u64p]
+    lib.lnr_index_alloc.argtypes = [C.c_void_p, C.POINTER(LnrIndexInfo), _u64p]
+    lib.lnr_index_blob.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), _u64p]
+    lib.lnr_index_adopt.argtypes = [C.c_void_p]
+    lib.lnr_filter_batch.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.POINTER(LnrCords)]
+    lib.lnr_filter_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(LnrCordsDev)]
+    lib.lnr_cords_to_host.argtypes = [C.c_void_p, C.POINTER(LnrCords)]
+    lib.lnr_seed_lookup_batch.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.POINTER(LnrAnchors)]
+    lib.lnr_seed_lookup_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.lnr_last_stats.argtypes = [C.c_void_p, C.POINTER(LnrStats)]
+    return lib
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+class Filter:
+    """One context = one GPU.  Mirrors the Mapper's compute interface: build the index once, then filter read blocks."""
+
+    def __init__(self, device: int = -1, scratch_budget: int = 0):
+        self.lib = load_library()
+        o = LnrOpts()
+        self.lib.lnr_opts_default(C.byref(o))
+        o.device = device
+        o.scratch_budget = scratch_budget
+        h = C.c_void_p()
+        st = self.lib.lnr_create(C.byref(o), C.byref(h))
+        if st != 0:
+            raise LnrError(st, self.lib.lnr_strerror(st).decode())
+        self.h = h
+        self._seq_len = None
+
+    def _ck(self, st: int):
+        if st != 0:
+            raise LnrError(st, self.lib.lnr_strerror(st).decode(), self.lib.lnr_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lnr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- index
+    def build_index(self, seqs: list[np.ndarray], layout_threads: int = 1) -> "LnrIndexInfo":
+        seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+        ptrs = (_u8p * len(seqs))(*[_p(s, _u8p) for s in seqs])
+        lens = np.array([s.size for s in seqs], dtype=np.uint64)
+        self._ck(self.lib.lnr_index_build(self.h, ptrs, _p(lens, _u64p), len(seqs), layout_threads))
+        self._seq_len = lens
+        return self.index_info()
+
+    def index_info(self) -> "LnrIndexInfo":
+        info = LnrIndexInfo()
+        self._ck(self.lib.lnr_index_info_get(self.h, C.byref(info)))
+        return info
+
+    def index_export(self):
+        info = self.index_info()
+        dir_ = np.zeros(info.dir_len, np.int32)
+        hs = np.zeros(max(info.hs_len, 1), np.uint64)
+        f2 = np.zeros((max(info.f2_len, 1), 3), np.int32)
+        f2_off = np.zeros(info.nseq + 1, np.uint64)
+        self._ck(self.lib.lnr_index_export(self.h, _p(dir_, _i32p), _p(hs, _u64p), _p(f2, _i32p), _p(f2_off, _u64p)))
+        return dir_, hs[:info.hs_len], f2[:info.f2_len], f2_off
+
+    def index_blobs(self):
+        """(device pointer, bytes) of the four index buffers (genome, dir, hs, f2) for an in-place RCCL broadcast."""
+        out = []
+        for k in range(4):
+            p, b = C.c_void_p(), C.c_uint64()
+            self._ck(self.lib.lnr_index_blob(self.h, k, C.byref(p), C.byref(b)))
+            out.append((p.value, b.value))
+        return out
+
+    def index_alloc(self, info: "LnrIndexInfo", seq_len: np.ndarray):
+        seq_len = np.ascontiguousarray(seq_len, dtype=np.uint64)
+        self._ck(self.lib.lnr_index_alloc(self.h, C.byref(info), _p(seq_len, _u64p)))
+        self._seq_len = seq_len
+
+    def index_adopt(self):
+        self._ck(self.lib.lnr_index_adopt(self.h))
+
+    # --------------------------------------------------------------- batches
+    def filter_batch(self, reads: np.ndarray, off: np.ndarray):
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = off.size - 1
+        out = LnrCords()
+        self._ck(self.lib.lnr_filter_batch(self.h, _p(reads, _u8p), _p(off, _u64p), n, C.byref(out)))
+        return self._cords_np(out)
+
+    @staticmethod
+    def _cords_np(out: "LnrCords"):
+        n = out.n_reads
+        coff = np.ctypeslib.as_array(out.cord_off, shape=(n + 1,)).copy()
+        if out.n_cords:
+            cs = np.ctypeslib.as_array(out.cords_str, shape=(out.n_cords,)).copy()
+            ce = np.ctypeslib.as_array(out.cords_end, shape=(out.n_cords,)).copy()
+        else:
+            cs, ce = np.zeros(0, np.uint64), np.zeros(0, np.uint64)
+        return coff, cs, ce
+
+    def filter_batch_dev(self, d_reads_ptr: int, d_off_ptr: int, n: int) -> "LnrCordsDev":
+        out = LnrCordsDev()
+        self._ck(self.lib.lnr_filter_batch_dev(self.h, C.c_void_p(d_reads_ptr), C.c_void_p(d_off_ptr), n, C.byref(out)))
+        return out
+
+    def cords_to_host(self):
+        out = LnrCords()
+        self._ck(self.lib.lnr_cords_to_host(self.h, C.byref(out)))
+        return self._cords_np(out)
+
+    def seed_lookup_batch(self, reads: np.ndarray, off: np.ndarray):
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = off.size - 1
+        out = LnrAnchors()
+        self._ck(self.lib.lnr_seed_lookup_batch(self.h, _p(reads, _u8p), _p(off, _u64p), n, C.byref(out)))
+        aoff = np.ctypeslib.as_array(out.anchor_off, shape=(n + 1,)).copy()
+        a = np.ctypeslib.as_array(out.anchors, shape=(out.n_anchors,)).copy() if out.n_anchors else np.zeros(0, np.uint64)
+        return aoff, a
+
+    def seed_lookup_batch_dev(self, d_reads_ptr: int, d_off_ptr: int, n: int):
+        self._ck(self.lib.lnr_seed_lookup_batch_dev(self.h, C.c_void_p(d_reads_ptr), C.c_void_p(d_off_ptr), n))
+
+    def stats(self) -> dict:
+        st = LnrStats()
+        self._ck(self.lib.lnr_last_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in LnrStats._fields_}

@@ -1,0 +1,41 @@
+"""Builds linear_amd/liblinear_amd.so (the HIP library behind include/linear_amd.h) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this also runs in the authoring container; the resulting .so
+travels to the GPU box with the snapshot."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "liblinear_amd.so")
+SOURCES = ["lnr_api.hip", "lnr_kernels.hip", "lnr_hd.h", "ref_sort.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def hipcc_path() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the MI355X library cannot be built")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "linear_amd.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False) -> str:
+    if force or needs_build():
+        cmd = [hipcc_path()] + FLAGS + ["-o", SO, os.path.join(CSRC, "lnr_api.hip")]
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,821 @@
+// lnr_api.hip -- C ABI (include/linear_amd.h) of the MI355X filter hot path: context, device memory,
+// index build orchestration and the per-batch kernel pipeline.  Device code: lnr_kernels.hip + lnr_hd.h.
+//
+// There is no CPU execution path in this library: every stage runs in a HIP kernel, and every entry
+// point fails (LNR_ERR_NO_DEVICE / LNR_ERR_HIP) when no GPU is usable.
+#include "lnr_kernels.hip"
+#include "../../include/linear_amd.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lnr;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap && p) return true;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t nc = bytes + bytes / 8 + 4096;
+        if (hipMalloc(&p, nc) != hipSuccess) { p = nullptr; cap = 0; (void)hipGetLastError(); return false; }
+        cap = nc;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    template <class T> T *as() const { return (T *)p; }
+};
+
+static const u64 SEQ_PAD = 64;
+static inline u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    void init() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+    void destroy() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    void start(hipStream_t s) { (void)hipEventRecord(a, s); }
+    void stop(hipStream_t s) { (void)hipEventRecord(b, s); }
+    double ms() { float f = 0; if (hipEventSynchronize(b) != hipSuccess) return 0; (void)hipEventElapsedTime(&f, a, b); return f; }
+};
+
+}  // namespace
+
+struct lnr_ctx {
+    lnr_opts opts;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // ---- index
+    bool has_index = false;
+    lnr_index_info info{};
+    std::vector<u64> seq_len, seq_off, f2_off;
+    u32 nbins = 0;
+    DevBuf g, dir, hs, f2, d_seq_off, d_f2_off;
+    // ---- batch inputs / per-read arrays
+    DevBuf in_reads, in_off;                       // staging for the host-buffer entry points
+    DevBuf reads_p, rp_off, lpad, rlen, rks, nf, f1_off, f1;
+    DevBuf cords, out_str, out_end, cords_off, cords_cap, ncords, nout, read_err;
+    DevBuf tail_scr, tail_off, tail_cap, gaps, gaps_off, gaps_cap, ngaps, remap;
+    // ---- jobs
+    DevBuf j_read, j_str, j_end, j_mode, j_samp_off, j_cap, j_look, j_anc_off, j_scr_off, j_nanc, grp_beg;
+    DevBuf samp, anchors, job_scr;
+    // ---- results
+    DevBuf r_off, r_str, r_end;
+    std::vector<u64> h_cord_off, h_cords_str, h_cords_end, h_anchor_off, h_anchors;
+    u32 last_n = 0;
+    u64 last_ncords = 0;
+    lnr_stats stats{};
+    Timer t_prep, t_sc, t_sg, t_job, t_tail, t_total;
+};
+
+namespace {
+
+#define HIPCK(call)                                                                                  \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            char b_[256];                                                                            \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            ctx->err = b_;                                                                           \
+            (void)hipGetLastError();                                                                 \
+            return LNR_ERR_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+#define ENSURE(buf, bytes)                                                                           \
+    do {                                                                                             \
+        if (!(buf).ensure(bytes)) {                                                                  \
+            char b_[160];                                                                            \
+            snprintf(b_, sizeof b_, "device allocation of %zu bytes failed (%s:%d)", (size_t)(bytes), __FILE__, __LINE__); \
+            ctx->err = b_;                                                                           \
+            return LNR_ERR_NOMEM;                                                                    \
+        }                                                                                            \
+    } while (0)
+#define KCHECK() HIPCK(hipGetLastError())
+
+template <class T>
+lnr_status upload(lnr_ctx *ctx, DevBuf &b, const std::vector<T> &v) {
+    ENSURE(b, std::max<size_t>(v.size() * sizeof(T), 16));
+    if (!v.empty()) HIPCK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return LNR_OK;
+}
+
+// exclusive scan of n int32 on the device (in -> out), tmp = block sums
+lnr_status dev_scan_i32(lnr_ctx *ctx, const i32 *in, i32 *out, u64 n, DevBuf &tmp) {
+    u32 nblk = (u32)((n + SCAN_BLK - 1) / SCAN_BLK);
+    ENSURE(tmp, (size_t)nblk * 4 + 16);
+    hipLaunchKernelGGL(k_scan_blk, dim3(nblk), dim3(SCAN_TPB), 0, ctx->stream, in, out, n, tmp.as<i32>());
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ctx->stream, tmp.as<i32>(), nblk);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(SCAN_TPB), 0, ctx->stream, out, n, tmp.as<i32>());
+    KCHECK();
+    return LNR_OK;
+}
+
+void set_index_layout(lnr_ctx *ctx, const u64 *len, u32 nseq) {
+    ctx->seq_len.assign(len, len + nseq);
+    ctx->seq_off.assign(nseq, 0);
+    ctx->f2_off.assign(nseq + 1, 0);
+    u64 o = 0, maxlen = 0;
+    for (u32 i = 0; i < nseq; i++) {
+        ctx->seq_off[i] = o;
+        o += align_up(len[i] + SEQ_PAD, 64);
+        ctx->f2_off[i + 1] = ctx->f2_off[i] + genome_feature_count(len[i]);
+        maxlen = std::max(maxlen, len[i]);
+    }
+    ctx->info.nseq = nseq;
+    ctx->info.genome_bytes = o;
+    ctx->info.dir_len = ((u64)1 << 26) + 1;
+    ctx->info.f2_len = ctx->f2_off[nseq];
+    ctx->nbins = (u32)((maxlen + (2ULL << 20)) / 30000 + 2);
+}
+
+lnr_status upload_index_layout(lnr_ctx *ctx) {
+    lnr_status s;
+    if ((s = upload(ctx, ctx->d_seq_off, ctx->seq_off)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->d_f2_off, ctx->f2_off)) != LNR_OK) return s;
+    return LNR_OK;
+}
+
+// ------------------------------------------------------------------ jobs ----
+struct HostJobs {
+    std::vector<u32> read, str, end, mode, grp_beg;
+    std::vector<u64> samp_off;
+    u64 nsamp = 0;
+    void add(u32 r, u32 s, u32 e, u32 m) {
+        read.push_back(r); str.push_back(s); end.push_back(e); mode.push_back(m);
+        samp_off.push_back(nsamp);
+        nsamp += seed_num_samples(s, e, (u32)job_parm((int)m).alpha);
+    }
+    u32 size() const { return (u32)read.size(); }
+};
+
+struct BatchHost {
+    u32 n = 0;
+    std::vector<u64> off;
+    std::vector<u32> len, lpad, nf, cords_cap, gaps_cap;
+    std::vector<u64> rp_off, f1_off, cords_off, gaps_off;
+};
+
+JobArrays job_arrays(lnr_ctx *ctx) {
+    JobArrays J;
+    J.read = ctx->j_read.as<u32>(); J.str = ctx->j_str.as<u32>(); J.end = ctx->j_end.as<u32>(); J.mode = ctx->j_mode.as<u32>();
+    J.samp_off = ctx->j_samp_off.as<u64>();
+    return J;
+}
+ReadArrays read_arrays(lnr_ctx *ctx) {
+    ReadArrays R;
+    R.bases = ctx->reads_p.as<u8>(); R.rp_off = ctx->rp_off.as<u64>(); R.lpad = ctx->lpad.as<u32>(); R.len = ctx->rlen.as<u32>(); R.ks = ctx->rks.as<i32>();
+    return R;
+}
+
+// Seed lookup (both passes) for the jobs in `hj`, optionally followed by the per-read job kernel.
+// Groups are processed in slices whose anchor + scratch footprint fits the scratch budget.
+lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool keep_anchor_layout) {
+    u32 nj = hj.size();
+    if (nj == 0) return LNR_OK;
+    lnr_status s;
+    if ((s = upload(ctx, ctx->j_read, hj.read)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->j_str, hj.str)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->j_end, hj.end)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->j_mode, hj.mode)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->j_samp_off, hj.samp_off)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->grp_beg, hj.grp_beg)) != LNR_OK) return s;
+    ENSURE(ctx->samp, std::max<size_t>(hj.nsamp * sizeof(SampRec), 16));
+    ENSURE(ctx->j_cap, (size_t)nj * 4);
+    ENSURE(ctx->j_look, (size_t)nj * 4);
+    ENSURE(ctx->j_nanc, (size_t)nj * 4);
+    JobArrays J = job_arrays(ctx);
+    ReadArrays R = read_arrays(ctx);
+    ctx->t_sc.start(ctx->stream);
+    hipLaunchKernelGGL(k_seed_count, dim3(nj), dim3(64), 0, ctx->stream, J, R, ctx->dir.as<i32>(), nj, ctx->samp.as<SampRec>(), ctx->j_cap.as<u32>(), ctx->j_look.as<u32>());
+    KCHECK();
+    ctx->t_sc.stop(ctx->stream);
+    std::vector<u32> cap(nj), look(nj);
+    HIPCK(hipMemcpyAsync(cap.data(), ctx->j_cap.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipMemcpyAsync(look.data(), ctx->j_look.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    ctx->stats.seed_count_ms += ctx->t_sc.ms();
+    ctx->stats.seed_count_launches++;
+    ctx->stats.jobs += nj;
+    ctx->stats.samples += hj.nsamp;
+    for (u32 j = 0; j < nj; j++) { ctx->stats.lookups += look[j]; ctx->stats.bucket_entries += cap[j] - 1; }
+
+    // slices of groups under the scratch budget
+    u64 budget = ctx->opts.scratch_budget ? ctx->opts.scratch_budget : (24ULL << 30);
+    u32 ngrp = (u32)hj.grp_beg.size() - 1;
+    std::vector<u64> anc_off(nj), scr_off(nj);
+    std::vector<u32> nanc_all;
+    if (keep_anchor_layout) nanc_all.resize(nj);
+    u32 g0 = 0;
+    while (g0 < ngrp) {
+        u64 anc = 0, scr = 0;
+        u32 g1 = g0;
+        while (g1 < ngrp) {
+            u64 a2 = anc, s2 = scr;
+            for (u32 j = hj.grp_beg[g1]; j < hj.grp_beg[g1 + 1]; j++) {
+                a2 += align_up((u64)cap[j] + 2, 2);
+                if (with_job_kernel) s2 += align_up(job_scratch_bytes((u64)cap[j] + 2), 256);
+            }
+            if (g1 > g0 && a2 * 8 + s2 > budget) break;
+            anc = a2; scr = s2; g1++;
+        }
+        u64 ao = 0, so = 0;
+        for (u32 j = hj.grp_beg[g0]; j < hj.grp_beg[g1]; j++) {
+            anc_off[j] = ao; ao += align_up((u64)cap[j] + 2, 2);
+            scr_off[j] = so; if (with_job_kernel) so += align_up(job_scratch_bytes((u64)cap[j] + 2), 256);
+        }
+        u32 j0 = hj.grp_beg[g0], j1 = hj.grp_beg[g1];
+        ENSURE(ctx->anchors, std::max<u64>(ao * 8, 16));
+        if (with_job_kernel) ENSURE(ctx->job_scr, std::max<u64>(so, 16));
+        ENSURE(ctx->j_anc_off, (size_t)nj * 8);
+        ENSURE(ctx->j_scr_off, (size_t)nj * 8);
+        HIPCK(hipMemcpyAsync(ctx->j_anc_off.as<u64>() + j0, anc_off.data() + j0, (size_t)(j1 - j0) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCK(hipMemcpyAsync(ctx->j_scr_off.as<u64>() + j0, scr_off.data() + j0, (size_t)(j1 - j0) * 8, hipMemcpyHostToDevice, ctx->stream));
+        ctx->t_sg.start(ctx->stream);
+        hipLaunchKernelGGL(k_seed_gather, dim3(j1 - j0), dim3(64), 0, ctx->stream, J, R, ctx->hs.as<u64>(), j0, j1, ctx->samp.as<SampRec>(),
+                           ctx->j_anc_off.as<u64>(), ctx->anchors.as<u64>(), ctx->j_nanc.as<u32>());
+        KCHECK();
+        ctx->t_sg.stop(ctx->stream);
+        if (with_job_kernel) {
+            JobArgs A;
+            A.grp_beg = ctx->grp_beg.as<u32>(); A.J = J;
+            A.anc_off = ctx->j_anc_off.as<u64>(); A.job_cap = ctx->j_cap.as<u32>(); A.n_anchors = ctx->j_nanc.as<u32>(); A.scr_off = ctx->j_scr_off.as<u64>();
+            A.anchors = ctx->anchors.as<u64>(); A.scratch = ctx->job_scr.as<char>();
+            A.read_len = ctx->rlen.as<u32>(); A.f1_off = ctx->f1_off.as<u64>(); A.nf = ctx->nf.as<u32>(); A.f1 = ctx->f1.as<F96>();
+            A.g.base = ctx->f2.as<F96>(); A.g.off = ctx->d_f2_off.as<u64>(); A.g.nseq = ctx->info.nseq;
+            A.cords = ctx->cords.as<u64>(); A.cords_off = ctx->cords_off.as<u64>(); A.cords_cap = ctx->cords_cap.as<u32>(); A.ncords = ctx->ncords.as<u32>();
+            A.read_err = ctx->read_err.as<i32>();
+            A.nbins = ctx->nbins; A.grp_lo = g0; A.grp_hi = g1;
+            size_t lds = (size_t)((ctx->nbins + 1) / 2) * 4;
+            ctx->t_job.start(ctx->stream);
+            hipLaunchKernelGGL(k_job, dim3(g1 - g0), dim3(64), lds, ctx->stream, A);
+            KCHECK();
+            ctx->t_job.stop(ctx->stream);
+        }
+        std::vector<u32> nanc(j1 - j0);
+        HIPCK(hipMemcpyAsync(nanc.data(), ctx->j_nanc.as<u32>() + j0, (size_t)(j1 - j0) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        ctx->stats.seed_gather_ms += ctx->t_sg.ms();
+        ctx->stats.seed_gather_launches++;
+        if (with_job_kernel) { ctx->stats.job_ms += ctx->t_job.ms(); ctx->stats.job_launches++; }
+        for (u32 j = 0; j < j1 - j0; j++) ctx->stats.anchors += nanc[j] - 1;
+        if (keep_anchor_layout) {
+            if (g0 != 0 || g1 != ngrp) { ctx->err = "anchor export needs the batch to fit one slice; lower the read count"; return LNR_ERR_LIMIT; }
+            // export CSR of the raw anchors to the host arrays
+            ctx->h_anchor_off.assign(nj + 1, 0);
+            for (u32 j = 0; j < nj; j++) ctx->h_anchor_off[j + 1] = ctx->h_anchor_off[j] + nanc[j];
+            ctx->h_anchors.resize(ctx->h_anchor_off[nj]);
+            std::vector<u64> all(ao);
+            HIPCK(hipMemcpy(all.data(), ctx->anchors.p, ao * 8, hipMemcpyDeviceToHost));
+            for (u32 j = 0; j < nj; j++) memcpy(ctx->h_anchors.data() + ctx->h_anchor_off[j], all.data() + anc_off[j], (size_t)nanc[j] * 8);
+        }
+        g0 = g1;
+    }
+    return LNR_OK;
+}
+
+// per-batch host tables + prep / feature kernels.  d_reads/d_off are device pointers.
+lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, BatchHost &B) {
+    B.n = n;
+    B.off.resize((size_t)n + 1);
+    HIPCK(hipMemcpyAsync(B.off.data(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    B.len.resize(n); B.lpad.resize(n); B.nf.resize(n); B.cords_cap.resize(n); B.gaps_cap.resize(n);
+    B.rp_off.resize(n); B.f1_off.resize(n); B.cords_off.resize(n); B.gaps_off.resize(n);
+    u64 rp = 0, fo = 0, co = 0, go = 0;
+    for (u32 i = 0; i < n; i++) {
+        if (B.off[i + 1] < B.off[i]) { ctx->err = "read offsets not monotone"; return LNR_ERR_ARG; }
+        u64 L = B.off[i + 1] - B.off[i];
+        if (L >= (1ULL << 20)) { ctx->err = "read longer than 2^20-1 bases (cord y field, cords.cpp:15)"; return LNR_ERR_LIMIT; }
+        B.len[i] = (u32)L;
+        B.lpad[i] = (u32)align_up(L + SEQ_PAD, 16);
+        B.rp_off[i] = rp; rp += 2ULL * B.lpad[i];
+        B.nf[i] = L > 200 ? read_feature_count(L) : 0;
+        B.f1_off[i] = fo; fo += 2ULL * B.nf[i];
+        B.cords_cap[i] = L > 200 ? (u32)(16 * (L / 64) + 256) : 0;
+        B.cords_off[i] = co; co += B.cords_cap[i];
+        B.gaps_cap[i] = L > 200 ? (u32)(L / 1000 + 4) : 0;
+        B.gaps_off[i] = go; go += B.gaps_cap[i];
+    }
+    lnr_status s;
+    if ((s = upload(ctx, ctx->rlen, B.len)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->lpad, B.lpad)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->rp_off, B.rp_off)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->nf, B.nf)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->f1_off, B.f1_off)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->cords_cap, B.cords_cap)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->cords_off, B.cords_off)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->gaps_cap, B.gaps_cap)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->gaps_off, B.gaps_off)) != LNR_OK) return s;
+    ENSURE(ctx->reads_p, std::max<u64>(rp, 16));
+    ENSURE(ctx->rks, (size_t)n * 4);
+    ENSURE(ctx->f1, std::max<u64>(fo * sizeof(F96), 16));
+    ENSURE(ctx->cords, std::max<u64>(co * 8, 16));
+    ENSURE(ctx->out_str, std::max<u64>(co * 8, 16));
+    ENSURE(ctx->out_end, std::max<u64>(co * 8, 16));
+    ENSURE(ctx->gaps, std::max<u64>(go * sizeof(UP), 16));
+    ENSURE(ctx->ncords, (size_t)n * 4);
+    ENSURE(ctx->nout, (size_t)n * 4);
+    ENSURE(ctx->read_err, (size_t)n * 4);
+    ENSURE(ctx->ngaps, (size_t)n * 4);
+    ENSURE(ctx->remap, (size_t)n * 4);
+    HIPCK(hipMemsetAsync(ctx->ncords.p, 0, (size_t)n * 4, ctx->stream));
+    HIPCK(hipMemsetAsync(ctx->read_err.p, 0, (size_t)n * 4, ctx->stream));
+    ctx->t_prep.start(ctx->stream);
+    hipLaunchKernelGGL(k_prep, dim3(n), dim3(256), 0, ctx->stream, d_reads, d_off, ctx->rp_off.as<u64>(), ctx->lpad.as<u32>(), n, ctx->reads_p.as<u8>(), ctx->rks.as<i32>());
+    KCHECK();
+    hipLaunchKernelGGL(k_f1, dim3(n), dim3(256), 0, ctx->stream, ctx->reads_p.as<u8>(), ctx->rp_off.as<u64>(), ctx->lpad.as<u32>(), ctx->nf.as<u32>(), ctx->f1_off.as<u64>(), n, ctx->f1.as<F96>());
+    KCHECK();
+    ctx->t_prep.stop(ctx->stream);
+    ctx->stats.reads = n;
+    ctx->stats.bases = B.off[n] - B.off[0];
+    return LNR_OK;
+}
+
+lnr_status tail_sizes(lnr_ctx *ctx, const BatchHost &B, std::vector<u32> &ncords) {
+    u32 n = B.n;
+    ncords.resize(n);
+    HIPCK(hipMemcpyAsync(ncords.data(), ctx->ncords.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    std::vector<u64> off(n);
+    std::vector<u32> cap(n);
+    u64 o = 0;
+    for (u32 i = 0; i < n; i++) { cap[i] = ncords[i] + 4; off[i] = o; o += align_up(tail_scratch_bytes(cap[i]), 256); }
+    lnr_status s;
+    if ((s = upload(ctx, ctx->tail_off, off)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->tail_cap, cap)) != LNR_OK) return s;
+    ENSURE(ctx->tail_scr, std::max<u64>(o, 16));
+    return LNR_OK;
+}
+
+TailArgs tail_args(lnr_ctx *ctx, u32 n) {
+    TailArgs T;
+    T.read_len = ctx->rlen.as<u32>(); T.n = n;
+    T.cords = ctx->cords.as<u64>(); T.cords_off = ctx->cords_off.as<u64>(); T.cords_cap = ctx->cords_cap.as<u32>(); T.ncords = ctx->ncords.as<u32>();
+    T.read_err = ctx->read_err.as<i32>();
+    T.scratch = ctx->tail_scr.as<char>(); T.scr_off = ctx->tail_off.as<u64>(); T.scr_cap = ctx->tail_cap.as<u32>();
+    T.gaps = ctx->gaps.as<UP>(); T.gaps_off = ctx->gaps_off.as<u64>(); T.gaps_cap = ctx->gaps_cap.as<u32>(); T.ngaps = ctx->ngaps.as<u32>(); T.remap = ctx->remap.as<u32>();
+    T.out_str = ctx->out_str.as<u64>(); T.out_end = ctx->out_end.as<u64>(); T.nout = ctx->nout.as<u32>();
+    return T;
+}
+
+void reset_stats(lnr_ctx *ctx) { memset(&ctx->stats, 0, sizeof ctx->stats); }
+void finish_stats(lnr_ctx *ctx, const BatchHost &B) {
+    u64 rb = 0;
+    for (u32 i = 0; i < B.n; i++) if (B.len[i] > 200) rb += (B.len[i] + 3) / 4;
+    ctx->stats.seed_bytes = rb + ctx->stats.lookups * 8 + ctx->stats.bucket_entries * 8 + ctx->stats.anchors * 8;
+}
+
+lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, lnr_cords_dev *out) {
+    if (!ctx->has_index) { ctx->err = "no index: call lnr_index_build or lnr_index_adopt first"; return LNR_ERR_NO_INDEX; }
+    reset_stats(ctx);
+    ctx->last_n = n; ctx->last_ncords = 0;
+    if (out) { out->n_reads = n; out->n_cords = 0; out->d_cord_off = nullptr; out->d_cords_str = nullptr; out->d_cords_end = nullptr; }
+    ENSURE(ctx->r_off, ((size_t)n + 1) * 8);
+    if (n == 0) {
+        HIPCK(hipMemsetAsync(ctx->r_off.p, 0, 8, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        if (out) out->d_cord_off = ctx->r_off.as<u64>();
+        return LNR_OK;
+    }
+    ctx->t_total.start(ctx->stream);
+    BatchHost B;
+    lnr_status s = prepare_batch(ctx, d_reads, d_off, n, B);
+    if (s != LNR_OK) return s;
+    // round 0: one job per read longer than 200 bases (mapper.cpp:430,440), whole read, default parameters
+    HostJobs j0;
+    for (u32 i = 0; i < n; i++) {
+        if (B.len[i] > 200) { j0.grp_beg.push_back(j0.size()); j0.add(i, 0, B.len[i], 0); }
+    }
+    j0.grp_beg.push_back(j0.size());
+    if ((s = run_jobs(ctx, j0, true, false)) != LNR_OK) return s;
+    // tail A: clean / gather / gaps, decides the remap loop (pmpfinder.cpp:2744-2749)
+    std::vector<u32> ncords;
+    if ((s = tail_sizes(ctx, B, ncords)) != LNR_OK) return s;
+    TailArgs T = tail_args(ctx, n);
+    ctx->t_tail.start(ctx->stream);
+    hipLaunchKernelGGL(k_tail_a, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, T);
+    KCHECK();
+    ctx->t_tail.stop(ctx->stream);
+    std::vector<u32> remap(n), ngaps(n);
+    HIPCK(hipMemcpyAsync(remap.data(), ctx->remap.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipMemcpyAsync(ngaps.data(), ctx->ngaps.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    ctx->stats.tail_ms += ctx->t_tail.ms();
+    // remap loop (pmpfinder.cpp:2749-2767): every gap of a poorly covered read is re-seeded with step 7 / score0
+    HostJobs j1;
+    u64 gtot = B.gaps_off[n - 1] + B.gaps_cap[n - 1];
+    std::vector<UP> gaps;
+    bool any = false;
+    for (u32 i = 0; i < n; i++) if (remap[i] && ngaps[i]) { any = true; break; }
+    if (any) {
+        gaps.resize(gtot);
+        HIPCK(hipMemcpy(gaps.data(), ctx->gaps.p, gtot * sizeof(UP), hipMemcpyDeviceToHost));
+        for (u32 i = 0; i < n; i++) {
+            if (!(remap[i] && ngaps[i])) continue;
+            ctx->stats.remap_reads++;
+            j1.grp_beg.push_back(j1.size());
+            for (u32 k = 0; k < ngaps[i]; k++) {
+                UP y = forward_y(gaps[B.gaps_off[i] + k], B.len[i]);
+                j1.add(i, (u32)y.first, (u32)y.second, 1);
+            }
+        }
+        j1.grp_beg.push_back(j1.size());
+        if ((s = run_jobs(ctx, j1, true, false)) != LNR_OK) return s;
+    }
+    // tail B: block chaining on both strands, flags, cords_end (pmpfinder.cpp:2764-2801)
+    if ((s = tail_sizes(ctx, B, ncords)) != LNR_OK) return s;
+    T = tail_args(ctx, n);
+    ctx->t_tail.start(ctx->stream);
+    hipLaunchKernelGGL(k_tail_b, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, T);
+    KCHECK();
+    ctx->t_tail.stop(ctx->stream);
+    std::vector<u32> nout(n);
+    std::vector<i32> rerr(n);
+    HIPCK(hipMemcpyAsync(nout.data(), ctx->nout.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipMemcpyAsync(rerr.data(), ctx->read_err.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    ctx->stats.tail_ms += ctx->t_tail.ms();
+    for (u32 i = 0; i < n; i++)
+        if (rerr[i]) {
+            char b[160];
+            snprintf(b, sizeof b, "device capacity overflow on read %u (stage code %d, length %u)", i, rerr[i], B.len[i]);
+            ctx->err = b;
+            return LNR_ERR_INTERNAL;
+        }
+    ctx->h_cord_off.assign((size_t)n + 1, 0);
+    for (u32 i = 0; i < n; i++) ctx->h_cord_off[i + 1] = ctx->h_cord_off[i] + nout[i];
+    u64 tot = ctx->h_cord_off[n];
+    ENSURE(ctx->r_str, std::max<u64>(tot * 8, 16));
+    ENSURE(ctx->r_end, std::max<u64>(tot * 8, 16));
+    HIPCK(hipMemcpyAsync(ctx->r_off.p, ctx->h_cord_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gather_out, dim3(n), dim3(64), 0, ctx->stream, ctx->out_str.as<u64>(), ctx->out_end.as<u64>(), ctx->cords_off.as<u64>(), ctx->nout.as<u32>(),
+                       ctx->r_off.as<u64>(), n, ctx->r_str.as<u64>(), ctx->r_end.as<u64>());
+    KCHECK();
+    ctx->t_total.stop(ctx->stream);
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    ctx->stats.prep_ms = ctx->t_prep.ms();
+    ctx->stats.total_ms = ctx->t_total.ms();
+    ctx->stats.cords = tot;
+    finish_stats(ctx, B);
+    ctx->last_ncords = tot;
+    if (out) { out->n_cords = tot; out->d_cord_off = ctx->r_off.as<u64>(); out->d_cords_str = ctx->r_str.as<u64>(); out->d_cords_end = ctx->r_end.as<u64>(); }
+    return LNR_OK;
+}
+
+lnr_status seed_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, bool to_host) {
+    if (!ctx->has_index) { ctx->err = "no index: call lnr_index_build or lnr_index_adopt first"; return LNR_ERR_NO_INDEX; }
+    reset_stats(ctx);
+    ctx->h_anchor_off.assign((size_t)n + 1, 0);
+    ctx->h_anchors.clear();
+    if (n == 0) return LNR_OK;
+    ctx->t_total.start(ctx->stream);
+    BatchHost B;
+    lnr_status s = prepare_batch(ctx, d_reads, d_off, n, B);
+    if (s != LNR_OK) return s;
+    HostJobs j0;
+    std::vector<u32> job_of(n, 0xffffffffu);
+    for (u32 i = 0; i < n; i++) {
+        if (B.len[i] >= 43) { job_of[i] = j0.size(); j0.grp_beg.push_back(j0.size()); j0.add(i, 0, B.len[i], 0); }
+    }
+    j0.grp_beg.push_back(j0.size());
+    std::vector<u64> joff, janc;
+    if ((s = run_jobs(ctx, j0, false, to_host)) != LNR_OK) return s;
+    ctx->t_total.stop(ctx->stream);
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    ctx->stats.prep_ms = ctx->t_prep.ms();
+    ctx->stats.total_ms = ctx->t_total.ms();
+    // stats.seed_bytes with every read counted
+    u64 rb = 0;
+    for (u32 i = 0; i < n; i++) if (job_of[i] != 0xffffffffu) rb += (B.len[i] + 3) / 4;
+    ctx->stats.seed_bytes = rb + ctx->stats.lookups * 8 + ctx->stats.bucket_entries * 8 + ctx->stats.anchors * 8;
+    if (to_host) {
+        // re-index the per-job CSR by read (reads without a job get the bare dummy)
+        std::vector<u64> off((size_t)n + 1, 0), vals;
+        for (u32 i = 0; i < n; i++) {
+            u64 c = job_of[i] == 0xffffffffu ? 1 : ctx->h_anchor_off[job_of[i] + 1] - ctx->h_anchor_off[job_of[i]];
+            off[i + 1] = off[i] + c;
+        }
+        vals.assign(off[n], 0);
+        for (u32 i = 0; i < n; i++)
+            if (job_of[i] != 0xffffffffu) {
+                u64 a = ctx->h_anchor_off[job_of[i]], c = ctx->h_anchor_off[job_of[i] + 1] - a;
+                memcpy(vals.data() + off[i], ctx->h_anchors.data() + a, c * 8);
+            }
+        ctx->h_anchor_off.swap(off);
+        ctx->h_anchors.swap(vals);
+    }
+    return LNR_OK;
+}
+
+lnr_status stage_reads(lnr_ctx *ctx, const u8 *reads, const u64 *off, u32 n) {
+    if (!off || (n && !reads)) { ctx->err = "null read buffer"; return LNR_ERR_ARG; }
+    u64 base = off[0], total = off[n] - off[0];
+    ENSURE(ctx->in_reads, std::max<u64>(total, 16));
+    ENSURE(ctx->in_off, ((size_t)n + 1) * 8);
+    std::vector<u64> o((size_t)n + 1);
+    for (u32 i = 0; i <= n; i++) o[i] = off[i] - base;
+    if (total) HIPCK(hipMemcpyAsync(ctx->in_reads.p, reads + base, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCK(hipMemcpyAsync(ctx->in_off.p, o.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    return LNR_OK;
+}
+
+}  // namespace
+
+// ======================================================================= C ABI ====
+extern "C" {
+
+void lnr_opts_default(lnr_opts *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->device = -1; o->index_type = 1; o->feature_type = 2; o->preset = 1; o->gap_len = 0; o->scratch_budget = 0;
+}
+
+const char *lnr_strerror(lnr_status s) {
+    switch (s) {
+        case LNR_OK: return "ok";
+        case LNR_ERR_ARG: return "invalid argument";
+        case LNR_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+        case LNR_ERR_HIP: return "HIP runtime error";
+        case LNR_ERR_NOMEM: return "out of memory";
+        case LNR_ERR_NO_INDEX: return "index not built";
+        case LNR_ERR_LIMIT: return "input exceeds a format limit";
+        case LNR_ERR_UNSUPPORTED: return "option not supported by this build";
+        case LNR_ERR_INTERNAL: return "internal capacity overflow";
+    }
+    return "unknown status";
+}
+const char *lnr_last_error(const lnr_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
+    if (!out) return LNR_ERR_ARG;
+    *out = nullptr;
+    lnr_opts o;
+    if (opts) o = *opts; else lnr_opts_default(&o);
+    if (o.index_type != 1 || o.feature_type != 2 || o.gap_len != 0 || o.preset != 1) return LNR_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return LNR_ERR_NO_DEVICE; }
+    int dev = o.device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return LNR_ERR_NO_DEVICE; }
+    if (dev >= ndev) return LNR_ERR_ARG;
+    if (hipSetDevice(dev) != hipSuccess) return LNR_ERR_NO_DEVICE;
+    lnr_ctx *ctx = new (std::nothrow) lnr_ctx();
+    if (!ctx) return LNR_ERR_NOMEM;
+    ctx->opts = o;
+    ctx->device = dev;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
+    ctx->t_prep.init(); ctx->t_sc.init(); ctx->t_sg.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();
+    *out = ctx;
+    return LNR_OK;
+}
+
+void lnr_destroy(lnr_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->g, &ctx->dir, &ctx->hs, &ctx->f2, &ctx->d_seq_off, &ctx->d_f2_off, &ctx->in_reads, &ctx->in_off, &ctx->reads_p, &ctx->rp_off,
+                      &ctx->lpad, &ctx->rlen, &ctx->rks, &ctx->nf, &ctx->f1_off, &ctx->f1, &ctx->cords, &ctx->out_str, &ctx->out_end, &ctx->cords_off,
+                      &ctx->cords_cap, &ctx->ncords, &ctx->nout, &ctx->read_err, &ctx->tail_scr, &ctx->tail_off, &ctx->tail_cap, &ctx->gaps, &ctx->gaps_off,
+                      &ctx->gaps_cap, &ctx->ngaps, &ctx->remap, &ctx->j_read, &ctx->j_str, &ctx->j_end, &ctx->j_mode, &ctx->j_samp_off, &ctx->j_cap,
+                      &ctx->j_look, &ctx->j_anc_off, &ctx->j_scr_off, &ctx->j_nanc, &ctx->grp_beg, &ctx->samp, &ctx->anchors, &ctx->job_scr, &ctx->r_off,
+                      &ctx->r_str, &ctx->r_end};
+    for (DevBuf *b : bufs) b->release();
+    ctx->t_prep.destroy(); ctx->t_sc.destroy(); ctx->t_sg.destroy(); ctx->t_job.destroy(); ctx->t_tail.destroy(); ctx->t_total.destroy();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64_t *len, uint32_t nseq, uint32_t T) {
+    if (!ctx) return LNR_ERR_ARG;
+    if (!seq || !len || nseq == 0) { ctx->err = "null/empty sequence set"; return LNR_ERR_ARG; }
+    if (nseq >= 1024) { ctx->err = "at most 1023 reference sequences (cord id field; linear.cpp:107)"; return LNR_ERR_LIMIT; }
+    if (T == 0) T = 1;
+    for (u32 i = 0; i < nseq; i++) {
+        if (!seq[i]) { ctx->err = "null sequence pointer"; return LNR_ERR_ARG; }
+        if (len[i] >= (1ULL << 30) - (1ULL << 20)) { ctx->err = "sequence too long for the 30-bit x field (cords.cpp:13-14)"; return LNR_ERR_LIMIT; }
+    }
+    HIPCK(hipSetDevice(ctx->device));
+    ctx->has_index = false;
+    set_index_layout(ctx, len, nseq);
+    ctx->info.layout_threads = T;
+    lnr_status s;
+    if ((s = upload_index_layout(ctx)) != LNR_OK) return s;
+    // genome: padded device copy (zero padding pins the reference's out-of-range reads to 'A')
+    ENSURE(ctx->g, ctx->info.genome_bytes + 64);
+    HIPCK(hipMemsetAsync(ctx->g.p, 0, ctx->info.genome_bytes + 64, ctx->stream));
+    for (u32 i = 0; i < nseq; i++)
+        if (len[i]) HIPCK(hipMemcpyAsync(ctx->g.as<u8>() + ctx->seq_off[i], seq[i], len[i], hipMemcpyHostToDevice, ctx->stream));
+    Timer tm; tm.init();
+    tm.start(ctx->stream);
+    // chunks of the T-thread layout (index_util.cpp:1654-1666)
+    std::vector<ChunkDesc> chunks;
+    u64 nsamp = 0;
+    for (u32 i = 0; i < nseq; i++)
+        for (u32 t = 0; t < T; t++) {
+            i64 ts, te;
+            chunk_bounds(len[i], T, t, ts, te);
+            if (ts >= te) continue;
+            u64 ns = chunk_num_samples(ts, te);
+            if (!ns) continue;
+            ChunkDesc c; c.seq_off = ctx->seq_off[i]; c.t_str = ts; c.samp_base = nsamp; c.nsamp = (u32)ns; c.seq_id = i; c.ks = 0; c.C = 0;
+            chunks.push_back(c);
+            nsamp += ns;
+        }
+    if (nsamp >= (1ULL << 32) - 2) { ctx->err = "too many genome samples"; return LNR_ERR_LIMIT; }
+    ctx->info.n_samples = nsamp;
+    u64 dir_len = ctx->info.dir_len;
+    ENSURE(ctx->dir, dir_len * 4);
+    DevBuf d_chunks, Xs, vals, cnt, blk, scan_tmp, big, nbig;
+    auto cleanup = [&]() { d_chunks.release(); Xs.release(); vals.release(); cnt.release(); blk.release(); scan_tmp.release(); big.release(); nbig.release(); tm.destroy(); };
+#define IXCK(expr) do { lnr_status s_ = (expr); if (s_ != LNR_OK) { cleanup(); return s_; } } while (0)
+#define IXHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); (void)hipGetLastError(); cleanup(); return LNR_ERR_HIP; } } while (0)
+#define IXENS(b, bytes) do { if (!(b).ensure(bytes)) { ctx->err = "device allocation failed during index build"; cleanup(); return LNR_ERR_NOMEM; } } while (0)
+    IXENS(cnt, dir_len * 4);
+    IXHIP(hipMemsetAsync(cnt.p, 0, dir_len * 4, ctx->stream));
+    u64 hs_len = 0;
+    if (nsamp) {
+        IXCK(upload(ctx, d_chunks, chunks));
+        IXENS(Xs, nsamp * 4);
+        IXENS(vals, nsamp * 8);
+        u32 nch = (u32)chunks.size();
+        hipLaunchKernelGGL(k_ix_chunk_const, dim3((nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->g.as<u8>(), d_chunks.as<ChunkDesc>(), nch);
+        IXHIP(hipGetLastError());
+        hipLaunchKernelGGL(k_ix_sample, dim3((u32)((nsamp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->g.as<u8>(), d_chunks.as<ChunkDesc>(), nch, nsamp, Xs.as<u32>(), vals.as<u64>());
+        IXHIP(hipGetLastError());
+        u32 nrb = (u32)((nsamp + REC_BLK - 1) / REC_BLK);
+        IXENS(blk, (size_t)nrb * 4);
+        hipLaunchKernelGGL(k_ix_start_blk, dim3(nrb), dim3(REC_TPB), 0, ctx->stream, Xs.as<u32>(), nsamp, blk.as<u32>());
+        IXHIP(hipGetLastError());
+        hipLaunchKernelGGL(k_max_top, dim3(1), dim3(1024), 0, ctx->stream, blk.as<u32>(), nrb);
+        IXHIP(hipGetLastError());
+        hipLaunchKernelGGL(k_ix_rec, dim3(nrb), dim3(REC_TPB), 0, ctx->stream, Xs.as<u32>(), nsamp, blk.as<u32>(), cnt.as<i32>());
+        IXHIP(hipGetLastError());
+        hipLaunchKernelGGL(k_ix_omit, dim3((u32)((dir_len + 255) / 256)), dim3(256), 0, ctx->stream, cnt.as<i32>(), dir_len);
+        IXHIP(hipGetLastError());
+    }
+    IXCK(dev_scan_i32(ctx, cnt.as<i32>(), ctx->dir.as<i32>(), dir_len, scan_tmp));
+    i32 total = 0;
+    IXHIP(hipMemcpyAsync(&total, ctx->dir.as<i32>() + (dir_len - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    IXHIP(hipStreamSynchronize(ctx->stream));
+    hs_len = (u64)total;
+    IXENS(ctx->hs, std::max<u64>(hs_len * 8, 16));
+    if (nsamp && hs_len) {
+        IXHIP(hipMemsetAsync(cnt.p, 0, dir_len * 4, ctx->stream));
+        hipLaunchKernelGGL(k_ix_scatter, dim3((u32)((nsamp + 255) / 256)), dim3(256), 0, ctx->stream, Xs.as<u32>(), vals.as<u64>(), nsamp, ctx->dir.as<i32>(), cnt.as<i32>(), ctx->hs.as<u64>());
+        IXHIP(hipGetLastError());
+        IXENS(big, (hs_len / 33 + 2) * 4);
+        IXENS(nbig, 16);
+        IXHIP(hipMemsetAsync(nbig.p, 0, 4, ctx->stream));
+        u64 nb = dir_len - 1;
+        hipLaunchKernelGGL(k_ix_sort_small, dim3((u32)((nb + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->hs.as<u64>(), big.as<u32>(), nbig.as<u32>());
+        IXHIP(hipGetLastError());
+        u32 hb = 0;
+        IXHIP(hipMemcpyAsync(&hb, nbig.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        IXHIP(hipStreamSynchronize(ctx->stream));
+        if (hb) {
+            hipLaunchKernelGGL(k_ix_sort_big, dim3(hb), dim3(64), 0, ctx->stream, ctx->dir.as<i32>(), ctx->hs.as<u64>(), big.as<u32>(), hb);
+            IXHIP(hipGetLastError());
+        }
+    }
+    // genome window features
+    ENSURE(ctx->f2, std::max<u64>(ctx->info.f2_len * sizeof(F96), 16));
+    if (ctx->info.f2_len) {
+        hipLaunchKernelGGL(k_f2, dim3((u32)((ctx->info.f2_len + 255) / 256)), dim3(256), 0, ctx->stream, ctx->g.as<u8>(), ctx->d_seq_off.as<u64>(), ctx->d_f2_off.as<u64>(), nseq,
+                           ctx->info.f2_len, ctx->f2.as<F96>());
+        IXHIP(hipGetLastError());
+    }
+    tm.stop(ctx->stream);
+    IXHIP(hipStreamSynchronize(ctx->stream));
+    ctx->info.build_ms = tm.ms();
+    ctx->info.hs_len = hs_len;
+    cleanup();
+    ctx->has_index = true;
+    return LNR_OK;
+}
+
+lnr_status lnr_index_info_get(const lnr_ctx *ctx, lnr_index_info *info) {
+    if (!ctx || !info) return LNR_ERR_ARG;
+    if (!ctx->has_index) return LNR_ERR_NO_INDEX;
+    *info = ctx->info;
+    return LNR_OK;
+}
+
+lnr_status lnr_index_export(lnr_ctx *ctx, int32_t *dir, uint64_t *hs, int32_t *f2, uint64_t *f2_off) {
+    if (!ctx) return LNR_ERR_ARG;
+    if (!ctx->has_index) return LNR_ERR_NO_INDEX;
+    HIPCK(hipSetDevice(ctx->device));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    if (dir) HIPCK(hipMemcpy(dir, ctx->dir.p, ctx->info.dir_len * 4, hipMemcpyDeviceToHost));
+    if (hs && ctx->info.hs_len) HIPCK(hipMemcpy(hs, ctx->hs.p, ctx->info.hs_len * 8, hipMemcpyDeviceToHost));
+    if (f2 && ctx->info.f2_len) {
+        std::vector<F96> tmp(ctx->info.f2_len);
+        HIPCK(hipMemcpy(tmp.data(), ctx->f2.p, ctx->info.f2_len * sizeof(F96), hipMemcpyDeviceToHost));
+        for (u64 i = 0; i < ctx->info.f2_len; i++) { f2[3 * i] = tmp[i].v0; f2[3 * i + 1] = tmp[i].v1; f2[3 * i + 2] = tmp[i].v2; }
+    }
+    if (f2_off) memcpy(f2_off, ctx->f2_off.data(), ctx->f2_off.size() * 8);
+    return LNR_OK;
+}
+
+lnr_status lnr_index_alloc(lnr_ctx *ctx, const lnr_index_info *info, const uint64_t *seq_len) {
+    if (!ctx || !info || !seq_len || info->nseq == 0 || info->nseq >= 1024) return LNR_ERR_ARG;
+    HIPCK(hipSetDevice(ctx->device));
+    ctx->has_index = false;
+    set_index_layout(ctx, seq_len, info->nseq);
+    if (ctx->info.genome_bytes != info->genome_bytes || ctx->info.f2_len != info->f2_len || ctx->info.dir_len != info->dir_len) {
+        ctx->err = "index info does not match the sequence lengths";
+        return LNR_ERR_ARG;
+    }
+    ctx->info = *info;
+    lnr_status s;
+    if ((s = upload_index_layout(ctx)) != LNR_OK) return s;
+    ENSURE(ctx->g, ctx->info.genome_bytes + 64);
+    ENSURE(ctx->dir, ctx->info.dir_len * 4);
+    ENSURE(ctx->hs, std::max<u64>(ctx->info.hs_len * 8, 16));
+    ENSURE(ctx->f2, std::max<u64>(ctx->info.f2_len * sizeof(F96), 16));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    return LNR_OK;
+}
+lnr_status lnr_index_blob(lnr_ctx *ctx, uint32_t which, void **d_ptr, uint64_t *bytes) {
+    if (!ctx || !d_ptr || !bytes) return LNR_ERR_ARG;
+    switch (which) {
+        case 0: *d_ptr = ctx->g.p; *bytes = ctx->info.genome_bytes; break;
+        case 1: *d_ptr = ctx->dir.p; *bytes = ctx->info.dir_len * 4; break;
+        case 2: *d_ptr = ctx->hs.p; *bytes = ctx->info.hs_len * 8; break;
+        case 3: *d_ptr = ctx->f2.p; *bytes = ctx->info.f2_len * sizeof(F96); break;
+        default: return LNR_ERR_ARG;
+    }
+    if (!*d_ptr) return LNR_ERR_NO_INDEX;
+    return LNR_OK;
+}
+lnr_status lnr_index_adopt(lnr_ctx *ctx) {
+    if (!ctx) return LNR_ERR_ARG;
+    if (!ctx->g.p || !ctx->dir.p || !ctx->hs.p || !ctx->f2.p) return LNR_ERR_NO_INDEX;
+    ctx->has_index = true;
+    return LNR_OK;
+}
+
+lnr_status lnr_filter_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_off, uint32_t n, lnr_cords_dev *out) {
+    if (!ctx || !d_off || (n && !d_reads)) return LNR_ERR_ARG;
+    HIPCK(hipSetDevice(ctx->device));
+    return filter_dev(ctx, d_reads, d_off, n, out);
+}
+lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out) {
+    if (!ctx || !out) return LNR_ERR_ARG;
+    HIPCK(hipSetDevice(ctx->device));
+    u64 tot = ctx->last_ncords;
+    ctx->h_cords_str.resize(tot);
+    ctx->h_cords_end.resize(tot);
+    if (ctx->h_cord_off.size() != (size_t)ctx->last_n + 1) ctx->h_cord_off.assign((size_t)ctx->last_n + 1, 0);
+    if (tot) {
+        HIPCK(hipMemcpy(ctx->h_cords_str.data(), ctx->r_str.p, tot * 8, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(ctx->h_cords_end.data(), ctx->r_end.p, tot * 8, hipMemcpyDeviceToHost));
+    }
+    out->n_reads = ctx->last_n; out->n_cords = tot;
+    out->cord_off = ctx->h_cord_off.data(); out->cords_str = ctx->h_cords_str.data(); out->cords_end = ctx->h_cords_end.data();
+    return LNR_OK;
+}
+lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *off, uint32_t n, lnr_cords *out) {
+    if (!ctx || !out) return LNR_ERR_ARG;
+    HIPCK(hipSetDevice(ctx->device));
+    if (!ctx->has_index) { ctx->err = "no index"; return LNR_ERR_NO_INDEX; }
+    lnr_status s = stage_reads(ctx, reads, off, n);
+    if (s != LNR_OK) return s;
+    if ((s = filter_dev(ctx, ctx->in_reads.as<u8>(), ctx->in_off.as<u64>(), n, nullptr)) != LNR_OK) return s;
+    return lnr_cords_to_host(ctx, out);
+}
+
+lnr_status lnr_seed_lookup_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_off, uint32_t n) {
+    if (!ctx || !d_off || (n && !d_reads)) return LNR_ERR_ARG;
+    HIPCK(hipSetDevice(ctx->device));
+    return seed_dev(ctx, d_reads, d_off, n, false);
+}
+lnr_status lnr_seed_lookup_batch(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *off, uint32_t n, lnr_anchors *out) {
+    if (!ctx || !out) return LNR_ERR_ARG;
+    HIPCK(hipSetDevice(ctx->device));
+    if (!ctx->has_index) { ctx->err = "no index"; return LNR_ERR_NO_INDEX; }
+    lnr_status s = stage_reads(ctx, reads, off, n);
+    if (s != LNR_OK) return s;
+    if ((s = seed_dev(ctx, ctx->in_reads.as<u8>(), ctx->in_off.as<u64>(), n, true)) != LNR_OK) return s;
+    out->n_reads = n; out->n_anchors = ctx->h_anchor_off[n];
+    out->anchor_off = ctx->h_anchor_off.data(); out->anchors = ctx->h_anchors.data();
+    return LNR_OK;
+}
+
+lnr_status lnr_last_stats(const lnr_ctx *ctx, lnr_stats *st) {
+    if (!ctx || !st) return LNR_ERR_ARG;
+    *st = ctx->stats;
+    return LNR_OK;
+}
+
+}  // extern "C"

@@ -79,7 +79,7 @@ struct Arena {
     }
 };
 // bytes of per-job scratch needed by job_process for a job with `cap` anchor slots
-LNR_HD inline u64 job_scratch_bytes(u64 cap) { return cap * 176 + 4096; }
+LNR_HD inline u64 job_scratch_bytes(u64 cap) { return (cap + 2) * 144 + 1024; }
 LNR_HD inline u64 tail_scratch_bytes(u64 cap) { return cap * 240 + 8192; }
 
 // --------------------------------------------------------- minimizer shape ----
@@ -812,61 +812,76 @@ struct JobCtx {
     u16 *bins; u32 nbins;
     u64 *pair_evals;
 };
-// Everything after the ascending sort.  `a` = sorted anchors (n), scratch from `ar`.
-// Output: cords appended to `cords`.  Returns 0, or 1 on scratch/capacity overflow.
+// Per-job scratch, carved once from the job's arena (cap = anchor slots of the job).
+struct JobScratch {
+    Vec<u64> hits; Vec<i32> hscore; Vec<UP> sep, tmp;
+    Rec rec;
+    i32 *chain, *chain_sc, *cnt, *sep_score;
+    u32 *xs, *ys;
+    u64 *cuts, *xy_strs, *alt;
+};
+LNR_HD inline bool job_carve(Arena &ar, u32 cap, JobScratch &S, int *ovf) {
+    u32 c2 = cap + 2;
+    S.hits.init(ar.get<u64>(c2), c2, ovf);
+    S.hscore.init(ar.get<i32>(c2), c2, ovf);
+    S.sep.init(ar.get<UP>(c2), c2, ovf);
+    S.tmp.init(ar.get<UP>(c2), c2, ovf);
+    S.rec.score = ar.get<i32>(c2); S.rec.score2 = ar.get<i32>(c2); S.rec.len = ar.get<i32>(c2);
+    S.rec.p2 = ar.get<i32>(c2); S.rec.root = ar.get<i32>(c2); S.rec.leaf = ar.get<i32>(c2);
+    S.chain = ar.get<i32>(c2); S.chain_sc = ar.get<i32>(c2); S.cnt = ar.get<i32>(c2); S.sep_score = ar.get<i32>(c2);
+    S.xs = ar.get<u32>(c2); S.ys = ar.get<u32>(c2);
+    S.cuts = ar.get<u64>(2 * (u64)c2); S.xy_strs = ar.get<u64>(c2); S.alt = ar.get<u64>(c2);
+    return !ar.ovf;
+}
 struct JobDebug { u64 *filt; u32 *nfilt; u64 *xsort; u32 *nxsort; u64 *hits_chain; u32 *nhits_chain; u64 *hits_blocks; u32 *nhits_blocks; };
 
-LNR_HD inline int job_after_sort(u64 *a, u32 n_sorted, u32 cap, Arena &ar, const JobCtx &c, Vec<u64> &cords, JobDebug *dbg) {
-    int ovf = 0;
-    u32 m = n_sorted > 1 ? filter_anchor_list(a, n_sorted) : 0;   // filterAnchors1: n<=1 -> unchanged; see below
-    if (n_sorted <= 1) m = n_sorted;
+// Phase 1 (serial): a = ascending-sorted anchors with a[0]==0.  filterAnchors1 compaction, the
+// tie-sensitive x-descending sort of chainAnchorsHits (pmpfinder.cpp:2465), x/y extraction.
+// Returns m, the number of anchors that enter the chaining DP.
+LNR_HD inline u32 job_phase1(u64 *a, u32 n_sorted, JobScratch &S, JobDebug *dbg) {
+    u32 m = n_sorted > 1 ? filter_anchor_list(a, n_sorted) : n_sorted;   // filterAnchors1: length <= 1 -> unchanged
     if (dbg && dbg->filt) { for (u32 i = 0; i < m; i++) dbg->filt[i] = a[i]; *dbg->nfilt = m; }
-    // chainAnchorsHits pmpfinder.cpp:2448-2481
-    Vec<u64> hits; hits.init(ar.get<u64>(cap + 2), cap + 2, &ovf);
-    Vec<i32> hscore; hscore.init(ar.get<i32>(cap + 2), cap + 2, &ovf);
-    hits.push(F_END);     // initHits
-    hscore.push(0);       // initHitsScore
     ref_sort(a, (long)m, [](const u64 &p, const u64 &q) { return anchor_x(p) > anchor_x(q); });
     if (dbg && dbg->xsort) { for (u32 i = 0; i < m; i++) dbg->xsort[i] = a[i]; *dbg->nxsort = m; }
-    Rec rec;
-    rec.score = ar.get<i32>(cap + 2); rec.score2 = ar.get<i32>(cap + 2); rec.len = ar.get<i32>(cap + 2);
-    rec.p2 = ar.get<i32>(cap + 2); rec.root = ar.get<i32>(cap + 2); rec.leaf = ar.get<i32>(cap + 2);
-    i32 *chain = ar.get<i32>(cap + 2), *chain_sc = ar.get<i32>(cap + 2), *cnt = ar.get<i32>(cap + 2);
-    u32 *xs = ar.get<u32>(cap + 2), *ys = ar.get<u32>(cap + 2);
-    if (ar.ovf) return 1;
-    JobParm pm = job_parm(c.mode);
+    for (u32 i = 0; i < m; i++) { S.xs[i] = (u32)anchor_x(a[i]); S.ys[i] = (u32)cord_y(a[i]); }
+    return m;
+}
+// (between the phases: the chaining DP over S.xs/S.ys into S.rec -- best_chains_serial here,
+//  its wave-parallel twin in the kernel -- only when m >= 2, chainAnchorsBase cluster_util.cpp:450)
+
+// Phase 3 (serial): traceback -> hits, hit blocks, window filter, path extension -> cords appended.
+// Returns 0, or 1 on capacity overflow.
+LNR_HD inline int job_phase3(u64 *a, u32 m, JobScratch &S, const JobCtx &c, Vec<u64> &cords, JobDebug *dbg) {
+    int *ovf = S.hits.ovf;
+    Vec<u64> &hits = S.hits;
+    hits.n = 0; S.hscore.n = 0; S.sep.n = 0; S.tmp.n = 0;
+    hits.push(F_END);        // initHits
+    S.hscore.push(0);        // initHitsScore
     if (m >= 2) {
-        for (u32 i = 0; i < m; i++) { xs[i] = (u32)anchor_x(a[i]); ys[i] = (u32)cord_y(a[i]); }
-        best_chains_serial(xs, ys, m, rec, pm.score_type, c.pair_evals);
-        AnchorSink sink; sink.anchors = a; sink.hits = &hits; sink.hscore = &hscore; sink.first_len = 0; sink.nchains = 0;
-        traceback(rec, m, sink, chain, chain_sc, cnt, 1, 45, 50, 0.0f);
+        AnchorSink sink; sink.anchors = a; sink.hits = &hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
+        traceback(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, 1, 45, 50, 0.0f);
     }
     if (dbg && dbg->hits_chain) { for (u32 i = 0; i < hits.n; i++) dbg->hits_chain[i] = hits[i]; *dbg->nhits_chain = hits.n; }
     // getAnchorHitsChains pmpfinder.cpp:2535-2545
-    Vec<UP> sep; sep.init(ar.get<UP>(cap + 2), cap + 2, &ovf);
-    gather_blocks(hits.p, hits.n, nullptr, sep, 1, hits.n, c.L, 600, 0, 0);
-    u64 *cuts = ar.get<u64>(2 * (u64)cap + 4), *xy_strs = ar.get<u64>(cap + 2);
-    Vec<UP> tmp; tmp.init(ar.get<UP>(cap + 2), cap + 2, &ovf);
-    if (ar.ovf) return 1;
-    prefilter_chains2(hits.p, hits.n, sep, cuts, xy_strs, tmp);
-    i32 *sep_score = ar.get<i32>(cap + 2);
-    for (u32 i = 0; i < sep.n; i++) sep_score[i] = hscore[(u32)sep[i].first] - hscore[(u32)sep[i].second - 1];
-    // chainBlocksHits cluster_util.cpp:721-732
-    BlockSink bs; bs.el = tmp.p; bs.off = chain; bs.nchains = 0; bs.nel = 0; bs.cap = cap + 2; bs.ovf = &ovf; bs.first_len = 0; bs.off[0] = 0;
-    BlockScratch s; s.ptr = xs; s.sep_tmp = (UP *)cuts; s.score_tmp = (i32 *)ys; s.rec = rec; s.chain = chain_sc; s.chain_sc = (i32 *)xy_strs; s.cnt = cnt;
-    chain_blocks_base(bs, hits.p, sep.p, sep_score, sep.n, c.L, 2, 0, 1, s);
-    u64 *hits2 = a;   // anchors are dead by now: reuse as the rewritten hits (cap+? slots: hits never exceed m+1 <= cap)
+    gather_blocks(hits.p, hits.n, nullptr, S.sep, 1, hits.n, c.L, 600, 0, 0);
+    prefilter_chains2(hits.p, hits.n, S.sep, S.cuts, S.xy_strs, S.tmp);
+    for (u32 i = 0; i < S.sep.n; i++) S.sep_score[i] = S.hscore[(u32)S.sep[i].first] - S.hscore[(u32)S.sep[i].second - 1];
+    // chainBlocksHits cluster_util.cpp:721-732 (scratch arrays of the anchor DP are dead and reused)
+    BlockSink bs; bs.el = S.tmp.p; bs.off = S.chain; bs.nchains = 0; bs.nel = 0; bs.cap = S.tmp.cap; bs.ovf = ovf; bs.first_len = 0; bs.off[0] = 0;
+    BlockScratch s; s.ptr = S.xs; s.sep_tmp = (UP *)S.cuts; s.score_tmp = (i32 *)S.ys; s.rec = S.rec; s.chain = S.chain_sc; s.chain_sc = (i32 *)S.xy_strs; s.cnt = S.cnt;
+    chain_blocks_base(bs, hits.p, S.sep.p, S.sep_score, S.sep.n, c.L, 2, 0, 1, s);
+    u64 *hits2 = a;   // anchors are dead by now; hits never outnumber them
     u32 nh2 = filter_blocks_hits(bs, hits.p, hits2);
     u64 *H; u32 nH;
     if (nh2 == 0xffffffffu) { H = hits.p; nH = hits.n; } else { H = hits2; nH = nh2; }
     if (dbg && dbg->hits_blocks) { for (u32 i = 0; i < nH; i++) dbg->hits_blocks[i] = H[i]; *dbg->nhits_blocks = nH; }
-    if (ovf) return 1;
+    if (*ovf) return 1;
     // path_dst alg 2 (pmpfinder.cpp:1447-1469)
     if (nH >= 2) {
         nH = filter_hits(H, nH, c.f1, c.g);
         path_dst_2(H, nH, c.f1, c.g, cords, c.read_str, c.read_end, c.L);
     }
-    return (ovf || *cords.ovf) ? 1 : 0;
+    return (*ovf || *cords.ovf) ? 1 : 0;
 }
 
 // ==================================================================== tails ====

@@ -1,0 +1,616 @@
+// lnr_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the filter hot path.
+// Included by lnr_api.hip (single translation unit).  All per-read stage logic lives in
+// lnr_hd.h; this file holds the data-parallel kernels and the wave-parallel twins of the
+// serial stages (binning, radix sort, chaining DP).
+//
+// Kernel inventory (reference rows of SURVEY.md 8a in brackets):
+//   index build  [a3-a5]: k_ix_chunk_const, k_ix_sample, k_ix_start_blk, k_max_top, k_ix_rec,
+//                         k_ix_omit, k_scan_*, k_ix_scatter, k_ix_sort_small, k_ix_sort_big
+//   features     [a6]   : k_f2 (genome), k_f1 (reads, both strands)
+//   read prep    [a1,a2]: k_prep (padded copy + reverse complement + hashInit N-skip)
+//   seed lookup  [a3,a4,a7]: k_seed_count, k_seed_gather
+//   per-read job [a8-a16]: k_job (binning, radix sort, filter, introsort, DP, traceback, blocks, windows)
+//   tails        [a17-a20]: k_tail_a, k_tail_b, k_gather_out
+#pragma once
+#include <hip/hip_runtime.h>
+#include "lnr_hd.h"
+
+namespace lnr {
+
+#define WAVE 64
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ULL << lane_id()) - 1ULL; }
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+    for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(v, o); if (lane_id() >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ i64 wave_max_i64(i64 v) {
+    for (int o = 32; o > 0; o >>= 1) { i64 t = __shfl_xor((long long)v, o); v = t > v ? t : v; }
+    return v;
+}
+
+// ============================================================ generic scans ====
+#define SCAN_TPB 256
+#define SCAN_IPT 16
+#define SCAN_BLK (SCAN_TPB * SCAN_IPT)
+
+__global__ void __launch_bounds__(SCAN_TPB) k_scan_blk(const i32 *in, i32 *out, u64 n, i32 *blk_sums) {
+    __shared__ i32 sh[SCAN_TPB];
+    u64 base = (u64)blockIdx.x * SCAN_BLK + (u64)threadIdx.x * SCAN_IPT;
+    i32 v[SCAN_IPT];
+    i32 sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) { u64 idx = base + k; v[k] = idx < n ? in[idx] : 0; sum += v[k]; }
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < SCAN_TPB; off <<= 1) {
+        i32 t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    i32 run = sh[threadIdx.x] - sum;
+    if (threadIdx.x == SCAN_TPB - 1) blk_sums[blockIdx.x] = sh[SCAN_TPB - 1];
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) { u64 idx = base + k; if (idx < n) out[idx] = run; run += v[k]; }
+}
+// exclusive scan of nblk block sums by one 1024-thread block
+__global__ void __launch_bounds__(1024) k_scan_top(i32 *blk, u32 nblk) {
+    __shared__ i32 sh[1024];
+    __shared__ i32 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < nblk; base += 1024) {
+        u32 i = base + threadIdx.x;
+        i32 v = i < nblk ? blk[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            i32 t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        i32 c = carry;
+        if (i < nblk) blk[i] = c + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + sh[1023];
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(SCAN_TPB) k_scan_add(i32 *out, u64 n, const i32 *blk) {
+    u64 base = (u64)blockIdx.x * SCAN_BLK + (u64)threadIdx.x * SCAN_IPT;
+    i32 add = blk[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) { u64 idx = base + k; if (idx < n) out[idx] += add; }
+}
+
+// ============================================================== index build ====
+struct ChunkDesc { u64 seq_off; i64 t_str; u64 samp_base; u32 nsamp; u32 seq_id; i32 ks; i32 C; };
+static const u32 X_MASK = (1u << 26) - 1, X_REC = 1u << 30, X_FIRST = 1u << 31;
+
+// hashInit's N-skip and the strand-selector constant of every chunk (one thread per chunk; the
+// N scan is serial but runs once per chunk and stops at the first N-free 21-mer)
+__global__ void k_ix_chunk_const(const u8 *g, ChunkDesc *ch, u32 nch) {
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch) return;
+    const u8 *s = g + ch[c].seq_off;
+    int ks = shape_init_skip(s + ch[c].t_str);
+    ch[c].ks = ks;
+    ch[c].C = shape_const(s, (u64)ch[c].t_str, ks, (u64)ch[c].t_str);
+}
+// one thread per genome sample: minimizer X, Y, strand in closed form
+__global__ void __launch_bounds__(256) k_ix_sample(const u8 *g, const ChunkDesc *ch, u32 nch, u64 nsamp, u32 *Xs, u64 *vals) {
+    u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nsamp) return;
+    u32 lo = 0, hi = nch - 1;   // last chunk with samp_base <= m
+    while (lo < hi) { u32 mid = (lo + hi + 1) >> 1; if (ch[mid].samp_base <= m) lo = mid; else hi = mid - 1; }
+    ChunkDesc c = ch[lo];
+    u64 ml = m - c.samp_base;
+    u64 j = (u64)c.t_str + 8 + 9 * ml;
+    SeedOut o = seed_sample(g + c.seq_off, j, (u64)c.t_str, (u64)c.t_str, c.ks, c.C);
+    Xs[m] = o.X | (ml == 0 ? X_FIRST : 0);
+    vals[m] = create_cord(c.seq_id, j + ANCHOR_ZERO, o.Y, o.strand);
+}
+// "recorded" rule of the two-pass build (index_util.cpp:1680-1685,1756-1767): a sample is kept iff it sits
+// at an even position inside its run of equal minimizers (runs restart at chunk borders).  Needs, per
+// sample, the index of the last run start at or before it: a max-scan, done in three kernels.
+#define REC_TPB 256
+#define REC_IPT 4
+#define REC_BLK (REC_TPB * REC_IPT)
+__device__ __forceinline__ bool ix_is_start(const u32 *Xs, u64 m) {
+    u32 x = Xs[m];
+    if (x & X_FIRST) return true;
+    return (x & X_MASK) != (Xs[m - 1] & X_MASK);
+}
+__global__ void __launch_bounds__(REC_TPB) k_ix_start_blk(const u32 *Xs, u64 n, u32 *blk_max) {
+    __shared__ u32 sh[REC_TPB];
+    u64 base = (u64)blockIdx.x * REC_BLK + (u64)threadIdx.x * REC_IPT;
+    u32 mx = 0;
+    for (int k = 0; k < REC_IPT; k++) { u64 m = base + k; if (m < n && ix_is_start(Xs, m)) mx = (u32)m + 1; }
+    sh[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = REC_TPB / 2; off > 0; off >>= 1) { if (threadIdx.x < (unsigned)off) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + off]); __syncthreads(); }
+    if (threadIdx.x == 0) blk_max[blockIdx.x] = sh[0];
+}
+// exclusive running max over blocks
+__global__ void __launch_bounds__(1024) k_max_top(u32 *blk, u32 nblk) {
+    __shared__ u32 sh[1024];
+    __shared__ u32 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < nblk; base += 1024) {
+        u32 i = base + threadIdx.x;
+        u32 v = i < nblk ? blk[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            u32 t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] = max(sh[threadIdx.x], t);
+            __syncthreads();
+        }
+        u32 c = carry;
+        u32 excl = threadIdx.x ? sh[threadIdx.x - 1] : 0;
+        if (i < nblk) blk[i] = max(c, excl);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = max(c, sh[1023]);
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(REC_TPB) k_ix_rec(u32 *Xs, u64 n, const u32 *blk_prefix, i32 *cnt) {
+    __shared__ u32 sh[REC_TPB];
+    u64 base = (u64)blockIdx.x * REC_BLK + (u64)threadIdx.x * REC_IPT;
+    u32 st[REC_IPT];
+    u32 mx = 0;
+    for (int k = 0; k < REC_IPT; k++) { u64 m = base + k; st[k] = (m < n && ix_is_start(Xs, m)) ? (u32)m + 1 : 0; mx = max(mx, st[k]); }
+    sh[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 1; off < REC_TPB; off <<= 1) {
+        u32 t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] = max(sh[threadIdx.x], t);
+        __syncthreads();
+    }
+    u32 last = max(blk_prefix[blockIdx.x], threadIdx.x ? sh[threadIdx.x - 1] : 0u);
+    __syncthreads();   // all reads of Xs[m-1] across thread borders are done (st[] computed) before flags are written
+    for (int k = 0; k < REC_IPT; k++) {
+        u64 m = base + k;
+        if (m >= n) break;
+        last = max(last, st[k]);
+        if ((((u32)m + 1 - last) & 1) == 0) {
+            u32 x = Xs[m];
+            Xs[m] = x | X_REC;
+            atomicAdd(&cnt[x & X_MASK], 1);
+        }
+    }
+}
+__global__ void k_ix_omit(i32 *cnt, u64 n) {   // buckets of more than 400 entries are emptied (index_util.cpp:1705-1708)
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && cnt[i] > 400) cnt[i] = 0;
+}
+__global__ void __launch_bounds__(256) k_ix_scatter(const u32 *Xs, const u64 *vals, u64 n, const i32 *dir, i32 *fill, u64 *hs) {
+    u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    u32 x = Xs[m];
+    if (!(x & X_REC)) return;
+    x &= X_MASK;
+    i32 b = dir[x], e = dir[x + 1];
+    if (e > b) { i32 p = atomicAdd(&fill[x], 1); hs[b + p] = vals[m]; }
+}
+// per-bucket ascending sort (index_util.cpp:1788-1796).  Entries are distinct, so the result is unique.
+__global__ void __launch_bounds__(256) k_ix_sort_small(const i32 *dir, u64 nbuckets, u64 *hs, u32 *big, u32 *nbig) {
+    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    i32 s = dir[b], e = dir[b + 1];
+    i32 len = e - s;
+    if (len < 2) return;
+    if (len > 32) { u32 i = atomicAdd(nbig, 1u); big[i] = (u32)b; return; }
+    u64 *a = hs + s;
+    for (int i = 1; i < len; i++) {
+        u64 v = a[i];
+        int j = i - 1;
+        while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; j--; }
+        a[j + 1] = v;
+    }
+}
+__global__ void __launch_bounds__(64) k_ix_sort_big(const i32 *dir, u64 *hs, const u32 *big, u32 nbig) {
+    __shared__ u64 sh[512];
+    u32 bi = blockIdx.x;
+    if (bi >= nbig) return;
+    u32 b = big[bi];
+    i32 s = dir[b], len = dir[b + 1] - s;   // 33..400
+    for (int i = threadIdx.x; i < 512; i += 64) sh[i] = i < len ? hs[s + i] : ~0ULL;
+    __syncthreads();
+    for (int k = 2; k <= 512; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < 512; i += 64) {
+                int l = i ^ j;
+                if (l > i) {
+                    u64 x = sh[i], y = sh[l];
+                    bool up = (i & k) == 0;
+                    if ((x > y) == up) { sh[i] = y; sh[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < len; i += 64) hs[s + i] = sh[i];
+}
+
+// ================================================================= features ====
+// genome window features f2 (createFeatures2_48 parallel form, pmpfinder.cpp:589-652): entry m of a
+// sequence = 2-mer counts of bases [16m, 16m+48]; independent of the thread layout.
+__global__ void __launch_bounds__(256) k_f2(const u8 *g, const u64 *seq_off, const u64 *f2_off, u32 nseq, u64 total, F96 *f2) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    u32 lo = 0, hi = nseq - 1;
+    while (lo < hi) { u32 mid = (lo + hi + 1) >> 1; if (f2_off[mid] <= e) lo = mid; else hi = mid - 1; }
+    const u8 *s = g + seq_off[lo] + 16 * (e - f2_off[lo]);
+    i32 w0 = 0, w1 = 0, w2 = 0;
+    u32 prev = s[0];
+    for (int j = 1; j <= 48; j++) { u32 cur = s[j]; add2mer(w0, w1, w2, prev, cur); prev = cur; }
+    F96 o; o.v0 = w0; o.v1 = w1; o.v2 = w2; o.pad = 0;
+    f2[e] = o;
+}
+
+// ================================================================ read prep ====
+// Padded forward copy + reverse complement (_compltRvseStr, base.cpp:335-344) of every read, and the
+// N-skip hashInit would take at the read start.  One block per read.
+__global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, const u64 *rp_off, const u32 *lpad, u32 n, u8 *dst, i32 *read_ks) {
+    u32 r = blockIdx.x;
+    if (r >= n) return;
+    u64 o = off[r];
+    u32 L = (u32)(off[r + 1] - o);
+    u32 P = lpad[r];
+    u8 *fwd = dst + rp_off[r], *rev = fwd + P;
+    for (u32 i = threadIdx.x; i < P; i += blockDim.x) {
+        u8 a = 0, b = 0;
+        if (i < L) {
+            a = src[o + i]; if (a > 4) a = 4;
+            u8 c = src[o + L - 1 - i]; if (c > 4) c = 4;
+            b = c == 4 ? 4 : 3 - c;
+        }
+        fwd[i] = a;
+        rev[i] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) read_ks[r] = shape_init_skip(fwd);
+}
+// read window features of both strands (createFeatures2_48 serial form, pmpfinder.cpp:556-588, in closed form)
+__global__ void __launch_bounds__(256) k_f1(const u8 *reads_p, const u64 *rp_off, const u32 *lpad, const u32 *nf, const u64 *f1_off, u32 n, F96 *f1) {
+    u32 r = blockIdx.x;
+    if (r >= n) return;
+    u32 cnt = nf[r];
+    const u8 *fwd = reads_p + rp_off[r];
+    F96 *out = f1 + f1_off[r];
+    for (u32 e = threadIdx.x; e < 2 * cnt; e += blockDim.x) {
+        u32 strand = e >= cnt;
+        u32 m = strand ? e - cnt : e;
+        const u8 *s = fwd + (strand ? lpad[r] : 0) + 16 * m;
+        i32 w0 = 0, w1 = 0, w2 = 0;
+        u32 prev = s[0];
+        for (int j = 1; j <= 48; j++) { u32 cur = s[j]; add2mer(w0, w1, w2, prev, cur); prev = cur; }
+        F96 o; o.v0 = w0; o.v1 = w1; o.v2 = w2; o.pad = 0;
+        out[e] = o;
+    }
+}
+
+// ============================================================== seed lookup ====
+struct SampRec { u32 xs; u32 y; i32 dstart; u32 dlen; };   // xs = X | strand<<26 | lookup<<27
+struct JobArrays {
+    const u32 *read, *str, *end, *mode;   // per job
+    const u64 *samp_off;                  // per job: first sample record
+};
+struct ReadArrays {
+    const u8 *bases; const u64 *rp_off; const u32 *lpad; const u32 *len; const i32 *ks;
+};
+
+// pass 1: one wave per job.  Minimizers of all samples, the "minimizer changed" lookup rule
+// (xpre of pmpfinder.cpp:1882,1906 is always the previous sample's X), bucket bounds from dir.
+__global__ void __launch_bounds__(64) k_seed_count(JobArrays J, ReadArrays R, const i32 *dir, u32 njobs, SampRec *samp, u32 *job_cap, u32 *job_look) {
+    u32 j = blockIdx.x;
+    if (j >= njobs) return;
+    int lane = lane_id();
+    u32 r = J.read[j];
+    const u8 *s = R.bases + R.rp_off[r];
+    u64 rs = J.str[j], re = J.end[j];
+    u32 alpha = (u32)job_parm((int)J.mode[j]).alpha;
+    int ks = R.ks[r];
+    u64 k0 = rs + 21;
+    int C = shape_const(s, 0, ks, k0);
+    u32 ns = seed_num_samples(rs, re, alpha);
+    SampRec *out = samp + J.samp_off[j];
+    u32 carry = 0, cap = 0, looks = 0;
+    for (u32 base = 0; base < ns; base += 64) {
+        u32 si = base + lane;
+        bool valid = si < ns;
+        SeedOut o; o.X = 0; o.Y = 0; o.strand = 0;
+        if (valid) o = seed_sample(s, k0 + alpha - 1 + (u64)alpha * si, k0, 0, ks, C);
+        u32 prev = __shfl_up(o.X, 1);
+        if (lane == 0) prev = carry;
+        bool look = valid && o.X != prev;
+        i32 ds = 0; u32 dl = 0;
+        if (look) { ds = dir[o.X]; dl = (u32)(dir[o.X + 1] - ds); }
+        if (valid) { SampRec rec; rec.xs = o.X | (o.strand << 26) | ((u32)look << 27); rec.y = o.Y; rec.dstart = ds; rec.dlen = dl; out[si] = rec; }
+        cap += wave_sum(dl);
+        looks += (u32)__popcll(__ballot(look));
+        carry = __shfl(o.X, 63);
+    }
+    if (lane == 0) { job_cap[j] = cap + 1; job_look[j] = looks; }
+}
+// pass 2: one wave per job.  (sample, bucket entry) pairs are flattened over the lanes, filtered on Y
+// (pmpfinder.cpp:1890-1899) and written in the reference's order by ballot compaction.
+__global__ void __launch_bounds__(64) k_seed_gather(JobArrays J, ReadArrays R, const u64 *hs, u32 job_lo, u32 job_hi, const SampRec *samp,
+                                                    const u64 *anc_off, u64 *anchors, u32 *n_anchors) {
+    __shared__ u32 s_incl[64], s_excl[64], s_xs[64], s_y[64];
+    __shared__ i32 s_ds[64];
+    u32 j = job_lo + blockIdx.x;
+    if (j >= job_hi) return;
+    int lane = lane_id();
+    u32 r = J.read[j];
+    u64 L = R.len[r];
+    u64 rs = J.str[j], re = J.end[j];
+    u32 alpha = (u32)job_parm((int)J.mode[j]).alpha;
+    u64 k0 = rs + 21;
+    u32 ns = seed_num_samples(rs, re, alpha);
+    const SampRec *in = samp + J.samp_off[j];
+    u64 *out = anchors + anc_off[j];
+    if (lane == 0) out[0] = 0;   // the dummy the reference keeps at anchors[0] (base.cpp:272-277)
+    u32 nout = 1;
+    for (u32 base = 0; base < ns; base += 64) {
+        u32 si = base + lane;
+        SampRec rec; rec.xs = 0; rec.y = 0; rec.dstart = 0; rec.dlen = 0;
+        if (si < ns) rec = in[si];
+        u32 incl = wave_incl_scan(rec.dlen);
+        u32 total = __shfl(incl, 63);
+        __syncthreads();
+        s_incl[lane] = incl; s_excl[lane] = incl - rec.dlen; s_xs[lane] = rec.xs; s_y[lane] = rec.y; s_ds[lane] = rec.dstart;
+        __syncthreads();
+        for (u32 e0 = 0; e0 < total; e0 += 64) {
+            u32 e = e0 + lane;
+            bool act = e < total;
+            bool match = false;
+            u64 av = 0;
+            if (act) {
+                int lo = 0, hi = 63;   // first sample whose inclusive count exceeds e
+                while (lo < hi) { int mid = (lo + hi) >> 1; if (s_incl[mid] > e) hi = mid; else lo = mid + 1; }
+                u64 ent = hs[s_ds[lo] + (i32)(e - s_excl[lo])];
+                if (y_match(cord_y(ent), s_y[lo])) {
+                    match = true;
+                    u64 k = k0 + alpha - 1 + (u64)alpha * (base + lo);
+                    av = val2anchor(ent, k, L, (s_xs[lo] >> 26) & 1);
+                }
+            }
+            u64 mask = __ballot(match);
+            if (match) out[nout + __popcll(mask & lanemask_lt())] = av;
+            nout += (u32)__popcll(mask);
+        }
+    }
+    if (lane == 0) n_anchors[j] = nout;
+}
+
+// =================================================================== job =====
+struct JobArgs {
+    const u32 *grp_beg;     // [ngroups+1] job ranges; all jobs of a group belong to one read and run in order
+    JobArrays J;
+    const u64 *anc_off; const u32 *job_cap; const u32 *n_anchors; const u64 *scr_off;
+    u64 *anchors; char *scratch;
+    const u32 *read_len; const u64 *f1_off; const u32 *nf; const F96 *f1;
+    GenomeFeat g;
+    u64 *cords; const u64 *cords_off; const u32 *cords_cap; u32 *ncords; i32 *read_err;
+    u32 nbins; u32 grp_lo, grp_hi;
+};
+
+// wave-parallel twin of binning_filter_serial: LDS histogram of anchor x-field / 30000 (saturating u16
+// halves of u32 words), order-preserving ballot compaction.
+__device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 nbins) {
+    int lane = lane_id();
+    u32 nw = (nbins + 1) >> 1;
+    for (u32 w = lane; w < nw; w += 64) binw[w] = 0;
+    __syncthreads();
+    for (u32 i = lane; i < n; i += 64) {
+        u32 b = (u32)(cord_x(a[i]) / 30000);
+        if (b < nbins) {
+            u32 inc = (b & 1) ? 0x10000u : 1u;
+            u32 old = atomicAdd(&binw[b >> 1], inc);
+            u32 half = (b & 1) ? (old >> 16) : (old & 0xffffu);
+            if (half >= 0x8000u) atomicSub(&binw[b >> 1], inc);   // saturate well below carry into the neighbour half
+        }
+    }
+    __syncthreads();
+    u32 ii = 0;
+    for (u32 base = 0; base < n; base += 64) {
+        u32 i = base + lane;
+        u64 v = i < n ? a[i] : 0;
+        bool keep = false;
+        if (i < n) {
+            u32 b = (u32)(cord_x(v) / 30000);
+            if (b < nbins) { u32 w = binw[b >> 1]; keep = ((b & 1) ? (w >> 16) : (w & 0xffffu)) > 10; }
+        }
+        u64 mask = __ballot(keep);
+        if (keep) a[ii + __popcll(mask & lanemask_lt())] = v;
+        ii += (u32)__popcll(mask);
+    }
+    __syncthreads();
+    return ii ? ii : n;   // nothing survives -> everything is kept (pmpfinder.cpp:2007-2010)
+}
+
+// wave-level LSD radix sort, ascending u64 (the reference's ska_sort, base.cpp:570; result unique).
+// Returns with the sorted keys in `a`.  hist = 256 LDS words.
+__device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
+    int lane = lane_id();
+    u64 *src = a, *dst = alt;
+    for (int pass = 0; pass < 8; pass++) {
+        int shift = pass * 8;
+        for (int b = lane; b < 256; b += 64) hist[b] = 0;
+        __syncthreads();
+        for (u32 i = lane; i < n; i += 64) atomicAdd(&hist[(src[i] >> shift) & 255], 1u);
+        __syncthreads();
+        // exclusive prefix over the 256 bins: 4 bins per lane
+        u32 c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        bool uniform = (c0 == n) || (c1 == n) || (c2 == n) || (c3 == n);
+        if (__ballot(uniform)) { __syncthreads(); continue; }   // every key has the same digit: pass is the identity
+        u32 s4 = c0 + c1 + c2 + c3;
+        u32 ex = wave_incl_scan(s4) - s4;
+        __syncthreads();
+        hist[4 * lane] = ex; hist[4 * lane + 1] = ex + c0; hist[4 * lane + 2] = ex + c0 + c1; hist[4 * lane + 3] = ex + c0 + c1 + c2;
+        __syncthreads();
+        for (u32 base = 0; base < n; base += 64) {
+            u32 i = base + lane;
+            bool valid = i < n;
+            u64 key = valid ? src[i] : 0;
+            u32 d = (u32)(key >> shift) & 255;
+            u64 m = __ballot(valid);
+            for (int bit = 0; bit < 8; bit++) { u64 bm = __ballot((d >> bit) & 1); m &= ((d >> bit) & 1) ? bm : ~bm; }
+            u32 pos = 0;
+            if (valid) pos = hist[d] + (u32)__popcll(m & lanemask_lt());
+            __syncthreads();
+            if (valid) {
+                dst[pos] = key;
+                if ((m >> lane) >> 1 == 0) hist[d] += (u32)__popcll(m);   // highest lane of the digit group advances the cursor
+            }
+            __syncthreads();
+        }
+        u64 *t = src; src = dst; dst = t;
+    }
+    if (src != a) { for (u32 i = lane; i < n; i += 64) a[i] = src[i]; }
+    __syncthreads();
+}
+
+// wave-parallel twin of best_chains_serial (getBestChains, cluster_util.cpp:53-111): serial over i, lanes over
+// the predecessor window, max-reduce with "smallest j wins among equal totals".
+__device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type) {
+    int lane = lane_id();
+    u32 p300 = 0;
+    for (u32 i = 0; i < m; i++) {
+        u32 xi = xs[i], yi = ys[i];
+        int j_str = (int)i - 20 < 0 ? 0 : (int)i - 20;
+        while (p300 < i && xs[p300] - xi >= 300) p300++;
+        int j_lo = (int)p300 < j_str ? (int)p300 : j_str;
+        i64 best = -1;
+        for (int jb = (int)i - 1; jb >= j_lo; jb -= 64) {
+            int j = jb - lane;
+            if (j >= j_lo) {
+                int sc = score_type ? chain_score0(xs[j], ys[j], xi, yi) : chain_score(xs[j], ys[j], xi, yi);
+                if (sc > 0) {
+                    i64 key = ((i64)(sc + r.score[j]) << 32) | (i64)(u32)(0x7fffffff - j);
+                    best = key > best ? key : best;
+                }
+            }
+        }
+        best = wave_max_i64(best);
+        if (lane == 0) {
+            if (best >= 0) {
+                int tot = (int)(best >> 32);
+                int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff);
+                r.p2[i] = mj; r.score[i] = tot; r.len[i] = r.len[mj] + 1; r.score2[i] = tot;
+                r.root[i] = r.root[mj]; r.leaf[i] = 1; r.leaf[mj] = 0;
+            } else {
+                r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = (i32)i; r.leaf[i] = 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One wave per read: runs the read's jobs in order (round 0: the whole read; remap round: its gaps),
+// appending cords to the read's cord list exactly like consecutive apxMap_ calls do.
+__global__ void __launch_bounds__(64) k_job(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];   // binning halves
+    __shared__ u32 hist[256];
+    __shared__ u32 s_m;
+    __shared__ int s_ovf;
+    u32 grp = A.grp_lo + blockIdx.x;
+    if (grp >= A.grp_hi) return;
+    int lane = lane_id();
+    u32 jb = A.grp_beg[grp], je = A.grp_beg[grp + 1];
+    if (jb >= je) return;
+    u32 r = A.J.read[jb];
+    u64 L = A.read_len[r];
+    if (lane == 0) s_ovf = 0;
+    __syncthreads();
+    Vec<u64> cords;
+    cords.init(A.cords + A.cords_off[r], A.cords_cap[r], &s_ovf);
+    cords.n = A.ncords[r];
+    for (u32 j = jb; j < je; j++) {
+        u64 *a = A.anchors + A.anc_off[j];
+        u32 n = A.n_anchors[j];
+        u32 cap = A.job_cap[j] + 2;
+        Arena ar; ar.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
+        JobScratch S;
+        bool ok = job_carve(ar, cap, S, &s_ovf);
+        if (!ok) { if (lane == 0) s_ovf = 1; __syncthreads(); break; }
+        n = binning_wave(a, n, dyn_lds, A.nbins);
+        if (n > 1) {
+            if (lane == 0) a[0] = 0;   // filterAnchorsList pmpfinder.cpp:2031
+            __syncthreads();
+            radix_sort_wave(a, S.alt, n, hist);
+        }
+        if (lane == 0) s_m = job_phase1(a, n, S, nullptr);
+        __syncthreads();
+        u32 m = s_m;
+        int mode = (int)A.J.mode[j];
+        if (m >= 2) best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type);
+        if (lane == 0) {
+            JobCtx c;
+            c.L = L; c.read_str = A.J.str[j]; c.read_end = A.J.end[j]; c.mode = mode;
+            u32 nf = A.nf[r];
+            c.f1[0].p = A.f1 + A.f1_off[r]; c.f1[0].n = nf;
+            c.f1[1].p = A.f1 + A.f1_off[r] + nf; c.f1[1].n = nf;
+            c.g = A.g; c.bins = nullptr; c.nbins = 0; c.pair_evals = nullptr;
+            if (job_phase3(a, m, S, c, cords, nullptr)) s_ovf = 1;
+        }
+        __syncthreads();
+        if (s_ovf) break;
+    }
+    if (lane == 0) { A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
+}
+
+// =================================================================== tails ====
+struct TailArgs {
+    const u32 *read_len; u32 n;
+    u64 *cords; const u64 *cords_off; const u32 *cords_cap; u32 *ncords; i32 *read_err;
+    char *scratch; const u64 *scr_off; const u32 *scr_cap;   // per read: bytes offset / capacity in cord slots used for sizing
+    UP *gaps; const u64 *gaps_off; const u32 *gaps_cap; u32 *ngaps; u32 *remap;
+    u64 *out_str, *out_end; u32 *nout;
+};
+__global__ void __launch_bounds__(64) k_tail_a(TailArgs T) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= T.n) return;
+    T.ngaps[r] = 0; T.remap[r] = 0;
+    u64 L = T.read_len[r];
+    if (L <= 200 || T.read_err[r]) return;
+    Arena ar; ar.init(T.scratch + T.scr_off[r], tail_scratch_bytes(T.scr_cap[r]));
+    u32 nc = T.ncords[r], ng = 0, rm = 0;
+    int rc = tail_a(T.cords + T.cords_off[r], nc, L, ar, T.gaps + T.gaps_off[r], T.gaps_cap[r], ng, rm);
+    T.ncords[r] = nc; T.ngaps[r] = ng; T.remap[r] = rm;
+    if (rc || ar.ovf) T.read_err[r] = 2;
+}
+__global__ void __launch_bounds__(64) k_tail_b(TailArgs T) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= T.n) return;
+    T.nout[r] = 0;
+    u64 L = T.read_len[r];
+    if (L <= 200 || T.read_err[r]) return;
+    Arena ar; ar.init(T.scratch + T.scr_off[r], tail_scratch_bytes(T.scr_cap[r]));
+    u32 no = 0;
+    int rc = tail_b(T.cords + T.cords_off[r], T.ncords[r], L, ar, T.out_str + T.cords_off[r], T.out_end + T.cords_off[r], T.cords_cap[r], no);
+    T.nout[r] = no;
+    if (rc || ar.ovf) { T.read_err[r] = 3; T.nout[r] = 0; }
+}
+__global__ void __launch_bounds__(64) k_gather_out(const u64 *out_str, const u64 *out_end, const u64 *cords_off, const u32 *nout, const u64 *cord_off, u32 n,
+                                                   u64 *cs, u64 *ce) {
+    u32 r = blockIdx.x;
+    if (r >= n) return;
+    u32 c = nout[r];
+    const u64 *s = out_str + cords_off[r], *e = out_end + cords_off[r];
+    u64 o = cord_off[r];
+    for (u32 i = threadIdx.x; i < c; i += blockDim.x) { cs[o + i] = s[i]; ce[o + i] = e[i]; }
+}
+
+}  // namespace lnr

@@ -122,7 +122,12 @@ int run_job(Shim &c, const u8 *read, u64 L, u64 read_str, u64 read_end, int mode
     std::vector<u64> d1(cap), d2(cap), d3(cap + 2);
     u32 n1 = 0, n2 = 0, n3 = 0;
     if (dbg) { jd.filt = d1.data(); jd.nfilt = &n1; jd.xsort = d2.data(); jd.nxsort = &n2; jd.hits_chain = d3.data(); jd.nhits_chain = &n3; }
-    int rc = job_after_sort(a.data(), n, cap, ar, jc, cords, dbg ? &jd : nullptr);
+    int ovf = 0;
+    JobScratch S;
+    if (!job_carve(ar, cap, S, &ovf)) return 1;
+    u32 m = job_phase1(a.data(), n, S, dbg ? &jd : nullptr);
+    if (m >= 2) best_chains_serial(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, jc.pair_evals);
+    int rc = job_phase3(a.data(), m, S, jc, cords, dbg ? &jd : nullptr);
     if (dbg) { c.dbg[1].assign(d1.begin(), d1.begin() + n1); c.dbg[2].assign(d2.begin(), d2.begin() + n2); c.dbg[3].assign(d3.begin(), d3.begin() + n3); }
     return rc;
 }

@@ -1,0 +1,101 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the reference's golden
+vectors.  Bit-exact: every value on this path is an integer word."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+PARAMS = [(n, T) for n, (_, Ts) in cases.CASES.items() for T in Ts]
+
+
+@pytest.fixture(scope="module")
+def flt():
+    from linear_amd import build as lb
+    lb.build()
+    from linear_amd import Filter
+    f = Filter(device=0)
+    yield f
+    f.close()
+
+
+@pytest.mark.parametrize("name,T", PARAMS)
+def test_gpu_matches_golden(flt, case_inputs, name, T):
+    refs, reads, off = case_inputs(name)
+    g = np.load(os.path.join(GOLD, f"{name}_T{T}.npz"))
+    assert cases.input_digest(refs, reads, off) == str(g["digest"])
+    info = flt.build_index(refs, T)
+    assert info.hs_len == int(g["hs_len"])
+    dir_, hs, f2, f2_off = flt.index_export()
+    assert cases.sha(dir_) == str(g["dir_sha"]), "dir differs from the reference"
+    assert np.array_equal(hs[:4096], g["hs_head"])
+    assert cases.sha(hs) == str(g["hs_sha"]), "hs differs from the reference"
+    for k in range(len(refs)):
+        f = f2[int(f2_off[k]):int(f2_off[k + 1])]
+        assert f.shape[0] == int(g["f2_len"][k])
+        assert cases.sha(np.ascontiguousarray(f[:-1])) == str(g["f2_sha"][k]), f"f2 of sequence {k}"
+    # stage a7: raw anchors
+    aoff, anc = flt.seed_lookup_batch(reads, off)
+    for k, i in enumerate(g["stage_reads"]):
+        got = anc[int(aoff[i]):int(aoff[i + 1])]
+        assert np.array_equal(got, g[f"st{k}_raw"]), f"raw anchors of read {i}"
+    # the whole path
+    coff, cs, ce = flt.filter_batch(reads, off)
+    assert np.array_equal(coff, g["cord_off"])
+    assert np.array_equal(cs, g["cords_str"])
+    assert np.array_equal(ce, g["cords_end"])
+
+
+def test_gpu_matches_oracle_fresh_seed(flt, oracle_lib):
+    """Fresh inputs without a stored golden: oracle as the checker, incl. the seed-byte counters of SURVEY 8(d)."""
+    from linear_amd import synth
+    refs = [synth.repeat_ref(500_000, 321), synth.add_n_runs(synth.random_ref(200_000, 322), 323, lead=3000)]
+    reads, off, _ = synth.sample_reads(refs, 200, 7000, 0.1, 324, "random", len_jitter=0.6)
+    o = oracle_lib.Checker("oracle", refs, 3)
+    flt.build_index(refs, 3)
+    dir_, hs, _, _ = flt.index_export()
+    assert np.array_equal(dir_, o.dir()) and np.array_equal(hs, o.hs())
+    ooff, ocs, oce, ost = o.map_batch(reads, off, threads=8)
+    coff, cs, ce = flt.filter_batch(reads, off)
+    assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
+    st = flt.stats()
+    assert (st["samples"], st["lookups"], st["bucket_entries"], st["anchors"]) == tuple(int(x) for x in ost[:4])
+
+
+def test_gpu_edge_batches(flt, oracle_lib):
+    """Empty batch, batch of only too-short reads, single read, ragged lengths."""
+    from linear_amd import synth
+    ref = synth.random_ref(300_000, 77)
+    flt.build_index([ref], 1)
+    o = oracle_lib.Checker("oracle", [ref], 1)
+    coff, cs, ce = flt.filter_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert coff.tolist() == [0] and cs.size == 0
+    short, soff = synth.pack_reads([ref[10:60], ref[100:300], np.zeros(0, np.uint8)])
+    coff, cs, ce = flt.filter_batch(short, soff)
+    assert coff.tolist() == [0, 0, 0, 0]
+    lst = [ref[1000:1000 + L].copy() for L in (201, 250, 999, 4097, 12000, 30000)]
+    rd, ro = synth.pack_reads(lst)
+    coff, cs, ce = flt.filter_batch(rd, ro)
+    ooff, ocs, oce, _ = o.map_batch(rd, ro, threads=2)
+    assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
+    # offsets that do not start at zero (a window into a larger buffer)
+    coff2, cs2, ce2 = flt.filter_batch(rd, ro[2:])
+    assert np.array_equal(cs2, ocs[int(ooff[2]):]) and np.array_equal(coff2, ooff[2:] - ooff[2])
+
+
+def test_gpu_scratch_slicing(oracle_lib):
+    """A tiny scratch budget forces the job kernel to run in several slices; results must not change."""
+    from linear_amd import Filter, synth
+    ref = synth.repeat_ref(400_000, 55)
+    reads, off, _ = synth.sample_reads([ref], 120, 5000, 0.08, 56, "random")
+    f = Filter(device=0, scratch_budget=4 << 20)
+    f.build_index([ref], 1)
+    coff, cs, ce = f.filter_batch(reads, off)
+    assert f.stats()["job_launches"] > 1
+    o = oracle_lib.Checker("oracle", [ref], 1)
+    ooff, ocs, oce, _ = o.map_batch(reads, off, threads=4)
+    assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
+    f.close()
