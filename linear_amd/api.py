@@ -156,6 +156,19 @@ class Filter:
     def index_adopt(self):
         self._ck(self.lib.lnr_index_adopt(self.h))
 
+    # small-vector forms used by linear_amd.dist.broadcast_index
+    def index_info_vec(self) -> np.ndarray:
+        i = self.index_info()
+        return np.array([i.nseq, i.layout_threads, i.genome_bytes, i.dir_len, i.hs_len, i.f2_len, i.n_samples, 0], dtype=np.int64)
+
+    def seq_len(self) -> np.ndarray:
+        return np.asarray(self._seq_len, dtype=np.int64)
+
+    def index_alloc_from(self, vec8: np.ndarray, seq_len: np.ndarray):
+        info = LnrIndexInfo()
+        info.nseq, info.layout_threads, info.genome_bytes, info.dir_len, info.hs_len, info.f2_len, info.n_samples = [int(v) for v in vec8[:7]]
+        self.index_alloc(info, np.asarray(seq_len, dtype=np.uint64))
+
     # --------------------------------------------------------------- batches
     def filter_batch(self, reads: np.ndarray, off: np.ndarray):
         reads = np.ascontiguousarray(reads, dtype=np.uint8)

@@ -172,3 +172,52 @@ def edge_reads(refs: list[np.ndarray], seed: int) -> list[np.ndarray]:
         out.append(mutate(refs[1][1000:9000], 0.1, rng))
         out.append(revcomp(mutate(refs[-1][2000:7000], 0.1, rng)))
     return out
+
+
+def chr22_like(seed: int = 2022, length: int = 50_818_468, lead_n: int = 10_510_000) -> np.ndarray:
+    """Stand-in for GRCh38 chr22 (no network / no genome file on the box): same length, the ~10.5 Mb of
+    leading N of the p-arm, and a human-like repeat spectrum on the rest -- interspersed repeat families
+    with 2-25 % divergence over ~45 % of the sequence, tandem repeats over ~3 %, a few large segmental
+    duplications -- so minimizer buckets, anchor counts and the chaining load are neither the repeat-free
+    nor the worst-case regime of BASELINE.md section 2."""
+    rng = np.random.default_rng(seed)
+    ref = rng.integers(0, 4, size=length, dtype=np.uint8)
+    body0 = lead_n
+    fams = [(rng.integers(0, 4, size=int(rng.integers(280, 6500)), dtype=np.uint8), float(rng.choice([0.02, 0.05, 0.10, 0.15, 0.20, 0.25], p=[0.05, 0.10, 0.20, 0.25, 0.25, 0.15])))
+            for _ in range(40)]
+    target = 0.45 * (length - body0)
+    filled = 0
+    while filled < target:
+        f, div = fams[int(rng.integers(0, len(fams)))]
+        a = int(rng.integers(0, max(1, f.size - 300)))
+        b = int(rng.integers(a + 280, f.size + 1))
+        cp = f[a:b].copy()
+        mut = rng.random(cp.size) < div
+        cp[mut] = (cp[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+        if rng.random() < 0.5:
+            cp = revcomp(cp)
+        pos = int(rng.integers(body0, length - cp.size))
+        ref[pos:pos + cp.size] = cp
+        filled += cp.size
+    filled = 0
+    while filled < 0.03 * (length - body0):
+        unit = rng.integers(0, 4, size=int(rng.integers(1, 70)), dtype=np.uint8)
+        n = int(rng.integers(100, 4000))
+        t = np.tile(unit, n // unit.size + 1)[:n]
+        pos = int(rng.integers(body0, length - n))
+        ref[pos:pos + n] = t
+        filled += n
+    for _ in range(6):   # segmental duplications, 1-2 % divergence
+        n = int(rng.integers(20_000, 120_000))
+        src = int(rng.integers(body0, length - n))
+        dst = int(rng.integers(body0, length - n))
+        cp = ref[src:src + n].copy()
+        mut = rng.random(n) < 0.015
+        cp[mut] = (cp[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+        ref[dst:dst + n] = cp
+    ref[:lead_n] = 4
+    for _ in range(8):   # internal assembly gaps
+        n = int(rng.integers(1000, 50_000))
+        pos = int(rng.integers(body0, length - n))
+        ref[pos:pos + n] = 4
+    return ref
