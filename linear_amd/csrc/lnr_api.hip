@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,6 +60,7 @@ struct lnr_ctx {
     lnr_index_info info{};
     std::vector<u64> seq_len, seq_off, f2_off;
     u32 nbins = 0;
+    size_t job_lds_bytes = 24 * 1024;   // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off;
     // ---- batch inputs / per-read arrays
     DevBuf in_reads, in_off;                       // staging for the host-buffer entry points
@@ -66,8 +68,8 @@ struct lnr_ctx {
     DevBuf cords, out_str, out_end, cords_off, cords_cap, ncords, nout, read_err;
     DevBuf tail_scr, tail_off, tail_cap, gaps, gaps_off, gaps_cap, ngaps, remap;
     // ---- jobs
-    DevBuf j_read, j_str, j_end, j_mode, j_samp_off, j_cap, j_look, j_anc_off, j_scr_off, j_nanc, grp_beg;
-    DevBuf samp, anchors, job_scr;
+    DevBuf j_read, j_str, j_end, j_mode, j_samp_off, j_cap, j_look, j_anc_off, j_scr_off, j_nanc, grp_beg, grp_order, job_list;
+    DevBuf samp, anchors, job_scr, prof;
     // ---- results
     DevBuf r_off, r_str, r_end;
     std::vector<u64> h_cord_off, h_cords_str, h_cords_end, h_anchor_off, h_anchors;
@@ -210,19 +212,38 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
     ctx->stats.samples += hj.nsamp;
     for (u32 j = 0; j < nj; j++) { ctx->stats.lookups += look[j]; ctx->stats.bucket_entries += cap[j] - 1; }
 
-    // slices of groups under the scratch budget
+    // launch order: heaviest group first (sum of bucket entries is the work proxy), so the long tail of
+    // repeat-rich reads starts at once instead of at the end of the grid
     u64 budget = ctx->opts.scratch_budget ? ctx->opts.scratch_budget : (24ULL << 30);
     u32 ngrp = (u32)hj.grp_beg.size() - 1;
+    std::vector<u32> order(ngrp);
+    for (u32 g = 0; g < ngrp; g++) order[g] = g;
+    if (with_job_kernel) {
+        std::vector<u64> w(ngrp, 0);
+        for (u32 g = 0; g < ngrp; g++) for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) w[g] += cap[j];
+        std::stable_sort(order.begin(), order.end(), [&w](u32 a, u32 b) { return w[a] > w[b]; });
+    }
+    std::vector<u32> job_list;
+    job_list.reserve(nj);
+    std::vector<u32> ord_job_beg(ngrp + 1, 0);
+    for (u32 k = 0; k < ngrp; k++) {
+        u32 g = order[k];
+        ord_job_beg[k] = (u32)job_list.size();
+        for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) job_list.push_back(j);
+    }
+    ord_job_beg[ngrp] = (u32)job_list.size();
+    if ((s = upload(ctx, ctx->grp_order, order)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->job_list, job_list)) != LNR_OK) return s;
+    // slices of (ordered) groups under the scratch budget
     std::vector<u64> anc_off(nj), scr_off(nj);
-    std::vector<u32> nanc_all;
-    if (keep_anchor_layout) nanc_all.resize(nj);
     u32 g0 = 0;
     while (g0 < ngrp) {
         u64 anc = 0, scr = 0;
         u32 g1 = g0;
         while (g1 < ngrp) {
             u64 a2 = anc, s2 = scr;
-            for (u32 j = hj.grp_beg[g1]; j < hj.grp_beg[g1 + 1]; j++) {
+            for (u32 q = ord_job_beg[g1]; q < ord_job_beg[g1 + 1]; q++) {
+                u32 j = job_list[q];
                 a2 += align_up((u64)cap[j] + 2, 2);
                 if (with_job_kernel) s2 += align_up(job_scratch_bytes((u64)cap[j] + 2), 256);
             }
@@ -230,25 +251,26 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             anc = a2; scr = s2; g1++;
         }
         u64 ao = 0, so = 0;
-        for (u32 j = hj.grp_beg[g0]; j < hj.grp_beg[g1]; j++) {
+        u32 j0 = ord_job_beg[g0], j1 = ord_job_beg[g1];   // positions in job_list
+        for (u32 q = j0; q < j1; q++) {
+            u32 j = job_list[q];
             anc_off[j] = ao; ao += align_up((u64)cap[j] + 2, 2);
             scr_off[j] = so; if (with_job_kernel) so += align_up(job_scratch_bytes((u64)cap[j] + 2), 256);
         }
-        u32 j0 = hj.grp_beg[g0], j1 = hj.grp_beg[g1];
         ENSURE(ctx->anchors, std::max<u64>(ao * 8, 16));
         if (with_job_kernel) ENSURE(ctx->job_scr, std::max<u64>(so, 16));
         ENSURE(ctx->j_anc_off, (size_t)nj * 8);
         ENSURE(ctx->j_scr_off, (size_t)nj * 8);
-        HIPCK(hipMemcpyAsync(ctx->j_anc_off.as<u64>() + j0, anc_off.data() + j0, (size_t)(j1 - j0) * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIPCK(hipMemcpyAsync(ctx->j_scr_off.as<u64>() + j0, scr_off.data() + j0, (size_t)(j1 - j0) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCK(hipMemcpyAsync(ctx->j_anc_off.p, anc_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCK(hipMemcpyAsync(ctx->j_scr_off.p, scr_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, ctx->stream));
         ctx->t_sg.start(ctx->stream);
-        hipLaunchKernelGGL(k_seed_gather, dim3(j1 - j0), dim3(64), 0, ctx->stream, J, R, ctx->hs.as<u64>(), j0, j1, ctx->samp.as<SampRec>(),
+        hipLaunchKernelGGL(k_seed_gather, dim3(j1 - j0), dim3(64), 0, ctx->stream, J, R, ctx->hs.as<u64>(), ctx->job_list.as<u32>(), j0, j1, ctx->samp.as<SampRec>(),
                            ctx->j_anc_off.as<u64>(), ctx->anchors.as<u64>(), ctx->j_nanc.as<u32>());
         KCHECK();
         ctx->t_sg.stop(ctx->stream);
         if (with_job_kernel) {
             JobArgs A;
-            A.grp_beg = ctx->grp_beg.as<u32>(); A.J = J;
+            A.grp_order = ctx->grp_order.as<u32>(); A.grp_beg = ctx->grp_beg.as<u32>(); A.J = J;
             A.anc_off = ctx->j_anc_off.as<u64>(); A.job_cap = ctx->j_cap.as<u32>(); A.n_anchors = ctx->j_nanc.as<u32>(); A.scr_off = ctx->j_scr_off.as<u64>();
             A.anchors = ctx->anchors.as<u64>(); A.scratch = ctx->job_scr.as<char>();
             A.read_len = ctx->rlen.as<u32>(); A.f1_off = ctx->f1_off.as<u64>(); A.nf = ctx->nf.as<u32>(); A.f1 = ctx->f1.as<F96>();
@@ -256,15 +278,24 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             A.cords = ctx->cords.as<u64>(); A.cords_off = ctx->cords_off.as<u64>(); A.cords_cap = ctx->cords_cap.as<u32>(); A.ncords = ctx->ncords.as<u32>();
             A.read_err = ctx->read_err.as<i32>();
             A.nbins = ctx->nbins; A.grp_lo = g0; A.grp_hi = g1;
-            size_t lds = (size_t)((ctx->nbins + 1) / 2) * 4;
+            A.prof = nullptr;
+#ifdef LNR_PROF
+            if (!ctx->prof.p) { if (!ctx->prof.ensure(32 * 8)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->prof.p, 0, 32 * 8, ctx->stream); }
+            A.prof = ctx->prof.as<unsigned long long>();
+#endif
+            size_t lds = std::max<size_t>((size_t)((ctx->nbins + 1) / 2) * 4, ctx->job_lds_bytes);
+            lds = (lds + 15) & ~(size_t)15;
+            A.lds_bytes = (u32)lds;
             ctx->t_job.start(ctx->stream);
             hipLaunchKernelGGL(k_job, dim3(g1 - g0), dim3(64), lds, ctx->stream, A);
             KCHECK();
             ctx->t_job.stop(ctx->stream);
         }
-        std::vector<u32> nanc(j1 - j0);
-        HIPCK(hipMemcpyAsync(nanc.data(), ctx->j_nanc.as<u32>() + j0, (size_t)(j1 - j0) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<u32> nanc_all(nj);
+        HIPCK(hipMemcpyAsync(nanc_all.data(), ctx->j_nanc.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCK(hipStreamSynchronize(ctx->stream));
+        std::vector<u32> nanc(j1 - j0);
+        for (u32 q = j0; q < j1; q++) nanc[q - j0] = nanc_all[job_list[q]];
         ctx->stats.seed_gather_ms += ctx->t_sg.ms();
         ctx->stats.seed_gather_launches++;
         if (with_job_kernel) { ctx->stats.job_ms += ctx->t_job.ms(); ctx->stats.job_launches++; }
@@ -273,11 +304,11 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             if (g0 != 0 || g1 != ngrp) { ctx->err = "anchor export needs the batch to fit one slice; lower the read count"; return LNR_ERR_LIMIT; }
             // export CSR of the raw anchors to the host arrays
             ctx->h_anchor_off.assign(nj + 1, 0);
-            for (u32 j = 0; j < nj; j++) ctx->h_anchor_off[j + 1] = ctx->h_anchor_off[j] + nanc[j];
+            for (u32 j = 0; j < nj; j++) ctx->h_anchor_off[j + 1] = ctx->h_anchor_off[j] + nanc_all[j];
             ctx->h_anchors.resize(ctx->h_anchor_off[nj]);
             std::vector<u64> all(ao);
             HIPCK(hipMemcpy(all.data(), ctx->anchors.p, ao * 8, hipMemcpyDeviceToHost));
-            for (u32 j = 0; j < nj; j++) memcpy(ctx->h_anchors.data() + ctx->h_anchor_off[j], all.data() + anc_off[j], (size_t)nanc[j] * 8);
+            for (u32 j = 0; j < nj; j++) memcpy(ctx->h_anchors.data() + ctx->h_anchor_off[j], all.data() + anc_off[j], (size_t)nanc_all[j] * 8);
         }
         g0 = g1;
     }
@@ -575,6 +606,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     ctx->opts = o;
     ctx->device = dev;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
+    if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }
     ctx->t_prep.init(); ctx->t_sc.init(); ctx->t_sg.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();
     *out = ctx;
     return LNR_OK;
@@ -811,6 +843,16 @@ lnr_status lnr_seed_lookup_batch(lnr_ctx *ctx, const uint8_t *reads, const uint6
     out->anchor_off = ctx->h_anchor_off.data(); out->anchors = ctx->h_anchors.data();
     return LNR_OK;
 }
+
+#ifdef LNR_PROF
+// diagnostic build only: cumulative per-phase cycle sums of k_job's lane 0 (16 counters)
+lnr_status lnr_prof_read(lnr_ctx *ctx, unsigned long long *out16) {
+    if (!ctx || !out16 || !ctx->prof.p) return LNR_ERR_ARG;
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    HIPCK(hipMemcpy(out16, ctx->prof.p, 32 * 8, hipMemcpyDeviceToHost));
+    return LNR_OK;
+}
+#endif
 
 lnr_status lnr_last_stats(const lnr_ctx *ctx, lnr_stats *st) {
     if (!ctx || !st) return LNR_ERR_ARG;

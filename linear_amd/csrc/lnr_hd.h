@@ -69,17 +69,25 @@ struct Vec {
     LNR_HD T &operator[](u32 i) { return p[i]; }
     LNR_HD T &back() { return p[n - 1]; }
 };
+// Bump allocator over caller-provided storage.  With `next` set it is two-level: requests that do not
+// fit the fast region (LDS in the kernel) fall through to the next one (global scratch).
 struct Arena {
-    char *base; u64 off, cap; int ovf;
-    LNR_HD void init(void *b, u64 c) { base = (char *)b; off = 0; cap = c; ovf = 0; }
-    template <class T> LNR_HD T *get(u64 n) {
+    char *base; u64 off, cap; int ovf; Arena *next;
+    LNR_HD void init(void *b, u64 c) { base = (char *)b; off = 0; cap = c; ovf = 0; next = nullptr; }
+    template <class T> LNR_HD T *get(u64 n) {   // iterative on purpose: no recursion in device code
         u64 bytes = (n * sizeof(T) + 15) & ~15ULL;
-        if (off + bytes > cap) { ovf = 1; return (T *)base; }
-        T *r = (T *)(base + off); off += bytes; return r;
+        Arena *a = this;
+        while (a->off + bytes > a->cap) {
+            if (!a->next) { a->ovf = 1; ovf = 1; return (T *)base; }
+            a = a->next;
+        }
+        T *r = (T *)(a->base + a->off);
+        a->off += bytes;
+        return r;
     }
 };
 // bytes of per-job scratch needed by job_process for a job with `cap` anchor slots
-LNR_HD inline u64 job_scratch_bytes(u64 cap) { return (cap + 2) * 144 + 1024; }
+LNR_HD inline u64 job_scratch_bytes(u64 cap) { return (cap + 2) * 160 + 1024; }
 LNR_HD inline u64 tail_scratch_bytes(u64 cap) { return cap * 240 + 8192; }
 
 // --------------------------------------------------------- minimizer shape ----
@@ -212,6 +220,17 @@ LNR_HD inline u32 wdist_raw(FeatView f1, FeatView f2, u64 x1, u64 x2) {   // __w
     return 1000;
 }
 
+// In-kernel phase stamps: compiled in only for the diagnostic build (-DLNR_PROF); the shipped
+// kernels contain no stamp.
+#if defined(LNR_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define LNR_TICK(prof, idx, last)                                                        \
+    do {                                                                                 \
+        if (prof) { unsigned long long t_ = clock64(); atomicAdd(&(prof)[idx], t_ - (last)); atomicMax(&(prof)[16 + (idx)], t_ - (last)); (last) = t_; } \
+    } while (0)
+#else
+#define LNR_TICK(prof, idx, last) do { } while (0)
+#endif
+
 // -------------------------------------------------------------- parameters ----
 struct JobParm { i32 alpha; i32 score_type; };   // PMPParms::toggle (pmpfinder.cpp:21-29,1778-1784,2493-2503)
 LNR_HD inline JobParm job_parm(int mode) { JobParm p; p.alpha = mode ? 7 : 15; p.score_type = mode ? 1 : 0; return p; }
@@ -341,35 +360,48 @@ struct BlockSink {       // chains of blocks (StringSet<String<UPair>>) flattene
     }
 };
 
-// traceBackChains0 cluster_util.cpp:121-205
+// traceBackChains0 cluster_util.cpp:121-205.  One iteration = (a) scan for the first maximal score and the
+// running maximum seen before it, (b) everything else.  The scan is separate so that the kernel can run it
+// with all lanes (tb0_scan_serial here, tb0_scan_wave there).
+struct Tb0Scan { int max_score, max_2nd, max_str, max_len; };
+LNR_HD inline Tb0Scan tb0_scan_serial(const Rec &r, u32 n) {
+    Tb0Scan s; s.max_score = -1; s.max_2nd = -1; s.max_str = -1; s.max_len = 0;
+    for (u32 j = 0; j < n; j++)
+        if (r.score[j] > s.max_score) { s.max_2nd = s.max_score; s.max_str = (int)j; s.max_score = r.score[j]; s.max_len = r.len[j]; }
+    return s;
+}
+// returns false when the search is over
+template <class Sink>
+LNR_HD inline bool tb0_step(Rec r, const Tb0Scan &sc, Sink &sink, i32 *chain, i32 *chain_sc, int min_len, int abort_score, float stop_ratio) {
+    const int delete_score = -1000;
+    bool f_done = sc.max_str == -1;
+    int max_2nd = sc.max_2nd, max_score = sc.max_score, max_str = sc.max_str, max_len = sc.max_len;
+    if (sink.nchains) { if ((float)max_len > (float)sink.first_len * stop_ratio) f_done = false; }
+    if (f_done || max_score == 0) return false;
+    if (max_len > min_len && max_score / (max_len - 1) > abort_score) {
+        u32 cn = 0;
+        for (int j = max_str; j != -1; j = r.p2[j]) {
+            if (r.score[j] != delete_score) { chain[cn] = j; chain_sc[cn] = r.score2[j]; cn++; r.score[j] = delete_score; }
+            else {
+                int infix = r.score2[j];
+                if (max_score - infix < max_2nd) {
+                    for (int k = max_str; k != j; k = r.p2[k]) r.score[k] = r.score2[k] - infix;
+                    cn = 0;
+                }
+                break;
+            }
+        }
+        if (cn) sink.emit(chain, chain_sc, cn);
+    }
+    if (max_str != -1) r.score[max_str] = delete_score;
+    return true;
+}
 template <class Sink>
 LNR_HD inline void traceback0(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, int min_len, int abort_score, int bestn, float stop_ratio) {
-    const int delete_score = -1000;
     int search_times = bestn < 50 ? bestn : 50;
     for (int it = 0; it < search_times; it++) {
-        bool f_done = true;
-        int max_2nd = -1, max_score = -1, max_str = -1, max_len = 0;
-        for (u32 j = 0; j < n; j++) {
-            if (r.score[j] > max_score) { max_2nd = max_score; max_str = (int)j; max_score = r.score[j]; max_len = r.len[j]; f_done = false; }
-        }
-        if (sink.nchains) { if ((float)max_len > (float)sink.first_len * stop_ratio) f_done = false; }
-        if (f_done || max_score == 0) break;
-        if (max_len > min_len && max_score / (max_len - 1) > abort_score) {
-            u32 cn = 0;
-            for (int j = max_str; j != -1; j = r.p2[j]) {
-                if (r.score[j] != delete_score) { chain[cn] = j; chain_sc[cn] = r.score2[j]; cn++; r.score[j] = delete_score; }
-                else {
-                    int infix = r.score2[j];
-                    if (max_score - infix < max_2nd) {
-                        for (int k = max_str; k != j; k = r.p2[k]) r.score[k] = r.score2[k] - infix;
-                        cn = 0;
-                    }
-                    break;
-                }
-            }
-            if (cn) sink.emit(chain, chain_sc, cn);
-        }
-        if (max_str != -1) r.score[max_str] = delete_score;
+        Tb0Scan sc = tb0_scan_serial(r, n);
+        if (!tb0_step(r, sc, sink, chain, chain_sc, min_len, abort_score, stop_ratio)) break;
     }
 }
 // traceBackChains1 cluster_util.cpp:213-304 (at most 50 trees reach this function)
@@ -811,6 +843,8 @@ struct JobCtx {
     GenomeFeat g;
     u16 *bins; u32 nbins;
     u64 *pair_evals;
+    unsigned long long *prof;   // diagnostic build only
+    int traceback_done;         // kernel: the anchor traceback already ran (wave-parallel) and filled S.hits / S.hscore
 };
 // Per-job scratch, carved once from the job's arena (cap = anchor slots of the job).
 struct JobScratch {
@@ -820,17 +854,21 @@ struct JobScratch {
     u32 *xs, *ys;
     u64 *cuts, *xy_strs, *alt;
 };
+// cap = number of anchors that reach the chaining DP (m).  Arrays are requested hottest first so that a
+// two-level arena keeps the DP / traceback state in its fast region.  S.alt (radix ping-pong buffer, sized
+// by the raw anchor count) is carved by the caller.
 LNR_HD inline bool job_carve(Arena &ar, u32 cap, JobScratch &S, int *ovf) {
     u32 c2 = cap + 2;
-    S.hits.init(ar.get<u64>(c2), c2, ovf);
-    S.hscore.init(ar.get<i32>(c2), c2, ovf);
-    S.sep.init(ar.get<UP>(c2), c2, ovf);
-    S.tmp.init(ar.get<UP>(c2), c2, ovf);
+    S.xs = ar.get<u32>(c2); S.ys = ar.get<u32>(c2);
     S.rec.score = ar.get<i32>(c2); S.rec.score2 = ar.get<i32>(c2); S.rec.len = ar.get<i32>(c2);
     S.rec.p2 = ar.get<i32>(c2); S.rec.root = ar.get<i32>(c2); S.rec.leaf = ar.get<i32>(c2);
-    S.chain = ar.get<i32>(c2); S.chain_sc = ar.get<i32>(c2); S.cnt = ar.get<i32>(c2); S.sep_score = ar.get<i32>(c2);
-    S.xs = ar.get<u32>(c2); S.ys = ar.get<u32>(c2);
-    S.cuts = ar.get<u64>(2 * (u64)c2); S.xy_strs = ar.get<u64>(c2); S.alt = ar.get<u64>(c2);
+    S.hits.init(ar.get<u64>(c2), c2, ovf);
+    S.hscore.init(ar.get<i32>(c2), c2, ovf);
+    S.cnt = ar.get<i32>(c2); S.chain = ar.get<i32>(c2); S.chain_sc = ar.get<i32>(c2);
+    S.sep.init(ar.get<UP>(c2), c2, ovf);
+    S.sep_score = ar.get<i32>(c2);
+    S.tmp.init(ar.get<UP>(c2), c2, ovf);
+    S.cuts = ar.get<u64>(2 * (u64)c2); S.xy_strs = ar.get<u64>(c2);
     return !ar.ovf;
 }
 struct JobDebug { u64 *filt; u32 *nfilt; u64 *xsort; u32 *nxsort; u64 *hits_chain; u32 *nhits_chain; u64 *hits_blocks; u32 *nhits_blocks; };
@@ -838,13 +876,16 @@ struct JobDebug { u64 *filt; u32 *nfilt; u64 *xsort; u32 *nxsort; u64 *hits_chai
 // Phase 1 (serial): a = ascending-sorted anchors with a[0]==0.  filterAnchors1 compaction, the
 // tie-sensitive x-descending sort of chainAnchorsHits (pmpfinder.cpp:2465), x/y extraction.
 // Returns m, the number of anchors that enter the chaining DP.
-LNR_HD inline u32 job_phase1(u64 *a, u32 n_sorted, JobScratch &S, JobDebug *dbg) {
+LNR_HD inline u32 job_phase1(u64 *a, u32 n_sorted, JobDebug *dbg) {
     u32 m = n_sorted > 1 ? filter_anchor_list(a, n_sorted) : n_sorted;   // filterAnchors1: length <= 1 -> unchanged
     if (dbg && dbg->filt) { for (u32 i = 0; i < m; i++) dbg->filt[i] = a[i]; *dbg->nfilt = m; }
     ref_sort(a, (long)m, [](const u64 &p, const u64 &q) { return anchor_x(p) > anchor_x(q); });
     if (dbg && dbg->xsort) { for (u32 i = 0; i < m; i++) dbg->xsort[i] = a[i]; *dbg->nxsort = m; }
-    for (u32 i = 0; i < m; i++) { S.xs[i] = (u32)anchor_x(a[i]); S.ys[i] = (u32)cord_y(a[i]); }
     return m;
+}
+// x / y of the sorted anchors for the DP (elementwise; the kernel does this with all lanes)
+LNR_HD inline void job_fill_xy(const u64 *a, u32 m, JobScratch &S, u32 first, u32 step) {
+    for (u32 i = first; i < m; i += step) { S.xs[i] = (u32)anchor_x(a[i]); S.ys[i] = (u32)cord_y(a[i]); }
 }
 // (between the phases: the chaining DP over S.xs/S.ys into S.rec -- best_chains_serial here,
 //  its wave-parallel twin in the kernel -- only when m >= 2, chainAnchorsBase cluster_util.cpp:450)
@@ -854,17 +895,27 @@ LNR_HD inline u32 job_phase1(u64 *a, u32 n_sorted, JobScratch &S, JobDebug *dbg)
 LNR_HD inline int job_phase3(u64 *a, u32 m, JobScratch &S, const JobCtx &c, Vec<u64> &cords, JobDebug *dbg) {
     int *ovf = S.hits.ovf;
     Vec<u64> &hits = S.hits;
-    hits.n = 0; S.hscore.n = 0; S.sep.n = 0; S.tmp.n = 0;
-    hits.push(F_END);        // initHits
-    S.hscore.push(0);        // initHitsScore
-    if (m >= 2) {
-        AnchorSink sink; sink.anchors = a; sink.hits = &hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
-        traceback(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, 1, 45, 50, 0.0f);
+    unsigned long long tl_ = 0;
+#if defined(LNR_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    tl_ = clock64();
+#endif
+    (void)tl_;
+    S.sep.n = 0; S.tmp.n = 0;
+    if (!c.traceback_done) {
+        hits.n = 0; S.hscore.n = 0;
+        hits.push(F_END);        // initHits
+        S.hscore.push(0);        // initHitsScore
+        if (m >= 2) {
+            AnchorSink sink; sink.anchors = a; sink.hits = &hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
+            traceback(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, 1, 45, 50, 0.0f);
+        }
     }
     if (dbg && dbg->hits_chain) { for (u32 i = 0; i < hits.n; i++) dbg->hits_chain[i] = hits[i]; *dbg->nhits_chain = hits.n; }
+    if (!c.traceback_done) LNR_TICK(c.prof, 5, tl_);
     // getAnchorHitsChains pmpfinder.cpp:2535-2545
     gather_blocks(hits.p, hits.n, nullptr, S.sep, 1, hits.n, c.L, 600, 0, 0);
     prefilter_chains2(hits.p, hits.n, S.sep, S.cuts, S.xy_strs, S.tmp);
+    LNR_TICK(c.prof, 6, tl_);
     for (u32 i = 0; i < S.sep.n; i++) S.sep_score[i] = S.hscore[(u32)S.sep[i].first] - S.hscore[(u32)S.sep[i].second - 1];
     // chainBlocksHits cluster_util.cpp:721-732 (scratch arrays of the anchor DP are dead and reused)
     BlockSink bs; bs.el = S.tmp.p; bs.off = S.chain; bs.nchains = 0; bs.nel = 0; bs.cap = S.tmp.cap; bs.ovf = ovf; bs.first_len = 0; bs.off[0] = 0;
@@ -875,11 +926,14 @@ LNR_HD inline int job_phase3(u64 *a, u32 m, JobScratch &S, const JobCtx &c, Vec<
     u64 *H; u32 nH;
     if (nh2 == 0xffffffffu) { H = hits.p; nH = hits.n; } else { H = hits2; nH = nh2; }
     if (dbg && dbg->hits_blocks) { for (u32 i = 0; i < nH; i++) dbg->hits_blocks[i] = H[i]; *dbg->nhits_blocks = nH; }
+    LNR_TICK(c.prof, 7, tl_);
     if (*ovf) return 1;
     // path_dst alg 2 (pmpfinder.cpp:1447-1469)
     if (nH >= 2) {
         nH = filter_hits(H, nH, c.f1, c.g);
+        LNR_TICK(c.prof, 8, tl_);
         path_dst_2(H, nH, c.f1, c.g, cords, c.read_str, c.read_end, c.L);
+        LNR_TICK(c.prof, 9, tl_);
     }
     return (*ovf || *cords.ovf) ? 1 : 0;
 }

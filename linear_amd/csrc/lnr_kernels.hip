@@ -345,12 +345,12 @@ __global__ void __launch_bounds__(64) k_seed_count(JobArrays J, ReadArrays R, co
 }
 // pass 2: one wave per job.  (sample, bucket entry) pairs are flattened over the lanes, filtered on Y
 // (pmpfinder.cpp:1890-1899) and written in the reference's order by ballot compaction.
-__global__ void __launch_bounds__(64) k_seed_gather(JobArrays J, ReadArrays R, const u64 *hs, u32 job_lo, u32 job_hi, const SampRec *samp,
+__global__ void __launch_bounds__(64) k_seed_gather(JobArrays J, ReadArrays R, const u64 *hs, const u32 *job_list, u32 job_lo, u32 job_hi, const SampRec *samp,
                                                     const u64 *anc_off, u64 *anchors, u32 *n_anchors) {
     __shared__ u32 s_incl[64], s_excl[64], s_xs[64], s_y[64];
     __shared__ i32 s_ds[64];
-    u32 j = job_lo + blockIdx.x;
-    if (j >= job_hi) return;
+    if (job_lo + blockIdx.x >= job_hi) return;
+    u32 j = job_list[job_lo + blockIdx.x];   // jobs are visited heaviest group first
     int lane = lane_id();
     u32 r = J.read[j];
     u64 L = R.len[r];
@@ -396,6 +396,7 @@ __global__ void __launch_bounds__(64) k_seed_gather(JobArrays J, ReadArrays R, c
 
 // =================================================================== job =====
 struct JobArgs {
+    const u32 *grp_order;   // groups in launch order (heaviest first: the long tail of repeat-rich reads starts early)
     const u32 *grp_beg;     // [ngroups+1] job ranges; all jobs of a group belong to one read and run in order
     JobArrays J;
     const u64 *anc_off; const u32 *job_cap; const u32 *n_anchors; const u64 *scr_off;
@@ -404,6 +405,8 @@ struct JobArgs {
     GenomeFeat g;
     u64 *cords; const u64 *cords_off; const u32 *cords_cap; u32 *ncords; i32 *read_err;
     u32 nbins; u32 grp_lo, grp_hi;
+    u32 lds_bytes;          // dynamic LDS per block: binning histogram first, then the fast half of the job arena
+    unsigned long long *prof;   // diagnostic build (-DLNR_PROF) only: per-phase cycle sums of lane 0
 };
 
 // wave-parallel twin of binning_filter_serial: LDS histogram of anchor x-field / 30000 (saturating u16
@@ -482,6 +485,84 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
     __syncthreads();
 }
 
+// Wave-parallel, bit-exact std::sort(anchors, by getAnchorX descending) -- the tie-sensitive sort of
+// chainAnchorsHits (pmpfinder.cpp:2465).  Algorithm = ref_sort.h's ref_sort_model: ranges above SORT_SMALL are
+// partitioned by the whole wave with the list formulation of std::__unguarded_partition (ballot compaction of the
+// "left scan stops here" / "right scan stops here" positions, pair count, parallel swaps); the remaining small
+// ranges are independent and are finished one per lane (introsort loop + insertion sort).
+#define SORT_SMALL 32
+struct XDesc { LNR_HD bool operator()(const u64 &p, const u64 &q) const { return anchor_x(p) > anchor_x(q); } };
+
+__device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *tasks, u32 *s_w /* 4 LDS words */) {
+    int lane = lane_id();
+    XDesc comp;
+    if (n <= SORT_SMALL) {
+        if (lane == 0) ref_sort(a, (long)n, comp);
+        __syncthreads();
+        return;
+    }
+    u32 stk_first[64], stk_last[64];
+    int stk_depth[64];
+    int sp = 0, lg = 0;
+    for (u32 t = n; t > 1; t >>= 1) lg++;
+    stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = lg * 2; sp = 1;
+    u32 ntasks = 0;
+    while (sp > 0) {
+        --sp;
+        u32 first = stk_first[sp], last = stk_last[sp];
+        int depth = stk_depth[sp];
+        while (true) {
+            if (last - first <= SORT_SMALL) {
+                if (lane == 0) tasks[ntasks] = (u64)first | ((u64)last << 28) | ((u64)depth << 56);   // 28 + 28 + 8 bits
+                ntasks++;
+                break;
+            }
+            if (depth == 0) { if (lane == 0) rs_heap_sort(a, (long)first, (long)last, comp); __syncthreads(); break; }
+            --depth;
+            if (lane == 0) {   // __move_median_to_first(first, first+1, mid, last-1)
+                u32 A = first + 1, B = first + (last - first) / 2, C = last - 1;
+                u64 va = a[A], vb = a[B], vc = a[C];
+                u32 pick;
+                if (comp(va, vb)) pick = comp(vb, vc) ? B : (comp(va, vc) ? C : A);
+                else pick = comp(va, vc) ? A : (comp(vb, vc) ? C : B);
+                u64 t = a[first]; a[first] = a[pick]; a[pick] = t;
+            }
+            __syncthreads();
+            u32 xp = (u32)anchor_x(a[first]);
+            u32 lo = first + 1, nL = 0, nR = 0;
+            for (u32 base = lo; base < last; base += 64) {
+                u32 i = base + lane;
+                bool in = i < last;
+                u32 x = in ? (u32)anchor_x(a[i]) : 0;
+                bool fL = in && !(x > xp);    // !comp(a[i], p): the left scan stops here
+                bool fR = in && !(xp > x);    // !comp(p, a[i]): the right scan stops here
+                u64 mL = __ballot(fL), mR = __ballot(fR);
+                if (fL) Lbuf[nL + __popcll(mL & lanemask_lt())] = i;
+                if (fR) Rbuf[nR + __popcll(mR & lanemask_lt())] = i;
+                nL += (u32)__popcll(mL); nR += (u32)__popcll(mR);
+            }
+            __syncthreads();
+            u32 lim = nL < nR ? nL : nR, cnt = 0;
+            for (u32 k = lane; k < lim; k += 64) cnt += Lbuf[k] < Rbuf[nR - 1 - k] ? 1u : 0u;
+            u32 K = wave_sum(cnt);
+            for (u32 k = lane; k < K; k += 64) { u32 i = Lbuf[k], j = Rbuf[nR - 1 - k]; u64 t = a[i]; a[i] = a[j]; a[j] = t; }
+            u32 cut = last;
+            if (K < nL) cut = Lbuf[K];
+            if (K >= 1) { u32 r = Rbuf[nR - K]; cut = r < cut ? r : cut; }
+            __syncthreads();
+            stk_first[sp] = cut; stk_last[sp] = last; stk_depth[sp] = depth; ++sp;
+            last = cut;
+        }
+    }
+    __syncthreads();
+    for (u32 t = lane; t < ntasks; t += 64) {
+        u64 v = tasks[t];
+        rs_finish_range(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)(v >> 56), comp);
+    }
+    __syncthreads();
+    (void)s_w;
+}
+
 // wave-parallel twin of best_chains_serial (getBestChains, cluster_util.cpp:53-111): serial over i, lanes over
 // the predecessor window, max-reduce with "smallest j wins among equal totals".
 __device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type) {
@@ -518,15 +599,61 @@ __device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int
     }
 }
 
+// wave-parallel twin of tb0_scan_serial: first index of the maximal score (> -1), the running maximum seen before
+// it (floor -1) and the chain length there.
+__device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {
+    int lane = lane_id();
+    i64 best = -1;
+    for (u32 j = lane; j < n; j += 64) {
+        int sc = r.score[j];
+        if (sc > -1) { i64 key = ((i64)sc << 32) | (i64)(u32)(0x7fffffff - (int)j); best = key > best ? key : best; }
+    }
+    best = wave_max_i64(best);
+    Tb0Scan s; s.max_score = -1; s.max_2nd = -1; s.max_str = -1; s.max_len = 0;
+    if (best < 0) return s;
+    s.max_score = (int)(best >> 32);
+    s.max_str = 0x7fffffff - (int)(u32)(best & 0xffffffff);
+    i64 m2 = -1;
+    for (u32 j = lane; j < (u32)s.max_str; j += 64) { i64 v = r.score[j]; m2 = v > m2 ? v : m2; }
+    s.max_2nd = (int)wave_max_i64(m2);
+    s.max_len = r.len[s.max_str];
+    return s;
+}
+// traceBackChains (cluster_util.cpp:306-335) for the anchor DP, lanes cooperating on the scans; lane 0 walks chains
+// and emits hits.  s_flag = one LDS word.
+__device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int *s_flag) {
+    int lane = lane_id();
+    for (u32 i = lane; i < n; i += 64) cnt[i] = 0;
+    __syncthreads();
+    for (u32 i = lane; i < n; i += 64) cnt[r.root[i]] = 1;
+    __syncthreads();
+    u32 c = 0;
+    for (u32 i = lane; i < n; i += 64) c += (u32)cnt[i];
+    u32 root_num = wave_sum(c);
+    if (root_num > 50) {
+        for (int it = 0; it < 50; it++) {
+            Tb0Scan sc = tb0_scan_wave(r, n);
+            if (lane == 0) *s_flag = tb0_step(r, sc, sink, chain, chain_sc, 1, 45, 0.0f) ? 1 : 0;
+            __syncthreads();
+            int cont = *s_flag;
+            __syncthreads();
+            if (!cont) break;
+        }
+    } else {
+        if (lane == 0) traceback1(r, n, sink, chain, chain_sc, 1, 45, 50, 0.0f);
+        __syncthreads();
+    }
+}
+
 // One wave per read: runs the read's jobs in order (round 0: the whole read; remap round: its gaps),
 // appending cords to the read's cord list exactly like consecutive apxMap_ calls do.
 __global__ void __launch_bounds__(64) k_job(JobArgs A) {
     extern __shared__ u32 dyn_lds[];   // binning halves
     __shared__ u32 hist[256];
     __shared__ u32 s_m;
-    __shared__ int s_ovf;
-    u32 grp = A.grp_lo + blockIdx.x;
-    if (grp >= A.grp_hi) return;
+    __shared__ int s_ovf, s_flag;
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    u32 grp = A.grp_order[A.grp_lo + blockIdx.x];
     int lane = lane_id();
     u32 jb = A.grp_beg[grp], je = A.grp_beg[grp + 1];
     if (jb >= je) return;
@@ -537,35 +664,73 @@ __global__ void __launch_bounds__(64) k_job(JobArgs A) {
     Vec<u64> cords;
     cords.init(A.cords + A.cords_off[r], A.cords_cap[r], &s_ovf);
     cords.n = A.ncords[r];
+    unsigned long long tk_ = 0;
+#ifdef LNR_PROF
+    tk_ = clock64();
+#endif
+    (void)tk_;
+    unsigned long long *prof = lane == 0 ? A.prof : nullptr;
+    (void)prof;
     for (u32 j = jb; j < je; j++) {
-        u64 *a = A.anchors + A.anc_off[j];
+        u64 *ag = A.anchors + A.anc_off[j];
         u32 n = A.n_anchors[j];
         u32 cap = A.job_cap[j] + 2;
-        Arena ar; ar.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
-        JobScratch S;
-        bool ok = job_carve(ar, cap, S, &s_ovf);
-        if (!ok) { if (lane == 0) s_ovf = 1; __syncthreads(); break; }
-        n = binning_wave(a, n, dyn_lds, A.nbins);
+        LNR_TICK(prof, 0, tk_);
+        n = binning_wave(ag, n, dyn_lds, A.nbins);   // uses the dynamic LDS as its histogram
+        LNR_TICK(prof, 1, tk_);
+        // two-level arena: dynamic LDS first (re-used once binning is done), the job's global scratch behind it
+        Arena slow; slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
+        Arena ar; ar.init((void *)dyn_lds, A.lds_bytes); ar.next = &slow;
+        u64 *a = ag;
+        u64 *s_alt = nullptr;
         if (n > 1) {
-            if (lane == 0) a[0] = 0;   // filterAnchorsList pmpfinder.cpp:2031
+            if (lane == 0) ag[0] = 0;   // filterAnchorsList pmpfinder.cpp:2031
             __syncthreads();
-            radix_sort_wave(a, S.alt, n, hist);
+            u64 *alt = slow.get<u64>(cap);
+            s_alt = alt;
+            radix_sort_wave(ag, alt, n, hist);
+            a = ar.get<u64>((u64)n + 2);          // sorted anchors move next to the lanes (LDS when they fit)
+            for (u32 i = lane; i < n; i += 64) a[i] = ag[i];
+            __syncthreads();
         }
-        if (lane == 0) s_m = job_phase1(a, n, S, nullptr);
+        LNR_TICK(prof, 2, tk_);
+        if (lane == 0) s_m = n > 1 ? filter_anchor_list(a, n) : n;   // filterAnchors1 (pmpfinder.cpp:2073-2091)
         __syncthreads();
         u32 m = s_m;
+        if (m > 1) {
+            // scratch of the sort: position lists in the (dead) radix buffer, task list behind it
+            u32 *Lbuf = (u32 *)s_alt, *Rbuf = Lbuf + (m + 2);
+            u64 *tasks = slow.get<u64>((u64)m + 2);
+            introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, nullptr);
+        }
+        JobScratch S;
+        bool ok = job_carve(ar, m, S, &s_ovf);
+        if (!ok || slow.ovf) { if (lane == 0) s_ovf = 1; __syncthreads(); break; }
+        job_fill_xy(a, m, S, (u32)lane, 64);
+        __syncthreads();
+        LNR_TICK(prof, 3, tk_);
         int mode = (int)A.J.mode[j];
         if (m >= 2) best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type);
+        LNR_TICK(prof, 4, tk_);
+        // traceback of the anchor chains -> hits (lane 0 owns S.hits / S.hscore from here on)
+        AnchorSink sink; sink.anchors = a; sink.hits = &S.hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
+        if (lane == 0) { S.hits.n = 0; S.hscore.n = 0; S.hits.push(F_END); S.hscore.push(0); }
+        if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, &s_flag);
+        LNR_TICK(prof, 5, tk_);
         if (lane == 0) {
             JobCtx c;
+            c.traceback_done = 1;
             c.L = L; c.read_str = A.J.str[j]; c.read_end = A.J.end[j]; c.mode = mode;
             u32 nf = A.nf[r];
             c.f1[0].p = A.f1 + A.f1_off[r]; c.f1[0].n = nf;
             c.f1[1].p = A.f1 + A.f1_off[r] + nf; c.f1[1].n = nf;
-            c.g = A.g; c.bins = nullptr; c.nbins = 0; c.pair_evals = nullptr;
+            c.g = A.g; c.bins = nullptr; c.nbins = 0; c.pair_evals = nullptr; c.prof = prof;
             if (job_phase3(a, m, S, c, cords, nullptr)) s_ovf = 1;
         }
         __syncthreads();
+#ifdef LNR_PROF
+        tk_ = clock64();
+#endif
         if (s_ovf) break;
     }
     if (lane == 0) { A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }

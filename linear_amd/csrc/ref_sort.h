@@ -155,3 +155,105 @@ LNR_HD inline void ref_sort(T *a, long n, Comp comp) {
 }
 
 }  // namespace lnr
+
+// ---------------------------------------------------------------------------------------------------
+// List formulation of std::__unguarded_partition, the form the GPU kernel executes with all lanes
+// (lnr_kernels.hip: introsort_wave).  For the range [lo, hi) and pivot p (sitting at lo-1):
+//   L = positions, ascending,  of elements x with !comp(x, p)      (where the left scan stops)
+//   R = positions, descending, of elements x with !comp(p, x)      (where the right scan stops)
+// The serial algorithm swaps the pairs (L_k, R_k) for k = 0..K-1, K = number of leading pairs with
+// L_k < R_k (L grows, R shrinks, so the predicate is monotone), and returns
+//   cut = min(L_K if it exists, R_{K-1} if K >= 1)
+// because positions inside (L_{k-1}, R_{k-1}) are untouched when step k scans them, and R_{K-1} holds an
+// element >= p after its swap.  An element equal to the pivot is in both lists but can never be the left
+// member of one swapped pair and the right member of another.  ref_sort_model() is ref_sort() with this
+// partition and with the kernel's task split (large ranges partitioned by lists, ranges <= small_limit
+// finished independently: introsort loop + insertion sort of the range); tests fuzz it against std::sort.
+namespace lnr {
+
+template <class T, class Comp>
+LNR_HD inline long rs_partition_lists(T *a, long lo, long hi, const T &p, Comp comp, long *Lbuf, long *Rbuf) {
+    long nL = 0, nR = 0;
+    for (long i = lo; i < hi; i++) { if (!comp(a[i], p)) Lbuf[nL++] = i; if (!comp(p, a[i])) Rbuf[nR++] = i; }
+    // R_k = Rbuf[nR-1-k]
+    long K = 0;
+    long lim = nL < nR ? nL : nR;
+    while (K < lim && Lbuf[K] < Rbuf[nR - 1 - K]) K++;
+    for (long k = 0; k < K; k++) rs_swap(a[Lbuf[k]], a[Rbuf[nR - 1 - k]]);
+    long cut = hi;   // cannot stay hi: the median-of-3 guarantees a stop inside the range
+    if (K < nL) cut = Lbuf[K];
+    if (K >= 1 && Rbuf[nR - K] < cut) cut = Rbuf[nR - K];
+    return cut;
+}
+// serial introsort loop on [first,last) followed by the insertion sort of that range
+template <class T, class Comp>
+LNR_HD inline void rs_finish_range(T *a, long first0, long last0, int depth0, Comp comp) {
+    long stk_first[96], stk_last[96];
+    int stk_depth[96];
+    int sp = 0;
+    stk_first[0] = first0; stk_last[0] = last0; stk_depth[0] = depth0; sp = 1;
+    while (sp > 0) {
+        --sp;
+        long first = stk_first[sp], last = stk_last[sp];
+        int depth_limit = stk_depth[sp];
+        while (last - first > 16) {
+            if (depth_limit == 0) { rs_heap_sort(a, first, last, comp); break; }
+            --depth_limit;
+            long mid = first + (last - first) / 2;
+            long A = first + 1, B = mid, C = last - 1;
+            if (comp(a[A], a[B])) {
+                if (comp(a[B], a[C])) rs_swap(a[first], a[B]);
+                else if (comp(a[A], a[C])) rs_swap(a[first], a[C]);
+                else rs_swap(a[first], a[A]);
+            } else if (comp(a[A], a[C])) rs_swap(a[first], a[A]);
+            else if (comp(a[B], a[C])) rs_swap(a[first], a[C]);
+            else rs_swap(a[first], a[B]);
+            long lo = first + 1, hi = last;
+            while (true) {
+                while (comp(a[lo], a[first])) ++lo;
+                --hi;
+                while (comp(a[first], a[hi])) --hi;
+                if (!(lo < hi)) break;
+                rs_swap(a[lo], a[hi]);
+                ++lo;
+            }
+            stk_first[sp] = lo; stk_last[sp] = last; stk_depth[sp] = depth_limit; ++sp;
+            last = lo;
+        }
+    }
+    rs_insertion_sort(a, first0, last0, comp);
+}
+template <class T, class Comp>
+LNR_HD inline void ref_sort_model(T *a, long n, Comp comp, long small_limit, long *Lbuf, long *Rbuf) {
+    if (n <= 0) return;
+    long stk_first[96], stk_last[96];
+    int stk_depth[96];
+    int sp = 0, lg = 0;
+    for (long t = n; t > 1; t >>= 1) lg++;
+    stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = lg * 2; sp = 1;
+    while (sp > 0) {
+        --sp;
+        long first = stk_first[sp], last = stk_last[sp];
+        int depth_limit = stk_depth[sp];
+        while (true) {
+            if (last - first <= small_limit) { rs_finish_range(a, first, last, depth_limit, comp); break; }
+            if (depth_limit == 0) { rs_heap_sort(a, first, last, comp); break; }
+            --depth_limit;
+            long mid = first + (last - first) / 2;
+            long A = first + 1, B = mid, C = last - 1;
+            if (comp(a[A], a[B])) {
+                if (comp(a[B], a[C])) rs_swap(a[first], a[B]);
+                else if (comp(a[A], a[C])) rs_swap(a[first], a[C]);
+                else rs_swap(a[first], a[A]);
+            } else if (comp(a[A], a[C])) rs_swap(a[first], a[A]);
+            else if (comp(a[B], a[C])) rs_swap(a[first], a[C]);
+            else rs_swap(a[first], a[B]);
+            T p = a[first];
+            long cut = rs_partition_lists(a, first + 1, last, p, comp, Lbuf, Rbuf);
+            stk_first[sp] = cut; stk_last[sp] = last; stk_depth[sp] = depth_limit; ++sp;
+            last = cut;
+        }
+    }
+}
+
+}  // namespace lnr

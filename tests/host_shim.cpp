@@ -117,15 +117,16 @@ int run_job(Shim &c, const u8 *read, u64 L, u64 read_str, u64 read_end, int mode
     jc.L = L; jc.read_str = read_str; jc.read_end = read_end; jc.mode = mode;
     jc.f1[0] = f1[0]; jc.f1[1] = f1[1];
     jc.g.base = c.f2.data(); jc.g.off = c.f2_off.data(); jc.g.nseq = (u32)c.seqs.size();
-    jc.bins = bins.data(); jc.nbins = nbins; jc.pair_evals = &c.stats[4];
+    jc.bins = bins.data(); jc.nbins = nbins; jc.pair_evals = &c.stats[4]; jc.prof = nullptr; jc.traceback_done = 0;
     JobDebug jd; memset(&jd, 0, sizeof(jd));
     std::vector<u64> d1(cap), d2(cap), d3(cap + 2);
     u32 n1 = 0, n2 = 0, n3 = 0;
     if (dbg) { jd.filt = d1.data(); jd.nfilt = &n1; jd.xsort = d2.data(); jd.nxsort = &n2; jd.hits_chain = d3.data(); jd.nhits_chain = &n3; }
     int ovf = 0;
     JobScratch S;
-    if (!job_carve(ar, cap, S, &ovf)) return 1;
-    u32 m = job_phase1(a.data(), n, S, dbg ? &jd : nullptr);
+    u32 m = job_phase1(a.data(), n, dbg ? &jd : nullptr);
+    if (!job_carve(ar, m, S, &ovf)) return 1;
+    job_fill_xy(a.data(), m, S, 0, 1);
     if (m >= 2) best_chains_serial(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, jc.pair_evals);
     int rc = job_phase3(a.data(), m, S, jc, cords, dbg ? &jd : nullptr);
     if (dbg) { c.dbg[1].assign(d1.begin(), d1.begin() + n1); c.dbg[2].assign(d2.begin(), d2.begin() + n2); c.dbg[3].assign(d3.begin(), d3.begin() + n3); }
