@@ -681,7 +681,7 @@ lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64
         IXENS(Xs, nsamp * 4);
         IXENS(vals, nsamp * 8);
         u32 nch = (u32)chunks.size();
-        hipLaunchKernelGGL(k_ix_chunk_const, dim3((nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->g.as<u8>(), d_chunks.as<ChunkDesc>(), nch);
+        hipLaunchKernelGGL(k_ix_chunk_const, dim3(nch), dim3(256), 0, ctx->stream, ctx->g.as<u8>(), (u64)(ctx->info.genome_bytes + 64), d_chunks.as<ChunkDesc>(), nch);
         IXHIP(hipGetLastError());
         hipLaunchKernelGGL(k_ix_sample, dim3((u32)((nsamp + 255) / 256)), dim3(256), 0, ctx->stream, ctx->g.as<u8>(), d_chunks.as<ChunkDesc>(), nch, nsamp, Xs.as<u32>(), vals.as<u64>());
         IXHIP(hipGetLastError());

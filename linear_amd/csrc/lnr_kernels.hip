@@ -93,15 +93,38 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan_add(i32 *out, u64 n, const i3
 struct ChunkDesc { u64 seq_off; i64 t_str; u64 samp_base; u32 nsamp; u32 seq_id; i32 ks; i32 C; };
 static const u32 X_MASK = (1u << 26) - 1, X_REC = 1u << 30, X_FIRST = 1u << 31;
 
-// hashInit's N-skip and the strand-selector constant of every chunk (one thread per chunk; the
-// N scan is serial but runs once per chunk and stops at the first N-free 21-mer)
-__global__ void k_ix_chunk_const(const u8 *g, ChunkDesc *ch, u32 nch) {
-    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+// hashInit's N-skip (shape_extend.cpp:95-105: the first position p >= t_str whose 21-mer holds no N) and the
+// strand-selector constant of every chunk.  One 256-thread block per chunk: each thread brute-forces the 64
+// start positions of its segment (20 bytes of look-ahead), block-min, next 16 KB tile until found -- GRCh38
+// chromosomes open with megabases of N, which a single thread would walk for a second.
+__global__ void __launch_bounds__(256) k_ix_chunk_const(const u8 *g, u64 gbytes, ChunkDesc *ch, u32 nch) {
+    __shared__ unsigned long long s_best;
+    u32 c = blockIdx.x;
     if (c >= nch) return;
-    const u8 *s = g + ch[c].seq_off;
-    int ks = shape_init_skip(s + ch[c].t_str);
-    ch[c].ks = ks;
-    ch[c].C = shape_const(s, (u64)ch[c].t_str, ks, (u64)ch[c].t_str);
+    u64 s0 = ch[c].seq_off + (u64)ch[c].t_str;   // bytes past the buffer read as 0 (the zero padding continued)
+    u64 found = ~0ULL;
+    for (u64 tile = 0;; tile += 256 * 64) {
+        if (threadIdx.x == 0) s_best = ~0ULL;
+        __syncthreads();
+        u64 seg = tile + (u64)threadIdx.x * 64;
+        int run = 0;
+        u64 mine = ~0ULL;
+        for (int q = 0; q < 64 + 20; q++) {
+            u64 idx = s0 + seg + (u64)q;
+            if ((idx < gbytes ? g[idx] : (u8)0) == 4) run = 0; else run++;
+            if (run >= 21 && q - 20 >= 0 && q - 20 < 64) { mine = seg + (u64)(q - 20); break; }
+        }
+        if (mine != ~0ULL) atomicMin(&s_best, (unsigned long long)mine);
+        __syncthreads();
+        found = s_best;
+        __syncthreads();
+        if (found != ~0ULL) break;
+    }
+    if (threadIdx.x == 0) {
+        int ks = (int)found;
+        ch[c].ks = ks;
+        ch[c].C = shape_const(g + ch[c].seq_off, (u64)ch[c].t_str, ks, (u64)ch[c].t_str);
+    }
 }
 // one thread per genome sample: minimizer X, Y, strand in closed form
 __global__ void __launch_bounds__(256) k_ix_sample(const u8 *g, const ChunkDesc *ch, u32 nch, u64 nsamp, u32 *Xs, u64 *vals) {
