@@ -60,7 +60,10 @@ struct lnr_ctx {
     lnr_index_info info{};
     std::vector<u64> seq_len, seq_off, f2_off;
     u32 nbins = 0;
-    size_t job_lds_bytes = 24 * 1024;   // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
+    size_t job_lds_bytes = 8 * 1024;    // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
+    u32 heavy_cap = 4096;               // jobs with at least this many bucket entries take the heavy path (LNR_HEAVY_CAP overrides)
+    hipStream_t stream2 = nullptr;      // heavy path runs here, concurrently with the fused k_job
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off;
     // ---- batch inputs / per-read arrays
     DevBuf in_reads, in_off;                       // staging for the host-buffer entry points
@@ -69,7 +72,7 @@ struct lnr_ctx {
     DevBuf tail_scr, tail_off, tail_cap, gaps, gaps_off, gaps_cap, ngaps, remap;
     // ---- jobs
     DevBuf j_read, j_str, j_end, j_mode, j_samp_off, j_cap, j_look, j_anc_off, j_scr_off, j_nanc, grp_beg, grp_order, job_list;
-    DevBuf samp, anchors, job_scr, prof;
+    DevBuf samp, anchors, job_scr, prof, j_nbin, j_m, heavy_jobs;
     // ---- results
     DevBuf r_off, r_str, r_end;
     std::vector<u64> h_cord_off, h_cords_str, h_cords_end, h_anchor_off, h_anchors;
@@ -285,10 +288,47 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
 #endif
             size_t lds = std::max<size_t>((size_t)((ctx->nbins + 1) / 2) * 4, ctx->job_lds_bytes);
             lds = (lds + 15) & ~(size_t)15;
+            size_t lds_min = (((size_t)((ctx->nbins + 1) / 2) * 4) + 15) & ~(size_t)15;
             A.lds_bytes = (u32)lds;
+            A.arena_lds = (u32)lds;
+            A.phase = 0;
+            ENSURE(ctx->j_nbin, (size_t)nj * 4);
+            ENSURE(ctx->j_m, (size_t)nj * 4);
+            A.job_nbin = ctx->j_nbin.as<u32>(); A.job_m = ctx->j_m.as<u32>();
+            // heavy groups = prefix of the (weight-descending) slice
+            u32 gh = g0;
+            std::vector<u32> hjobs;
+            while (gh < g1) {
+                u64 wsum = 0;
+                for (u32 q = ord_job_beg[gh]; q < ord_job_beg[gh + 1]; q++) wsum += cap[job_list[q]];
+                if (wsum < ctx->heavy_cap) break;
+                for (u32 q = ord_job_beg[gh]; q < ord_job_beg[gh + 1]; q++) hjobs.push_back(job_list[q]);
+                gh++;
+            }
             ctx->t_job.start(ctx->stream);
-            hipLaunchKernelGGL(k_job, dim3(g1 - g0), dim3(64), lds, ctx->stream, A);
-            KCHECK();
+            if (gh > g0) {
+                // heavy path on stream2: pre (1 wave/read) -> DP with 16 waves per job -> post (1 wave/read)
+                if ((s = upload(ctx, ctx->heavy_jobs, hjobs)) != LNR_OK) return s;
+                HIPCK(hipEventRecord(ctx->ev_fork, ctx->stream));
+                HIPCK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                JobArgs H = A;
+                H.grp_lo = g0; H.grp_hi = gh; H.lds_bytes = (u32)std::max<size_t>(lds_min, 16); H.arena_lds = 0;
+                H.phase = 1;
+                hipLaunchKernelGGL(k_job, dim3(gh - g0), dim3(64), H.lds_bytes, ctx->stream2, H);
+                KCHECK();
+                hipLaunchKernelGGL(k_dp_big, dim3((u32)hjobs.size()), dim3(1024), 0, ctx->stream2, H, ctx->heavy_jobs.as<u32>(), (u32)hjobs.size());
+                KCHECK();
+                H.phase = 2;
+                hipLaunchKernelGGL(k_job, dim3(gh - g0), dim3(64), H.lds_bytes, ctx->stream2, H);
+                KCHECK();
+                HIPCK(hipEventRecord(ctx->ev_join, ctx->stream2));
+            }
+            if (g1 > gh) {
+                A.grp_lo = gh; A.grp_hi = g1;
+                hipLaunchKernelGGL(k_job, dim3(g1 - gh), dim3(64), lds, ctx->stream, A);
+                KCHECK();
+            }
+            if (gh > g0) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             ctx->t_job.stop(ctx->stream);
         }
         std::vector<u32> nanc_all(nj);
@@ -607,6 +647,9 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     ctx->device = dev;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }
+    if (const char *e = getenv("LNR_HEAVY_CAP")) { long v = atol(e); if (v >= 64) ctx->heavy_cap = (u32)v; }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     ctx->t_prep.init(); ctx->t_sc.init(); ctx->t_sg.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();
     *out = ctx;
     return LNR_OK;
@@ -624,6 +667,9 @@ void lnr_destroy(lnr_ctx *ctx) {
                       &ctx->r_str, &ctx->r_end};
     for (DevBuf *b : bufs) b->release();
     ctx->t_prep.destroy(); ctx->t_sc.destroy(); ctx->t_sg.destroy(); ctx->t_job.destroy(); ctx->t_tail.destroy(); ctx->t_total.destroy();
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -60,12 +60,30 @@ LNR_HD inline UP forward_y(UP se, u64 L) {
     return r;
 }
 
+LNR_HD inline bool lnr_is_leader() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (threadIdx.x & 63) == 0;
+#else
+    return true;
+#endif
+}
+// make the leader's stores visible to the other lanes of the wave (workgroup = one wave in k_job)
+LNR_HD inline void lnr_wave_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#endif
+}
 // bounded vector view over caller-provided storage; overflow is recorded, never written past cap
 template <class T>
 struct Vec {
     T *p; u32 n, cap; int *ovf;
     LNR_HD void init(T *p_, u32 cap_, int *ovf_) { p = p_; n = 0; cap = cap_; ovf = ovf_; }
     LNR_HD void push(const T &v) { if (n < cap) p[n++] = v; else *ovf = 1; }
+    // SIMT-uniform form for code that all lanes of a wave execute together: every lane tracks n, lane 0 stores
+    LNR_HD void push_u(const T &v) {
+        if (n < cap) { if (lnr_is_leader()) p[n] = v; n++; }
+        else if (lnr_is_leader()) *ovf = 1;
+    }
     LNR_HD T &operator[](u32 i) { return p[i]; }
     LNR_HD T &back() { return p[n - 1]; }
 };
@@ -283,12 +301,19 @@ LNR_HD inline u32 filter_anchor_list(u64 *a, u32 n) {
 }
 
 // ------------------------------------------------------------ chain scoring ----
+// derr = floor(100*da / max(|dy|,|dx|,50)) (cluster_util.cpp:350,401).  With |dx| < 2^20 every operand fits
+// 32 bits (y < 2^20), so the common case avoids the 64-bit division; same quotient either way.
+LNR_HD inline i64 chain_derr(i64 dx, i64 dy, i64 da) {
+    i64 M = max64(max64(labs64(dy), labs64(dx)), 50);
+    if (M < (1 << 20) && da < (1 << 21)) return (i64)((u32)(100u * (u32)da) / (u32)M);
+    return (100 * da) / M;
+}
 LNR_HD inline int chain_score0(u32 x1, u32 y1, u32 x2, u32 y2) {   // getApxChainScore0 cluster_util.cpp:337-385 (effective values)
     i64 dy = (i64)y1 - (i64)y2;
     if (dy < 5) return -10000;
     i64 dx = (i64)x1 - (i64)x2;
     i64 da = labs64(dx - dy);
-    i64 derr = (100 * da) / max64(max64(labs64(dy), labs64(dx)), 50);
+    i64 derr = chain_derr(dx, dy, da);
     if (derr >= 100) return -1000;
     if (da < 30) return (int)(100 - dy);
     return (int)(100 - dy - da);
@@ -298,7 +323,7 @@ LNR_HD inline int chain_score(u32 x1, u32 y1, u32 x2, u32 y2) {   // getApxChain
     if (dy < 10) return -10000;
     i64 dx = (i64)x1 - (i64)x2;
     i64 da = labs64(dx - dy);
-    i64 derr = (100 * da) / max64(max64(labs64(dy), labs64(dx)), 50);
+    i64 derr = chain_derr(dx, dy, da);
     int score_derr;
     if (derr < 5) score_derr = (int)(4 * derr);
     else if (derr < 10) score_derr = (int)(6 * derr - 10);
@@ -314,6 +339,15 @@ LNR_HD inline int chain_score(u32 x1, u32 y1, u32 x2, u32 y2) {   // getApxChain
 }
 
 struct Rec { i32 *score, *score2, *len, *p2, *root, *leaf; };   // ChainsRecord as SoA
+
+// Small arrays that only the leader lane touches (introsort stack, tree table of traceBackChains1).  In the
+// kernel one instance lives in LDS per wave; keeping them out of per-lane private memory is worth a factor in
+// occupancy.
+struct LeaderScratch {
+    SortStack st;
+    i32 l_root[64], l_score[64], l_len[64], l_leaf[64];
+    u64 ranks[64];
+};
 
 // getBestChains cluster_util.cpp:53-111, serial form.  xs/ys = getAnchorX / y of the x-descending anchors.
 LNR_HD inline void best_chains_serial(const u32 *xs, const u32 *ys, u32 n, Rec r, int score_type, u64 *pair_evals) {
@@ -406,8 +440,8 @@ LNR_HD inline void traceback0(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_s
 }
 // traceBackChains1 cluster_util.cpp:213-304 (at most 50 trees reach this function)
 template <class Sink>
-LNR_HD inline void traceback1(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, int min_len, int abort_score, int bestn, float stop_ratio) {
-    i32 l_root[64], l_score[64], l_len[64], l_leaf[64];
+LNR_HD inline void traceback1(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, int min_len, int abort_score, int bestn, float stop_ratio, LeaderScratch &ls) {
+    i32 *l_root = ls.l_root, *l_score = ls.l_score, *l_len = ls.l_len, *l_leaf = ls.l_leaf;
     int nl = 0;
     for (u32 j = 0; j < n; j++) {
         if (r.leaf[j]) {
@@ -421,9 +455,9 @@ LNR_HD inline void traceback1(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_s
             if (f_new && nl < 64) { l_root[nl] = r.root[j]; l_score[nl] = r.score[j]; l_len[nl] = r.len[j]; l_leaf[nl] = (i32)j; nl++; }
         }
     }
-    u64 ranks[64];   // (tree index, score) pairs; std::sort by score desc with ties (cluster_util.cpp:269)
+    u64 *ranks = ls.ranks;   // (tree index, score) pairs; std::sort by score desc with ties (cluster_util.cpp:269)
     for (int i = 0; i < nl; i++) ranks[i] = ((u64)(u32)l_score[i] << 32) | (u32)i;
-    ref_sort(ranks, (long)nl, [](const u64 &a, const u64 &b) { return (i32)(a >> 32) > (i32)(b >> 32); });
+    ref_sort(ranks, (long)nl, [](const u64 &a, const u64 &b) { return (i32)(a >> 32) > (i32)(b >> 32); }, ls.st);
     int lim = bestn < nl ? bestn : nl;
     for (int i = 0; i < lim; i++) {
         int t = (int)(u32)ranks[i];
@@ -441,12 +475,12 @@ LNR_HD inline void traceback1(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_s
 }
 // traceBackChains cluster_util.cpp:306-335; cnt = n zeroed ints of scratch
 template <class Sink>
-LNR_HD inline void traceback(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int min_len, int abort_score, int bestn, float stop_ratio) {
+LNR_HD inline void traceback(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int min_len, int abort_score, int bestn, float stop_ratio, LeaderScratch &ls) {
     u32 root_num = 0;
     for (u32 i = 0; i < n; i++) cnt[i] = 0;
     for (u32 i = 0; i < n; i++) { if (cnt[r.root[i]] == 0) root_num++; cnt[r.root[i]] = 1; }
     if (root_num > 50) traceback0(r, n, sink, chain, chain_sc, min_len, abort_score, bestn, stop_ratio);
-    else traceback1(r, n, sink, chain, chain_sc, min_len, abort_score, bestn, stop_ratio);
+    else traceback1(r, n, sink, chain, chain_sc, min_len, abort_score, bestn, stop_ratio, ls);
 }
 
 // ------------------------------------------------------------------ blocks ----
@@ -476,12 +510,12 @@ LNR_HD inline void gather_blocks(u64 *cords, u32 ncords, Vec<UP> *str_ends, Vec<
 }
 
 // preFilterChains2 pmpfinder.cpp:2366-2446 with getCordXY = get_cord_y.  sep is replaced.
-LNR_HD inline void prefilter_chains2(u64 *hits, u32 nhits, Vec<UP> &sep, u64 *cuts, u64 *xy_strs, Vec<UP> &tmp) {
+LNR_HD inline void prefilter_chains2(u64 *hits, u32 nhits, Vec<UP> &sep, u64 *cuts, u64 *xy_strs, Vec<UP> &tmp, LeaderScratch &ls) {
     const u64 mask = 1ULL << 62;
     u32 nb = sep.n;
     for (u32 i = 0; i < nb; i++) { cuts[2 * i] = sep[i].first; cuts[2 * i + 1] = (sep[i].second - 1) | mask; xy_strs[i] = sep[i].first; }
     const u64 *h = hits;
-    ref_sort(cuts, (long)(2 * nb), [h, mask](const u64 &a, const u64 &b) { return cord_y(h[a & ~mask]) < cord_y(h[b & ~mask]); });
+    ref_sort(cuts, (long)(2 * nb), [h, mask](const u64 &a, const u64 &b) { return cord_y(h[a & ~mask]) < cord_y(h[b & ~mask]); }, ls.st);
     tmp.n = 0;
     for (u32 i = 0; i < 2 * nb; i++) {
         u64 cuty = cord_y(hits[cuts[i] & ~mask]);
@@ -509,7 +543,7 @@ LNR_HD inline void prefilter_chains2(u64 *hits, u32 nhits, Vec<UP> &sep, u64 *cu
     }
     sep.n = 0;
     for (u32 i = 0; i < tmp.n; i++) sep.push(tmp[i]);
-    ref_sort(sep.p, (long)sep.n, [](const UP &a, const UP &b) { return a.second < b.second; });
+    ref_sort(sep.p, (long)sep.n, [](const UP &a, const UP &b) { return a.second < b.second; }, ls.st);
     for (u32 i = 0; i < sep.n; i++) hits[sep[i].second - 1] |= F_END;
 }
 
@@ -569,17 +603,17 @@ LNR_HD inline void best_chains2(const u64 *hits, const UP *sep, const i32 *sep_s
         }
     }
 }
-struct BlockScratch { u32 *ptr; UP *sep_tmp; i32 *score_tmp; Rec rec; i32 *chain, *chain_sc, *cnt; };
+struct BlockScratch { u32 *ptr; UP *sep_tmp; i32 *score_tmp; Rec rec; i32 *chain, *chain_sc, *cnt; LeaderScratch *ls; };
 // chainBlocksBase cluster_util.cpp:533-577
 LNR_HD inline void chain_blocks_base(BlockSink &sink, const u64 *records, const UP *sep, const i32 *sep_score, u32 nb, u64 L, int which, int strand,
                                      int f_sort, BlockScratch s) {
     if (nb < 2) return;
     for (u32 i = 0; i < nb; i++) s.ptr[i] = i;
-    if (f_sort) ref_sort(s.ptr, (long)nb, [records, sep](const u32 &a, const u32 &b) { return cord_x40(records[sep[a].first]) > cord_x40(records[sep[b].first]); });
+    if (f_sort) ref_sort(s.ptr, (long)nb, [records, sep](const u32 &a, const u32 &b) { return cord_x40(records[sep[a].first]) > cord_x40(records[sep[b].first]); }, s.ls->st);
     for (u32 i = 0; i < nb; i++) { s.sep_tmp[i] = sep[s.ptr[i]]; s.score_tmp[i] = sep_score[s.ptr[i]]; }
     best_chains2(records, s.sep_tmp, s.score_tmp, nb, s.rec, L, which, strand);
     sink.elements = s.sep_tmp;
-    traceback(s.rec, nb, sink, s.chain, s.chain_sc, s.cnt, 1, 0, 3, 0.7f);
+    traceback(s.rec, nb, sink, s.chain, s.chain_sc, s.cnt, 1, 0, 3, 0.7f, *s.ls);
 }
 // _filterBlocksHits cluster_util.cpp:633-719: rewrites hits from the chained blocks (note: the dummy hits[0] is dropped)
 LNR_HD inline u32 filter_blocks_hits(const BlockSink &ch, const u64 *hits, u64 *out) {
@@ -610,13 +644,30 @@ LNR_HD inline u32 filter_blocks_hits(const BlockSink &ch, const u64 *hits, u64 *
 }
 
 // ----------------------------------------------------------------- windows ----
+// best of the three candidate x-cells [x0, x0+3) against read cell y: minimal distance, first minimum wins.
+// Device: called by all 64 lanes with identical arguments; lanes 0..2 evaluate one candidate each, the result is
+// made uniform with shuffles (one memory round trip instead of twelve dependent ones).  Host: plain loop.
+LNR_HD inline u32 window_best3(FeatView f1, FeatView f2, u64 y, u64 x0, u64 &x_min) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int lane = (int)(threadIdx.x & 63);
+    u32 t = lane < 3 ? wdist_raw(f1, f2, y, x0 + (u64)lane) : 0xffffffffu;
+    u32 t0 = __shfl(t, 0), t1 = __shfl(t, 1), t2 = __shfl(t, 2);
+    u32 mn = t0; x_min = x0;
+    if (t1 < mn) { mn = t1; x_min = x0 + 1; }
+    if (t2 < mn) { mn = t2; x_min = x0 + 2; }
+    return mn;
+#else
+    u32 mn = ~0u;
+    for (u64 x = x0; x < x0 + 3; x++) { u32 t = wdist_raw(f1, f2, y, x); if (t < mn) { mn = t; x_min = x; } }
+    return mn;
+#endif
+}
 LNR_HD inline u64 previous_window(FeatView f1, FeatView f2, u64 cord) {   // pmpfinder.cpp:883-945
     u64 gid = cord_id(cord), strand = cord_strand(cord);
     u64 x_suf = cord_x(cord) >> 4, y_suf = cord_y(cord) >> 4, x_min = 0;
     if (y_suf < 5 || x_suf < 6) return 0;
     u64 y = y_suf - 5;
-    u32 mn = ~0u;
-    for (u64 x = x_suf - 6; x < x_suf - 3; x++) { u32 t = wdist_raw(f1, f2, y, x); if (t < mn) { mn = t; x_min = x; } }
+    u32 mn = window_best3(f1, f2, y, x_suf - 6, x_min);
     if (mn > 36) return 0;
     if (x_suf - x_min > 5) return mk_cord((gid << 30) + ((x_suf - 5) << 4), (x_suf - x_min - 5 + y) << 4, strand);
     return mk_cord((gid << 30) + (x_min << 4), y << 4, strand);
@@ -626,19 +677,33 @@ LNR_HD inline u64 next_window(FeatView f1, FeatView f2, u64 cord) {   // pmpfind
     u64 x_pre = cord_x(cord) >> 4, y_pre = cord_y(cord) >> 4, x_min = 0;
     if (y_pre + 12 > f1.n || x_pre + 12 > f2.n) return 0;
     u64 y = y_pre + 5;
-    u32 mn = ~0u;
-    for (u64 x = x_pre + 3; x < x_pre + 6; x++) { u32 t = wdist_raw(f1, f2, y, x); if (t < mn) { mn = t; x_min = x; } }
+    u32 mn = window_best3(f1, f2, y, x_pre + 3, x_min);
     if (mn > 36) return 0;
     if (x_min - x_pre > 5) return mk_cord((gid << 30) + ((x_pre + 5) << 4), (x_pre + 5 - x_min + y) << 4, strand);
     return mk_cord((gid << 30) + (x_min << 4), y << 4, strand);
 }
-LNR_HD inline void extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 cordy_str, u64 cordy_end) {   // pmpfinder.cpp:1152-1178
+// SIMT-uniform: on the device every lane of the wave executes this with the same arguments (see window_best3);
+// `tail` is the value of cords.back(), carried in a register so that no lane has to re-read the leader's store.
+LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 &tail, u64 cordy_str, u64 cordy_end) {   // pmpfinder.cpp:1152-1178
     u32 p_str = cords.n - 1;
     u64 nc;
-    while ((nc = previous_window(f1, f2, cords.back())) && cord_y(nc) >= cordy_str) { if (cords.n >= cords.cap) { *cords.ovf = 1; return; } cords.push(nc); }
+    while ((nc = previous_window(f1, f2, tail)) && cord_y(nc) >= cordy_str) {
+        if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return false; }
+        cords.push_u(nc); tail = nc;
+    }
     u32 p_end = cords.n;
-    for (u32 k = p_str; k < (p_str + p_end) / 2; k++) rs_swap(cords[k], cords[cords.n - k + p_str - 1]);
-    while ((nc = next_window(f1, f2, cords.back())) && cord_y(nc) + 96 < cordy_end) { if (cords.n >= cords.cap) { *cords.ovf = 1; return; } cords.push(nc); }
+    if (p_end - p_str > 1) {
+        lnr_wave_sync();
+        if (lnr_is_leader())
+            for (u32 k = p_str; k < (p_str + p_end) / 2; k++) rs_swap(cords[k], cords[cords.n - k + p_str - 1]);
+        lnr_wave_sync();
+        tail = cords[cords.n - 1];
+    }
+    while ((nc = next_window(f1, f2, tail)) && cord_y(nc) + 96 < cordy_end) {
+        if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return false; }
+        cords.push_u(nc); tail = nc;
+    }
+    return true;
 }
 struct GenomeFeat { const F96 *base; const u64 *off; u32 nseq; };   // f2 of all sequences, off[nseq+1] in entries
 LNR_HD inline FeatView f2_view(GenomeFeat g, u64 id) {
@@ -647,20 +712,30 @@ LNR_HD inline FeatView f2_view(GenomeFeat g, u64 id) {
     v.p = g.base + g.off[id]; v.n = (u32)(g.off[id + 1] - g.off[id]);
     return v;
 }
-LNR_HD inline u32 filter_hits(u64 *hits, u32 nhits, const FeatView f1[2], GenomeFeat g) {   // _filterHits pmpfinder.cpp:1417-1445
+// _filterHits pmpfinder.cpp:1417-1445 in two steps: the window distances (elementwise, one hit per lane in the
+// kernel), then the order-dependent compaction with block-end propagation.
+LNR_HD inline void filter_hits_flags(const u64 *hits, u32 nhits, const FeatView f1[2], GenomeFeat g, i32 *keep, u32 first, u32 step) {
+    for (u32 it = 1 + first; it < nhits; it += step) {
+        u32 dist = wdist_checked(f1[cord_strand(hits[it])], f2_view(g, cord_id(hits[it])), cord_y(hits[it]) >> 4, cord_x(hits[it]) >> 4);
+        keep[it] = dist < 50 ? 1 : 0;
+    }
+}
+LNR_HD inline u32 filter_hits_apply(u64 *hits, u32 nhits, const i32 *keep) {
     u32 mv = 0;
     for (u32 it = 1; it < nhits; it++) {
-        u32 dist = wdist_checked(f1[cord_strand(hits[it])], f2_view(g, cord_id(hits[it])), cord_y(hits[it]) >> 4, cord_x(hits[it]) >> 4);
-        if (dist < 50) hits[it - mv] = hits[it];
+        if (keep[it]) hits[it - mv] = hits[it];
         else mv++;
         if (is_end(hits[it])) hits[it - mv] |= F_END;
     }
     return nhits - mv;
 }
+// SIMT-uniform (all lanes execute it together on the device; hits are read-only, cords are written by the leader).
 LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], GenomeFeat g, Vec<u64> &cords, u64 read_str, u64 read_end, u64 L) {   // pmpfinder.cpp:1309-1410
     i64 hitBegin = 1, hitEnd = (i64)nhits;
     if (hitBegin >= hitEnd - 1) return;
-    if (cords.n == 0) cords.push(F_END);   // initCords
+    u64 tail;
+    if (cords.n == 0) { cords.push_u(F_END); tail = F_END; }   // initCords
+    else tail = cords[cords.n - 1];
     u64 ready_str, ready_end, cordy_str = 0, cordy_end = 0;
     bool f_sp_l, f_sp_r = false, f_block_end = false, f_append;
     i64 itt_next = hitBegin + 1, itt_first = hitBegin;
@@ -681,9 +756,10 @@ LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], 
         }
         f_append = false;
         if (!f_sp_r && !f_block_end) {
-            cordy_str = f_sp_l ? hi : (first_i ? ready_str : cord_y(cords.back()));
+            cordy_str = f_sp_l ? hi : (first_i ? ready_str : cord_y(tail));
             cordy_end = cord_y(hits[itt_next]);
-            cords.push(hi & ~F_END);
+            if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return; }
+            cords.push_u(hi & ~F_END); tail = hi & ~F_END;
             f_append = true;
         } else {
             u64 hl = hits[itt_next - 1];
@@ -691,14 +767,14 @@ LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], 
                 u64 nc = shift_cord(hl, -96, -96);
                 cordy_str = first_i ? read_str : cord_y(nc);
                 cordy_end = cord_y(hl);
-                cords.push(nc & ~F_END);
+                if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return; }
+                cords.push_u(nc & ~F_END); tail = nc & ~F_END;
                 f_append = true;
             }
         }
         if (is_end(hi) || f_block_end) { f_block_end = true; cordy_end = ready_end; }
-        if (*cords.ovf) return;
-        if (f_append) extend_window(f1[cord_strand(hi)], f2_view(g, cord_id(hi)), cords, cordy_str, cordy_end);
-        if (f_block_end) cords.back() |= F_END;
+        if (f_append && !extend_window(f1[cord_strand(hi)], f2_view(g, cord_id(hi)), cords, tail, cordy_str, cordy_end)) return;
+        if (f_block_end) { tail |= F_END; if (lnr_is_leader()) cords[cords.n - 1] = tail; }
         itt_next = f_block_end ? itt_first : itt_next;
         f_sp_r = false; f_block_end = false;
     }
@@ -726,7 +802,7 @@ LNR_HD inline u32 clean_blocks(u64 *cords, u32 n, u64 drop_len) {   // clean_blo
     return (u32)ptr;
 }
 // gather_gaps_y_ pmpfinder.cpp:1592-1667; str_ends is sorted in place; gaps = forward-y intervals
-LNR_HD inline int gather_gaps_y(UP *str_ends, u32 ns, Vec<UP> &gaps, u64 L, u64 gap_size) {
+LNR_HD inline int gather_gaps_y(UP *str_ends, u32 ns, Vec<UP> &gaps, u64 L, u64 gap_size, LeaderScratch &ls) {
     u64 cord_frt = 0, cord_end = L - 1;
     int sum = 0;
     UP u;
@@ -735,7 +811,7 @@ LNR_HD inline int gather_gaps_y(UP *str_ends, u32 ns, Vec<UP> &gaps, u64 L, u64 
         u64 y1 = cord_strand(i.first) ? L - cord_y(i.second) - 1 : cord_y(i.first);
         u64 y2 = cord_strand(j.first) ? L - cord_y(j.second) - 1 : cord_y(j.first);
         return y1 < y2;
-    });
+    }, ls.st);
     u64 f_cover = 0, cordy1 = 0, cordy2 = 0;
     UP y1 = forward_y(str_ends[0], L), y2 = y1;
     if (y1.first > gap_size) {
@@ -771,13 +847,13 @@ LNR_HD inline void chain_blocks_single_strand(const u64 *cords, UP *sep, u32 nb,
             u64 y1 = !cord_strand(cords[a.first]) ? L - 1 - cord_y(cords[a.second - 1]) : cord_y(cords[a.first]);
             u64 y2 = !cord_strand(cords[b.first]) ? L - 1 - cord_y(cords[b.second - 1]) : cord_y(cords[b.first]);
             return y1 > y2;
-        });
+        }, s.ls->st);
     else
         ref_sort(sep, (long)nb, [cords, L](const UP &a, const UP &b) {
             u64 y1 = cord_strand(cords[a.first]) ? L - 1 - cord_y(cords[a.second - 1]) : cord_y(cords[a.first]);
             u64 y2 = cord_strand(cords[b.first]) ? L - 1 - cord_y(cords[b.second - 1]) : cord_y(cords[b.first]);
             return y1 > y2;
-        });
+        }, s.ls->st);
     for (u32 i = 0; i < nb; i++) sep_score[i] = (i32)((sep[i].second - sep[i].first) * 16);
     chain_blocks_base(sink, cords, sep, sep_score, nb, L, 3, strand, 0, s);
 }
@@ -876,10 +952,10 @@ struct JobDebug { u64 *filt; u32 *nfilt; u64 *xsort; u32 *nxsort; u64 *hits_chai
 // Phase 1 (serial): a = ascending-sorted anchors with a[0]==0.  filterAnchors1 compaction, the
 // tie-sensitive x-descending sort of chainAnchorsHits (pmpfinder.cpp:2465), x/y extraction.
 // Returns m, the number of anchors that enter the chaining DP.
-LNR_HD inline u32 job_phase1(u64 *a, u32 n_sorted, JobDebug *dbg) {
+LNR_HD inline u32 job_phase1(u64 *a, u32 n_sorted, JobDebug *dbg, LeaderScratch &ls) {
     u32 m = n_sorted > 1 ? filter_anchor_list(a, n_sorted) : n_sorted;   // filterAnchors1: length <= 1 -> unchanged
     if (dbg && dbg->filt) { for (u32 i = 0; i < m; i++) dbg->filt[i] = a[i]; *dbg->nfilt = m; }
-    ref_sort(a, (long)m, [](const u64 &p, const u64 &q) { return anchor_x(p) > anchor_x(q); });
+    ref_sort(a, (long)m, [](const u64 &p, const u64 &q) { return anchor_x(p) > anchor_x(q); }, ls.st);
     if (dbg && dbg->xsort) { for (u32 i = 0; i < m; i++) dbg->xsort[i] = a[i]; *dbg->nxsort = m; }
     return m;
 }
@@ -890,9 +966,10 @@ LNR_HD inline void job_fill_xy(const u64 *a, u32 m, JobScratch &S, u32 first, u3
 // (between the phases: the chaining DP over S.xs/S.ys into S.rec -- best_chains_serial here,
 //  its wave-parallel twin in the kernel -- only when m >= 2, chainAnchorsBase cluster_util.cpp:450)
 
-// Phase 3 (serial): traceback -> hits, hit blocks, window filter, path extension -> cords appended.
-// Returns 0, or 1 on capacity overflow.
-LNR_HD inline int job_phase3(u64 *a, u32 m, JobScratch &S, const JobCtx &c, Vec<u64> &cords, JobDebug *dbg) {
+// Phase 3a (serial, leader): traceback -> hits, hit blocks, block chaining.  Leaves the surviving hits in
+// (H, nH).  Returns 0, or 1 on capacity overflow.  The caller continues with filter_hits_flags (elementwise),
+// filter_hits_apply (leader) and path_dst_2 (SIMT-uniform) -- path_dst alg 2, pmpfinder.cpp:1447-1469.
+LNR_HD inline int job_phase3a(u64 *a, u32 m, JobScratch &S, const JobCtx &c, JobDebug *dbg, u64 *&H, u32 &nH, LeaderScratch &ls) {
     int *ovf = S.hits.ovf;
     Vec<u64> &hits = S.hits;
     unsigned long long tl_ = 0;
@@ -907,35 +984,26 @@ LNR_HD inline int job_phase3(u64 *a, u32 m, JobScratch &S, const JobCtx &c, Vec<
         S.hscore.push(0);        // initHitsScore
         if (m >= 2) {
             AnchorSink sink; sink.anchors = a; sink.hits = &hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
-            traceback(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, 1, 45, 50, 0.0f);
+            traceback(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, 1, 45, 50, 0.0f, ls);
         }
     }
     if (dbg && dbg->hits_chain) { for (u32 i = 0; i < hits.n; i++) dbg->hits_chain[i] = hits[i]; *dbg->nhits_chain = hits.n; }
     if (!c.traceback_done) LNR_TICK(c.prof, 5, tl_);
     // getAnchorHitsChains pmpfinder.cpp:2535-2545
     gather_blocks(hits.p, hits.n, nullptr, S.sep, 1, hits.n, c.L, 600, 0, 0);
-    prefilter_chains2(hits.p, hits.n, S.sep, S.cuts, S.xy_strs, S.tmp);
+    prefilter_chains2(hits.p, hits.n, S.sep, S.cuts, S.xy_strs, S.tmp, ls);
     LNR_TICK(c.prof, 6, tl_);
     for (u32 i = 0; i < S.sep.n; i++) S.sep_score[i] = S.hscore[(u32)S.sep[i].first] - S.hscore[(u32)S.sep[i].second - 1];
     // chainBlocksHits cluster_util.cpp:721-732 (scratch arrays of the anchor DP are dead and reused)
     BlockSink bs; bs.el = S.tmp.p; bs.off = S.chain; bs.nchains = 0; bs.nel = 0; bs.cap = S.tmp.cap; bs.ovf = ovf; bs.first_len = 0; bs.off[0] = 0;
-    BlockScratch s; s.ptr = S.xs; s.sep_tmp = (UP *)S.cuts; s.score_tmp = (i32 *)S.ys; s.rec = S.rec; s.chain = S.chain_sc; s.chain_sc = (i32 *)S.xy_strs; s.cnt = S.cnt;
+    BlockScratch s; s.ptr = S.xs; s.sep_tmp = (UP *)S.cuts; s.score_tmp = (i32 *)S.ys; s.rec = S.rec; s.chain = S.chain_sc; s.chain_sc = (i32 *)S.xy_strs; s.cnt = S.cnt; s.ls = &ls;
     chain_blocks_base(bs, hits.p, S.sep.p, S.sep_score, S.sep.n, c.L, 2, 0, 1, s);
     u64 *hits2 = a;   // anchors are dead by now; hits never outnumber them
     u32 nh2 = filter_blocks_hits(bs, hits.p, hits2);
-    u64 *H; u32 nH;
     if (nh2 == 0xffffffffu) { H = hits.p; nH = hits.n; } else { H = hits2; nH = nh2; }
     if (dbg && dbg->hits_blocks) { for (u32 i = 0; i < nH; i++) dbg->hits_blocks[i] = H[i]; *dbg->nhits_blocks = nH; }
     LNR_TICK(c.prof, 7, tl_);
-    if (*ovf) return 1;
-    // path_dst alg 2 (pmpfinder.cpp:1447-1469)
-    if (nH >= 2) {
-        nH = filter_hits(H, nH, c.f1, c.g);
-        LNR_TICK(c.prof, 8, tl_);
-        path_dst_2(H, nH, c.f1, c.g, cords, c.read_str, c.read_end, c.L);
-        LNR_TICK(c.prof, 9, tl_);
-    }
-    return (*ovf || *cords.ovf) ? 1 : 0;
+    return *ovf ? 1 : 0;
 }
 
 // ==================================================================== tails ====
@@ -943,7 +1011,7 @@ LNR_HD inline int job_phase3(u64 *a, u32 m, JobScratch &S, const JobCtx &c, Vec<
 // clean, gather (sets block ends), gaps.  Returns the number of remap gaps written (0 = no remap).
 LNR_HD inline u32 drop_len_of(u64 L) { i64 d = (i64)((double)L * 0.05 / 96); return (u32)(d < 2 ? d : 2); }
 
-LNR_HD inline int tail_a(u64 *cords, u32 &ncords, u64 L, Arena &ar, UP *gaps_out, u32 gaps_cap, u32 &ngaps, u32 &remap) {
+LNR_HD inline int tail_a(u64 *cords, u32 &ncords, u64 L, Arena &ar, UP *gaps_out, u32 gaps_cap, u32 &ngaps, u32 &remap, LeaderScratch &ls) {
     int ovf = 0;
     ncords = clean_blocks(cords, ncords, drop_len_of(L));
     u32 cap = ncords + 2;
@@ -952,14 +1020,14 @@ LNR_HD inline int tail_a(u64 *cords, u32 &ncords, u64 L, Arena &ar, UP *gaps_out
     if (ar.ovf) return 1;
     gather_blocks(cords, ncords, &str_ends, sep, 1, ncords, L, 1000, 96, 1);
     Vec<UP> gaps; gaps.init(gaps_out, gaps_cap, &ovf);
-    int sum = gather_gaps_y(str_ends.p, str_ends.n, gaps, L, 1000);
+    int sum = gather_gaps_y(str_ends.p, str_ends.n, gaps, L, 1000, ls);
     ngaps = gaps.n;
     remap = ((float)sum / (float)L >= 0.7f) ? 1 : 0;
     return ovf;
 }
 // Tail B = rest of apxMap (pmpfinder.cpp:2764-2801): re-gather, chain cord blocks on both strands, clean, flags.
 // out_str/out_end receive the final cords; returns count through nout.
-LNR_HD inline int tail_b(u64 *cords, u32 ncords, u64 L, Arena &ar, u64 *out_str, u64 *out_end, u32 out_cap, u32 &nout) {
+LNR_HD inline int tail_b(u64 *cords, u32 ncords, u64 L, Arena &ar, u64 *out_str, u64 *out_end, u32 out_cap, u32 &nout, LeaderScratch &ls) {
     int ovf = 0;
     u32 cap = ncords + 2;
     Vec<UP> sep; sep.init(ar.get<UP>(cap), cap, &ovf);
@@ -975,7 +1043,7 @@ LNR_HD inline int tail_b(u64 *cords, u32 ncords, u64 L, Arena &ar, u64 *out_str,
     BlockScratch s;
     s.ptr = ar.get<u32>(cap); s.sep_tmp = ar.get<UP>(cap); s.score_tmp = ar.get<i32>(cap);
     s.rec.score = ar.get<i32>(cap); s.rec.score2 = ar.get<i32>(cap); s.rec.len = ar.get<i32>(cap); s.rec.p2 = ar.get<i32>(cap); s.rec.root = ar.get<i32>(cap); s.rec.leaf = ar.get<i32>(cap);
-    s.chain = ar.get<i32>(cap); s.chain_sc = ar.get<i32>(cap); s.cnt = ar.get<i32>(cap);
+    s.chain = ar.get<i32>(cap); s.chain_sc = ar.get<i32>(cap); s.cnt = ar.get<i32>(cap); s.ls = &ls;
     UP *sep_tmp2 = ar.get<UP>(cap);
     u64 *tmp_cords = ar.get<u64>(cap + 2);
     if (ar.ovf) return 1;

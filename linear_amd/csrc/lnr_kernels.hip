@@ -429,6 +429,9 @@ struct JobArgs {
     u64 *cords; const u64 *cords_off; const u32 *cords_cap; u32 *ncords; i32 *read_err;
     u32 nbins; u32 grp_lo, grp_hi;
     u32 lds_bytes;          // dynamic LDS per block: binning histogram first, then the fast half of the job arena
+    u32 arena_lds;          // bytes of that LDS the arena may use (0 on the heavy path: its three kernels must replay identical global addresses)
+    u32 phase;              // 0 = whole job in one launch; heavy path: 1 = up to the x/y fill (state saved), 2 = from the traceback on
+    u32 *job_nbin, *job_m;  // heavy path: per-job anchor counts after binning / after filtering
     unsigned long long *prof;   // diagnostic build (-DLNR_PROF) only: per-phase cycle sums of lane 0
 };
 
@@ -516,23 +519,25 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
 #define SORT_SMALL 32
 struct XDesc { LNR_HD bool operator()(const u64 &p, const u64 &q) const { return anchor_x(p) > anchor_x(q); } };
 
-__device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *tasks, u32 *s_w /* 4 LDS words */) {
+__device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *tasks, LeaderScratch *ls /* LDS */) {
     int lane = lane_id();
     XDesc comp;
     if (n <= SORT_SMALL) {
-        if (lane == 0) ref_sort(a, (long)n, comp);
+        if (lane == 0) ref_sort(a, (long)n, comp, ls->st);
         __syncthreads();
         return;
     }
-    u32 stk_first[64], stk_last[64];
-    int stk_depth[64];
+    // wave-uniform stack: kept in LDS (every lane writes the same value), not in per-lane private memory
+    int *stk_first = ls->st.first, *stk_last = ls->st.last, *stk_depth = ls->st.depth;
     int sp = 0, lg = 0;
     for (u32 t = n; t > 1; t >>= 1) lg++;
-    stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = lg * 2; sp = 1;
+    if (lane == 0) { stk_first[0] = 0; stk_last[0] = (int)n; stk_depth[0] = lg * 2; }
+    sp = 1;
     u32 ntasks = 0;
     while (sp > 0) {
         --sp;
-        u32 first = stk_first[sp], last = stk_last[sp];
+        __syncthreads();
+        u32 first = (u32)stk_first[sp], last = (u32)stk_last[sp];
         int depth = stk_depth[sp];
         while (true) {
             if (last - first <= SORT_SMALL) {
@@ -573,23 +578,37 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
             if (K < nL) cut = Lbuf[K];
             if (K >= 1) { u32 r = Rbuf[nR - K]; cut = r < cut ? r : cut; }
             __syncthreads();
-            stk_first[sp] = cut; stk_last[sp] = last; stk_depth[sp] = depth; ++sp;
+            if (lane == 0) { stk_first[sp] = (int)cut; stk_last[sp] = (int)last; stk_depth[sp] = depth; }
+            ++sp;
             last = cut;
         }
     }
     __syncthreads();
     for (u32 t = lane; t < ntasks; t += 64) {
         u64 v = tasks[t];
-        rs_finish_range(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)(v >> 56), comp);
+        rs_finish_range<16>(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)(v >> 56), comp);   // ranges of <= 32 elements
     }
     __syncthreads();
-    (void)s_w;
 }
 
 // wave-parallel twin of best_chains_serial (getBestChains, cluster_util.cpp:53-111): serial over i, lanes over
 // the predecessor window, max-reduce with "smallest j wins among equal totals".
-__device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type) {
+// Exact pruning for long windows: a pair score never exceeds 100 (cluster_util.cpp:435-441), so a 64-anchor chunk
+// whose best chain score + 100 is below the best total found among the nearest 128 predecessors cannot win or tie;
+// a chunk whose largest y is below y_i + dy_min has no admissible predecessor at all.  cmax / cymax hold those
+// per-chunk maxima (chunk = index >> 6).
+__device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type, i32 *cmax, u32 *cymax) {
     int lane = lane_id();
+    u32 nchunk = (m + 63) >> 6;
+    for (u32 c = lane; c < nchunk; c += 64) cmax[c] = 0;
+    for (u32 c = 0; c < nchunk; c++) {   // per-chunk max y
+        u32 j = c * 64 + lane;
+        u32 y = j < m ? ys[j] : 0;
+        for (int o = 32; o > 0; o >>= 1) { u32 t = __shfl_xor(y, o); y = t > y ? t : y; }
+        if (lane == 0) cymax[c] = y;
+    }
+    __syncthreads();
+    const u32 dy_min = score_type ? 5u : 10u;
     u32 p300 = 0;
     for (u32 i = 0; i < m; i++) {
         u32 xi = xs[i], yi = ys[i];
@@ -597,26 +616,49 @@ __device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int
         while (p300 < i && xs[p300] - xi >= 300) p300++;
         int j_lo = (int)p300 < j_str ? (int)p300 : j_str;
         i64 best = -1;
-        for (int jb = (int)i - 1; jb >= j_lo; jb -= 64) {
+        int near_lo = (int)i - 128 > j_lo ? (int)i - 128 : j_lo;
+        for (int jb = (int)i - 1; jb >= near_lo; jb -= 64) {
             int j = jb - lane;
-            if (j >= j_lo) {
+            if (j >= near_lo) {
                 int sc = score_type ? chain_score0(xs[j], ys[j], xi, yi) : chain_score(xs[j], ys[j], xi, yi);
-                if (sc > 0) {
-                    i64 key = ((i64)(sc + r.score[j]) << 32) | (i64)(u32)(0x7fffffff - j);
-                    best = key > best ? key : best;
+                if (sc > 0) { i64 key = ((i64)(sc + r.score[j]) << 32) | (i64)(u32)(0x7fffffff - j); best = key > best ? key : best; }
+            }
+        }
+        if (near_lo > j_lo) {
+            // far part [j_lo, near_lo): visit only the chunks that can still matter
+            i64 bw = wave_max_i64(best);
+            int bt = bw >= 0 ? (int)(bw >> 32) : -1;
+            int far_hi = near_lo - 1;
+            int c_lo = j_lo >> 6, c_hi = far_hi >> 6;
+            for (int cb = c_hi; cb >= c_lo; cb -= 64) {
+                int c = cb - lane;
+                bool cand = c >= c_lo && cmax[c] + 100 >= bt && cymax[c] >= yi + dy_min;
+                u64 mask = __ballot(cand);
+                while (mask) {
+                    int l = __builtin_ctzll(mask);   // lane l holds chunk cb - l: nearest remaining chunk first
+                    mask &= mask - 1;
+                    int cc = cb - l;
+                    int j = cc * 64 + lane;
+                    if (j >= j_lo && j <= far_hi) {
+                        int sc = score_type ? chain_score0(xs[j], ys[j], xi, yi) : chain_score(xs[j], ys[j], xi, yi);
+                        if (sc > 0) { i64 key = ((i64)(sc + r.score[j]) << 32) | (i64)(u32)(0x7fffffff - j); best = key > best ? key : best; }
+                    }
                 }
             }
         }
         best = wave_max_i64(best);
         if (lane == 0) {
+            int tot;
             if (best >= 0) {
-                int tot = (int)(best >> 32);
+                tot = (int)(best >> 32);
                 int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff);
                 r.p2[i] = mj; r.score[i] = tot; r.len[i] = r.len[mj] + 1; r.score2[i] = tot;
                 r.root[i] = r.root[mj]; r.leaf[i] = 1; r.leaf[mj] = 0;
             } else {
+                tot = 0;
                 r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = (i32)i; r.leaf[i] = 1;
             }
+            if (tot > cmax[i >> 6]) cmax[i >> 6] = tot;
         }
         __syncthreads();
     }
@@ -644,7 +686,7 @@ __device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {
 }
 // traceBackChains (cluster_util.cpp:306-335) for the anchor DP, lanes cooperating on the scans; lane 0 walks chains
 // and emits hits.  s_flag = one LDS word.
-__device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int *s_flag) {
+__device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int *s_flag, LeaderScratch *ls) {
     int lane = lane_id();
     for (u32 i = lane; i < n; i += 64) cnt[i] = 0;
     __syncthreads();
@@ -663,18 +705,21 @@ __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain
             if (!cont) break;
         }
     } else {
-        if (lane == 0) traceback1(r, n, sink, chain, chain_sc, 1, 45, 50, 0.0f);
+        if (lane == 0) traceback1(r, n, sink, chain, chain_sc, 1, 45, 50, 0.0f, *ls);
         __syncthreads();
     }
 }
 
 // One wave per read: runs the read's jobs in order (round 0: the whole read; remap round: its gaps),
 // appending cords to the read's cord list exactly like consecutive apxMap_ calls do.
-__global__ void __launch_bounds__(64) k_job(JobArgs A) {
+__global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
     extern __shared__ u32 dyn_lds[];   // binning halves
     __shared__ u32 hist[256];
     __shared__ u32 s_m;
     __shared__ int s_ovf, s_flag;
+    __shared__ u64 *s_H;
+    __shared__ u32 s_nH;
+    __shared__ LeaderScratch s_ls;   // introsort stack + tree table: one per wave, in LDS
     if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
     u32 grp = A.grp_order[A.grp_lo + blockIdx.x];
     int lane = lane_id();
@@ -699,56 +744,90 @@ __global__ void __launch_bounds__(64) k_job(JobArgs A) {
         u32 n = A.n_anchors[j];
         u32 cap = A.job_cap[j] + 2;
         LNR_TICK(prof, 0, tk_);
-        n = binning_wave(ag, n, dyn_lds, A.nbins);   // uses the dynamic LDS as its histogram
+        if (A.phase != 2) n = binning_wave(ag, n, dyn_lds, A.nbins);   // uses the dynamic LDS as its histogram
+        else n = A.job_nbin[j];
         LNR_TICK(prof, 1, tk_);
         // two-level arena: dynamic LDS first (re-used once binning is done), the job's global scratch behind it
         Arena slow; slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
-        Arena ar; ar.init((void *)dyn_lds, A.lds_bytes); ar.next = &slow;
+        Arena ar; ar.init((void *)dyn_lds, A.arena_lds); ar.next = &slow;
         u64 *a = ag;
         u64 *s_alt = nullptr;
         if (n > 1) {
-            if (lane == 0) ag[0] = 0;   // filterAnchorsList pmpfinder.cpp:2031
-            __syncthreads();
             u64 *alt = slow.get<u64>(cap);
             s_alt = alt;
-            radix_sort_wave(ag, alt, n, hist);
             a = ar.get<u64>((u64)n + 2);          // sorted anchors move next to the lanes (LDS when they fit)
-            for (u32 i = lane; i < n; i += 64) a[i] = ag[i];
-            __syncthreads();
+            if (A.phase != 2) {
+                if (lane == 0) ag[0] = 0;   // filterAnchorsList pmpfinder.cpp:2031
+                __syncthreads();
+                radix_sort_wave(ag, alt, n, hist);
+                for (u32 i = lane; i < n; i += 64) a[i] = ag[i];
+                __syncthreads();
+            }
         }
         LNR_TICK(prof, 2, tk_);
-        if (lane == 0) s_m = n > 1 ? filter_anchor_list(a, n) : n;   // filterAnchors1 (pmpfinder.cpp:2073-2091)
-        __syncthreads();
-        u32 m = s_m;
+        u32 m;
+        if (A.phase != 2) {
+            if (lane == 0) s_m = n > 1 ? filter_anchor_list(a, n) : n;   // filterAnchors1 (pmpfinder.cpp:2073-2091)
+            __syncthreads();
+            m = s_m;
+        } else m = A.job_m[j];
         if (m > 1) {
             // scratch of the sort: position lists in the (dead) radix buffer, task list behind it
             u32 *Lbuf = (u32 *)s_alt, *Rbuf = Lbuf + (m + 2);
             u64 *tasks = slow.get<u64>((u64)m + 2);
-            introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, nullptr);
+            if (A.phase != 2) introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, &s_ls);
         }
         JobScratch S;
         bool ok = job_carve(ar, m, S, &s_ovf);
         if (!ok || slow.ovf) { if (lane == 0) s_ovf = 1; __syncthreads(); break; }
-        job_fill_xy(a, m, S, (u32)lane, 64);
-        __syncthreads();
-        LNR_TICK(prof, 3, tk_);
         int mode = (int)A.J.mode[j];
-        if (m >= 2) best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type);
+        if (A.phase != 2) {
+            job_fill_xy(a, m, S, (u32)lane, 64);
+            __syncthreads();
+        }
+        LNR_TICK(prof, 3, tk_);
+        if (A.phase == 1) {   // heavy path: state saved, the DP runs in k_dp_big with 16 waves
+            if (lane == 0) { A.job_nbin[j] = n; A.job_m[j] = m; }
+            continue;
+        }
+        if (m >= 2 && A.phase == 0) {
+            u32 nchunk = (m + 63) >> 6;
+            i32 *cmax = ar.get<i32>(nchunk + 1);
+            u32 *cymax = ar.get<u32>(nchunk + 1);
+            best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, cmax, cymax);
+        }
         LNR_TICK(prof, 4, tk_);
-        // traceback of the anchor chains -> hits (lane 0 owns S.hits / S.hscore from here on)
+        // traceback of the anchor chains -> hits (the leader owns S.hits / S.hscore from here on)
         AnchorSink sink; sink.anchors = a; sink.hits = &S.hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
         if (lane == 0) { S.hits.n = 0; S.hscore.n = 0; S.hits.push(F_END); S.hscore.push(0); }
-        if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, &s_flag);
+        if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, &s_flag, &s_ls);
         LNR_TICK(prof, 5, tk_);
-        if (lane == 0) {
-            JobCtx c;
-            c.traceback_done = 1;
-            c.L = L; c.read_str = A.J.str[j]; c.read_end = A.J.end[j]; c.mode = mode;
-            u32 nf = A.nf[r];
-            c.f1[0].p = A.f1 + A.f1_off[r]; c.f1[0].n = nf;
-            c.f1[1].p = A.f1 + A.f1_off[r] + nf; c.f1[1].n = nf;
-            c.g = A.g; c.bins = nullptr; c.nbins = 0; c.pair_evals = nullptr; c.prof = prof;
-            if (job_phase3(a, m, S, c, cords, nullptr)) s_ovf = 1;
+        JobCtx c;
+        c.traceback_done = 1;
+        c.L = L; c.read_str = A.J.str[j]; c.read_end = A.J.end[j]; c.mode = mode;
+        u32 nf = A.nf[r];
+        c.f1[0].p = A.f1 + A.f1_off[r]; c.f1[0].n = nf;
+        c.f1[1].p = A.f1 + A.f1_off[r] + nf; c.f1[1].n = nf;
+        c.g = A.g; c.bins = nullptr; c.nbins = 0; c.pair_evals = nullptr; c.prof = prof;
+        if (lane == 0) {   // hit blocks + block chaining (serial)
+            u64 *H = nullptr; u32 nH = 0;
+            if (job_phase3a(a, m, S, c, nullptr, H, nH, s_ls)) s_ovf = 1;
+            s_H = H; s_nH = nH;
+        }
+        __syncthreads();
+        if (s_ovf) break;
+        {
+            u64 *H = s_H; u32 nH = s_nH;
+            if (nH >= 2) {
+                filter_hits_flags(H, nH, c.f1, c.g, S.cnt, (u32)lane, 64);    // window distance of one hit per lane
+                __syncthreads();
+                if (lane == 0) s_nH = filter_hits_apply(H, nH, S.cnt);
+                __syncthreads();
+                nH = s_nH;
+                LNR_TICK(prof, 8, tk_);
+                path_dst_2(H, nH, c.f1, c.g, cords, c.read_str, c.read_end, L);   // SIMT-uniform: candidates evaluated by lanes 0..2
+                LNR_TICK(prof, 9, tk_);
+            }
         }
         __syncthreads();
 #ifdef LNR_PROF
@@ -757,6 +836,56 @@ __global__ void __launch_bounds__(64) k_job(JobArgs A) {
         if (s_ovf) break;
     }
     if (lane == 0) { A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
+}
+
+// Heavy path, middle kernel: the chaining DP of one large job with 16 waves.  Same recurrence and tie rule as
+// best_chains_wave; the predecessor window of anchor i is spread over 1024 threads.  Pointers are recovered by
+// replaying the job's (global-only) arena allocations.
+__global__ void __launch_bounds__(1024) k_dp_big(JobArgs A, const u32 *jobs, u32 njobs) {
+    __shared__ long long s_best[16];
+    if (blockIdx.x >= njobs) return;
+    u32 j = jobs[blockIdx.x];
+    u32 n = A.job_nbin[j], m = A.job_m[j];
+    if (m < 2) return;
+    u32 cap = A.job_cap[j] + 2;
+    Arena slow; slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
+    if (n > 1) { (void)slow.get<u64>(cap); (void)slow.get<u64>((u64)n + 2); }
+    if (m > 1) (void)slow.get<u64>((u64)m + 2);
+    JobScratch S;
+    int dummy = 0;
+    if (!job_carve(slow, m, S, &dummy)) return;
+    const u32 *xs = S.xs, *ys = S.ys;
+    Rec r = S.rec;
+    int score_type = job_parm((int)A.J.mode[j]).score_type;
+    int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 p300 = 0;
+    for (u32 i = 0; i < m; i++) {
+        u32 xi = xs[i], yi = ys[i];
+        int j_str = (int)i - 20 < 0 ? 0 : (int)i - 20;
+        while (p300 < i && xs[p300] - xi >= 300) p300++;
+        int j_lo = (int)p300 < j_str ? (int)p300 : j_str;
+        i64 best = -1;
+        for (int jj = (int)i - 1 - tid; jj >= j_lo; jj -= 1024) {
+            int sc = score_type ? chain_score0(xs[jj], ys[jj], xi, yi) : chain_score(xs[jj], ys[jj], xi, yi);
+            if (sc > 0) { i64 key = ((i64)(sc + r.score[jj]) << 32) | (i64)(u32)(0x7fffffff - jj); best = key > best ? key : best; }
+        }
+        best = wave_max_i64(best);
+        if (lane == 0) s_best[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            i64 b = s_best[0];
+            for (int w = 1; w < 16; w++) b = s_best[w] > b ? s_best[w] : b;
+            if (b >= 0) {
+                int tot = (int)(b >> 32);
+                int mj = 0x7fffffff - (int)(u32)(b & 0xffffffff);
+                r.p2[i] = mj; r.score[i] = tot; r.len[i] = r.len[mj] + 1; r.score2[i] = tot;
+                r.root[i] = r.root[mj]; r.leaf[i] = 1; r.leaf[mj] = 0;
+            } else {
+                r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = (i32)i; r.leaf[i] = 1;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // =================================================================== tails ====
@@ -775,7 +904,8 @@ __global__ void __launch_bounds__(64) k_tail_a(TailArgs T) {
     if (L <= 200 || T.read_err[r]) return;
     Arena ar; ar.init(T.scratch + T.scr_off[r], tail_scratch_bytes(T.scr_cap[r]));
     u32 nc = T.ncords[r], ng = 0, rm = 0;
-    int rc = tail_a(T.cords + T.cords_off[r], nc, L, ar, T.gaps + T.gaps_off[r], T.gaps_cap[r], ng, rm);
+    LeaderScratch ls;
+    int rc = tail_a(T.cords + T.cords_off[r], nc, L, ar, T.gaps + T.gaps_off[r], T.gaps_cap[r], ng, rm, ls);
     T.ncords[r] = nc; T.ngaps[r] = ng; T.remap[r] = rm;
     if (rc || ar.ovf) T.read_err[r] = 2;
 }
@@ -787,7 +917,8 @@ __global__ void __launch_bounds__(64) k_tail_b(TailArgs T) {
     if (L <= 200 || T.read_err[r]) return;
     Arena ar; ar.init(T.scratch + T.scr_off[r], tail_scratch_bytes(T.scr_cap[r]));
     u32 no = 0;
-    int rc = tail_b(T.cords + T.cords_off[r], T.ncords[r], L, ar, T.out_str + T.cords_off[r], T.out_end + T.cords_off[r], T.cords_cap[r], no);
+    LeaderScratch ls;
+    int rc = tail_b(T.cords + T.cords_off[r], T.ncords[r], L, ar, T.out_str + T.cords_off[r], T.out_end + T.cords_off[r], T.cords_cap[r], no, ls);
     T.nout[r] = no;
     if (rc || ar.ovf) { T.read_err[r] = 3; T.nout[r] = 0; }
 }

@@ -101,13 +101,15 @@ LNR_HD inline void rs_heap_sort(T *a, long first, long last, Comp comp) {
     }
 }
 
+// Explicit stack of the introsort loop.  Depth <= 2*lg(n) + 1 entries; callers on the GPU place it in LDS
+// (one per wave) instead of per-lane private memory, which would cost occupancy.
+struct SortStack { int first[96], last[96], depth[96]; };
+
 // std::sort(a, a+n, comp)
 template <class T, class Comp>
-LNR_HD inline void ref_sort(T *a, long n, Comp comp) {
+LNR_HD inline void ref_sort(T *a, long n, Comp comp, SortStack &st) {
     if (n <= 0) return;
-    // __introsort_loop with an explicit stack; depth <= 2*lg(n) entries suffice
-    long stk_first[96], stk_last[96];
-    int stk_depth[96];
+    int *stk_first = st.first, *stk_last = st.last, *stk_depth = st.depth;
     int sp = 0;
     int lg = 0;
     for (long t = n; t > 1; t >>= 1) lg++;
@@ -142,7 +144,7 @@ LNR_HD inline void ref_sort(T *a, long n, Comp comp) {
             }
             long cut = lo;
             // recurse on [cut,last), continue with [first,cut)
-            stk_first[sp] = cut; stk_last[sp] = last; stk_depth[sp] = depth_limit; ++sp;
+            stk_first[sp] = (int)cut; stk_last[sp] = (int)last; stk_depth[sp] = depth_limit; ++sp;
             last = cut;
         }
     }
@@ -186,10 +188,11 @@ LNR_HD inline long rs_partition_lists(T *a, long lo, long hi, const T &p, Comp c
     return cut;
 }
 // serial introsort loop on [first,last) followed by the insertion sort of that range
-template <class T, class Comp>
+// STK = stack entries: a range of s elements needs at most min(depth, s - 16) entries.
+template <int STK, class T, class Comp>
 LNR_HD inline void rs_finish_range(T *a, long first0, long last0, int depth0, Comp comp) {
-    long stk_first[96], stk_last[96];
-    int stk_depth[96];
+    int stk_first[STK], stk_last[STK];
+    int stk_depth[STK];
     int sp = 0;
     stk_first[0] = first0; stk_last[0] = last0; stk_depth[0] = depth0; sp = 1;
     while (sp > 0) {
@@ -217,7 +220,7 @@ LNR_HD inline void rs_finish_range(T *a, long first0, long last0, int depth0, Co
                 rs_swap(a[lo], a[hi]);
                 ++lo;
             }
-            stk_first[sp] = lo; stk_last[sp] = last; stk_depth[sp] = depth_limit; ++sp;
+            stk_first[sp] = (int)lo; stk_last[sp] = (int)last; stk_depth[sp] = depth_limit; ++sp;
             last = lo;
         }
     }
@@ -236,7 +239,7 @@ LNR_HD inline void ref_sort_model(T *a, long n, Comp comp, long small_limit, lon
         long first = stk_first[sp], last = stk_last[sp];
         int depth_limit = stk_depth[sp];
         while (true) {
-            if (last - first <= small_limit) { rs_finish_range(a, first, last, depth_limit, comp); break; }
+            if (last - first <= small_limit) { rs_finish_range<96>(a, first, last, depth_limit, comp); break; }
             if (depth_limit == 0) { rs_heap_sort(a, first, last, comp); break; }
             --depth_limit;
             long mid = first + (last - first) / 2;

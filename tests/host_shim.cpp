@@ -124,11 +124,19 @@ int run_job(Shim &c, const u8 *read, u64 L, u64 read_str, u64 read_end, int mode
     if (dbg) { jd.filt = d1.data(); jd.nfilt = &n1; jd.xsort = d2.data(); jd.nxsort = &n2; jd.hits_chain = d3.data(); jd.nhits_chain = &n3; }
     int ovf = 0;
     JobScratch S;
-    u32 m = job_phase1(a.data(), n, dbg ? &jd : nullptr);
+    LeaderScratch ls;
+    u32 m = job_phase1(a.data(), n, dbg ? &jd : nullptr, ls);
     if (!job_carve(ar, m, S, &ovf)) return 1;
     job_fill_xy(a.data(), m, S, 0, 1);
     if (m >= 2) best_chains_serial(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, jc.pair_evals);
-    int rc = job_phase3(a.data(), m, S, jc, cords, dbg ? &jd : nullptr);
+    u64 *H = nullptr; u32 nH = 0;
+    int rc = job_phase3a(a.data(), m, S, jc, dbg ? &jd : nullptr, H, nH, ls);
+    if (!rc && nH >= 2) {
+        filter_hits_flags(H, nH, jc.f1, jc.g, S.cnt, 0, 1);
+        nH = filter_hits_apply(H, nH, S.cnt);
+        path_dst_2(H, nH, jc.f1, jc.g, cords, read_str, read_end, L);
+    }
+    if (ovf || *cords.ovf) rc = 1;
     if (dbg) { c.dbg[1].assign(d1.begin(), d1.begin() + n1); c.dbg[2].assign(d2.begin(), d2.begin() + n2); c.dbg[3].assign(d3.begin(), d3.begin() + n3); }
     return rc;
 }
@@ -156,7 +164,8 @@ int map_read(Shim &c, const u8 *read_in, u64 L, bool dbg) {
     Arena ar; ar.init(scratch.data(), scratch.size());
     std::vector<UP> gaps(cap_c);
     u32 ngaps = 0, remap = 0, nc = cv.n;
-    if (tail_a(cords.data(), nc, L, ar, gaps.data(), cap_c, ngaps, remap)) return -2;
+    LeaderScratch ls;
+    if (tail_a(cords.data(), nc, L, ar, gaps.data(), cap_c, ngaps, remap, ls)) return -2;
     cv.n = nc;
     if (remap) {
         for (u32 i = 0; i < ngaps; i++) {
@@ -167,7 +176,7 @@ int map_read(Shim &c, const u8 *read_in, u64 L, bool dbg) {
     ar.init(scratch.data(), scratch.size());
     std::vector<u64> os(cap_c), oe(cap_c);
     u32 nout = 0;
-    if (tail_b(cords.data(), cv.n, L, ar, os.data(), oe.data(), cap_c, nout)) return -4;
+    if (tail_b(cords.data(), cv.n, L, ar, os.data(), oe.data(), cap_c, nout, ls)) return -4;
     c.cs.assign(os.begin(), os.begin() + nout);
     c.ce.assign(oe.begin(), oe.begin() + nout);
     return 0;
@@ -243,8 +252,9 @@ void hs_get_stats(void *h, u64 *out5) { memcpy(out5, ((Shim *)h)->stats, 40); }
 
 // fuzz hook for ref_sort: sorts keys (compare on the high 32 bits only, descending when desc != 0)
 void hs_ref_sort_hi32(u64 *a, u64 n, int desc) {
-    if (desc) ref_sort(a, (long)n, [](const u64 &x, const u64 &y) { return (x >> 32) > (y >> 32); });
-    else ref_sort(a, (long)n, [](const u64 &x, const u64 &y) { return (x >> 32) < (y >> 32); });
+    SortStack st;
+    if (desc) ref_sort(a, (long)n, [](const u64 &x, const u64 &y) { return (x >> 32) > (y >> 32); }, st);
+    else ref_sort(a, (long)n, [](const u64 &x, const u64 &y) { return (x >> 32) < (y >> 32); }, st);
 }
 void hs_std_sort_hi32(u64 *a, u64 n, int desc) {
     if (desc) std::sort(a, a + n, [](const u64 &x, const u64 &y) { return (x >> 32) > (y >> 32); });

@@ -99,3 +99,17 @@ def test_gpu_scratch_slicing(oracle_lib):
     ooff, ocs, oce, _ = o.map_batch(reads, off, threads=4)
     assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
     f.close()
+
+
+def test_gpu_heavy_path(case_inputs, monkeypatch):
+    """Force every job through the heavy path (pre -> 16-wave DP -> post on a second stream): same cords."""
+    from linear_amd import Filter
+    monkeypatch.setenv("LNR_HEAVY_CAP", "64")
+    f = Filter(device=0)
+    for name, T in (("rep", 1), ("edge", 3)):
+        refs, reads, off = case_inputs(name)
+        g = np.load(os.path.join(GOLD, f"{name}_T{T}.npz"))
+        f.build_index(refs, T)
+        coff, cs, ce = f.filter_batch(reads, off)
+        assert np.array_equal(coff, g["cord_off"]) and np.array_equal(cs, g["cords_str"]) and np.array_equal(ce, g["cords_end"])
+    f.close()
