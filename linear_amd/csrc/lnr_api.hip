@@ -62,6 +62,7 @@ struct lnr_ctx {
     u32 nbins = 0;
     size_t job_lds_bytes = 8 * 1024;    // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
     u32 heavy_cap = 4096;               // jobs with at least this many bucket entries take the heavy path (LNR_HEAVY_CAP overrides)
+    u32 dp_lds_kb = 0;                  // LDS-resident DP state in k_dp_big (LNR_DP_LDS_KB; 0 = global arrays)
     hipStream_t stream2 = nullptr;      // heavy path runs here, concurrently with the fused k_job
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off;
@@ -316,7 +317,7 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
                 H.phase = 1;
                 hipLaunchKernelGGL(k_job, dim3(gh - g0), dim3(64), H.lds_bytes, ctx->stream2, H);
                 KCHECK();
-                hipLaunchKernelGGL(k_dp_big, dim3((u32)hjobs.size()), dim3(1024), 0, ctx->stream2, H, ctx->heavy_jobs.as<u32>(), (u32)hjobs.size());
+                hipLaunchKernelGGL(k_dp_big<1024>, dim3((u32)hjobs.size()), dim3(1024), 0, ctx->stream2, H, ctx->heavy_jobs.as<u32>(), (u32)hjobs.size(), 0u);
                 KCHECK();
                 H.phase = 2;
                 hipLaunchKernelGGL(k_job, dim3(gh - g0), dim3(64), H.lds_bytes, ctx->stream2, H);
@@ -648,6 +649,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_HEAVY_CAP")) { long v = atol(e); if (v >= 64) ctx->heavy_cap = (u32)v; }
+    if (const char *e = getenv("LNR_DP_LDS_KB")) { long v = atol(e); if (v >= 0 && v <= 63) ctx->dp_lds_kb = (u32)v; }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     ctx->t_prep.init(); ctx->t_sc.init(); ctx->t_sg.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();

@@ -301,40 +301,48 @@ LNR_HD inline u32 filter_anchor_list(u64 *a, u32 n) {
 }
 
 // ------------------------------------------------------------ chain scoring ----
-// derr = floor(100*da / max(|dy|,|dx|,50)) (cluster_util.cpp:350,401).  With |dx| < 2^20 every operand fits
-// 32 bits (y < 2^20), so the common case avoids the 64-bit division; same quotient either way.
-LNR_HD inline i64 chain_derr(i64 dx, i64 dy, i64 da) {
-    i64 M = max64(max64(labs64(dy), labs64(dx)), 50);
-    if (M < (1 << 20) && da < (1 << 21)) return (i64)((u32)(100u * (u32)da) / (u32)M);
-    return (100 * da) / M;
+// Pair scores of the chaining DP (getApxChainScore / getApxChainScore0, cluster_util.cpp:337-443) in 32-bit
+// arithmetic: x < 2^30 and y < 2^20 (cords.cpp:13-15), so dx, dy and da = |dx - dy| fit an int32.  The reference's
+// derr = floor(100*da / max(|dy|,|dx|,50)) is only evaluated where it matters:
+//   da >= M  <=>  derr >= 100  (reject, -1000);   da < 10 (score) / da < 30 (score0): the result does not use derr.
+// 100*da fits 32 bits when da < 2^25; beyond that the 64-bit quotient is taken (M > da >= 2^25 only for |dx| that large).
+LNR_HD inline i32 chain_derr32(i32 da, i32 M) {
+    if (da < (1 << 25)) return (i32)((u32)(100u * (u32)da) / (u32)M);
+    return (i32)((100LL * (i64)da) / (i64)M);
 }
 LNR_HD inline int chain_score0(u32 x1, u32 y1, u32 x2, u32 y2) {   // getApxChainScore0 cluster_util.cpp:337-385 (effective values)
-    i64 dy = (i64)y1 - (i64)y2;
+    i32 dy = (i32)y1 - (i32)y2;
     if (dy < 5) return -10000;
-    i64 dx = (i64)x1 - (i64)x2;
-    i64 da = labs64(dx - dy);
-    i64 derr = chain_derr(dx, dy, da);
-    if (derr >= 100) return -1000;
-    if (da < 30) return (int)(100 - dy);
-    return (int)(100 - dy - da);
+    i32 dx = (i32)x1 - (i32)x2;
+    i32 t = dx - dy;
+    i32 da = t < 0 ? -t : t;
+    i32 adx = dx < 0 ? -dx : dx;
+    i32 M = dy > adx ? dy : adx;
+    if (M < 50) M = 50;
+    if (da >= M) return -1000;          // derr >= 100
+    if (da < 30) return 100 - dy;
+    return 100 - dy - da;
 }
 LNR_HD inline int chain_score(u32 x1, u32 y1, u32 x2, u32 y2) {   // getApxChainScore cluster_util.cpp:387-443
-    i64 dy = (i64)y1 - (i64)y2;
+    i32 dy = (i32)y1 - (i32)y2;
     if (dy < 10) return -10000;
-    i64 dx = (i64)x1 - (i64)x2;
-    i64 da = labs64(dx - dy);
-    i64 derr = chain_derr(dx, dy, da);
-    int score_derr;
-    if (derr < 5) score_derr = (int)(4 * derr);
-    else if (derr < 10) score_derr = (int)(6 * derr - 10);
-    else if (derr < 100) score_derr = (int)(derr * derr - 5 * derr);
-    else return -1000;
-    int score_dy;
-    dy /= 15;
-    if (dy < 150) score_dy = (int)(dy / 5);
-    else if (dy < 10000) score_dy = (int)(dy * dy / 200 + 20);
+    i32 dx = (i32)x1 - (i32)x2;
+    i32 t = dx - dy;
+    i32 da = t < 0 ? -t : t;
+    i32 adx = dx < 0 ? -dx : dx;
+    i32 M = dy > adx ? dy : adx;
+    if (M < 50) M = 50;
+    if (da >= M) return -1000;          // derr >= 100
+    i32 dq = dy / 15, score_dy;
+    if (dq < 150) score_dy = dq / 5;
+    else if (dq < 10000) score_dy = dq * dq / 200 + 20;   // dq < 2^20/15: dq*dq < 2^33 cannot happen here (dq < 10000 -> < 1e8)
     else score_dy = 10000;
     if (da < 10) return 100 - score_dy;
+    i32 derr = chain_derr32(da, M);
+    i32 score_derr;
+    if (derr < 5) score_derr = 4 * derr;
+    else if (derr < 10) score_derr = 6 * derr - 10;
+    else score_derr = derr * derr - 5 * derr;
     return 100 - score_dy - score_derr;
 }
 

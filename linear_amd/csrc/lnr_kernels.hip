@@ -838,11 +838,23 @@ __global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
     if (lane == 0) { A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
 }
 
-// Heavy path, middle kernel: the chaining DP of one large job with 16 waves.  Same recurrence and tie rule as
-// best_chains_wave; the predecessor window of anchor i is spread over 1024 threads.  Pointers are recovered by
-// replaying the job's (global-only) arena allocations.
-__global__ void __launch_bounds__(1024) k_dp_big(JobArgs A, const u32 *jobs, u32 njobs) {
-    __shared__ long long s_best[16];
+// Heavy path, middle kernel: the chaining DP (getBestChains, cluster_util.cpp:53-111) of one large job, blocked.
+// The recurrence is serial in i only through predecessors inside a short distance, so anchors are processed in
+// tiles of 64:
+//   phase A (16 waves, no dependencies): for every anchor of the tile, the best (total, smallest j) over its
+//            predecessors that lie BEFORE the tile -- their chain scores are final;
+//   phase B (wave 0, all state in LDS): the 64 anchors in order, lanes over the in-tile predecessors, merged with the
+//            phase-A candidate under the same key (max total, ties -> smallest j).
+// Per-anchor cost drops from a chain of dependent global loads plus two block barriers to ~1/64 of two barriers
+// plus one LDS round.  Window bounds j_lo(i) depend on x only and are precomputed for the whole job.
+#define DP_TILE 64
+template <int NT>
+__global__ void __launch_bounds__(NT) k_dp_big(JobArgs A, const u32 *jobs, u32 njobs, u32 unused_) {
+    __shared__ u32 tx[DP_TILE], ty[DP_TILE];
+    __shared__ i32 ts[DP_TILE], tlen[DP_TILE], troot[DP_TILE], tjlo[DP_TILE];
+    __shared__ long long tkey[DP_TILE];
+    __shared__ i32 talen[DP_TILE], taroot[DP_TILE];   // len / root of the phase-A candidate (prefetched)
+    (void)unused_;
     if (blockIdx.x >= njobs) return;
     u32 j = jobs[blockIdx.x];
     u32 n = A.job_nbin[j], m = A.job_m[j];
@@ -854,38 +866,89 @@ __global__ void __launch_bounds__(1024) k_dp_big(JobArgs A, const u32 *jobs, u32
     JobScratch S;
     int dummy = 0;
     if (!job_carve(slow, m, S, &dummy)) return;
-    const u32 *xs = S.xs, *ys = S.ys;
     Rec r = S.rec;
-    int score_type = job_parm((int)A.J.mode[j]).score_type;
+    const u32 *xs = S.xs, *ys = S.ys;
+    i32 *jlo = S.cnt;   // dead until the traceback re-initialises it
     int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32 p300 = 0;
-    for (u32 i = 0; i < m; i++) {
-        u32 xi = xs[i], yi = ys[i];
-        int j_str = (int)i - 20 < 0 ? 0 : (int)i - 20;
-        while (p300 < i && xs[p300] - xi >= 300) p300++;
-        int j_lo = (int)p300 < j_str ? (int)p300 : j_str;
-        i64 best = -1;
-        for (int jj = (int)i - 1 - tid; jj >= j_lo; jj -= 1024) {
-            int sc = score_type ? chain_score0(xs[jj], ys[jj], xi, yi) : chain_score(xs[jj], ys[jj], xi, yi);
-            if (sc > 0) { i64 key = ((i64)(sc + r.score[jj]) << 32) | (i64)(u32)(0x7fffffff - jj); best = key > best ? key : best; }
-        }
-        best = wave_max_i64(best);
-        if (lane == 0) s_best[wave] = best;
+    const int NW = NT / 64;
+    int score_type = job_parm((int)A.J.mode[j]).score_type;
+#ifdef LNR_PROF
+    unsigned long long t_begin = clock64(), wsum = 0;
+#endif
+    // j_lo(i) = min(first j with xs[j] - xs[i] < 300, max(0, i - 20)); xs is non-increasing -> binary search
+    for (u32 i = tid; i < m; i += NT) {
+        u32 lim = xs[i] + 300;
+        u32 lo = 0, hi = i;   // first j in [0,i] with xs[j] < lim (j = i always qualifies)
+        while (lo < hi) { u32 mid = (lo + hi) >> 1; if (xs[mid] < lim) hi = mid; else lo = mid + 1; }
+        int js = (int)i - 20 < 0 ? 0 : (int)i - 20;
+        jlo[i] = (int)lo < js ? (int)lo : js;
+    }
+    __syncthreads();
+    for (u32 t0 = 0; t0 < m; t0 += DP_TILE) {
+        u32 tn = m - t0 < DP_TILE ? m - t0 : DP_TILE;
+        if (tid < (int)tn) { tx[tid] = xs[t0 + tid]; ty[tid] = ys[t0 + tid]; tjlo[tid] = jlo[t0 + tid]; }
         __syncthreads();
-        if (tid == 0) {
-            i64 b = s_best[0];
-            for (int w = 1; w < 16; w++) b = s_best[w] > b ? s_best[w] : b;
-            if (b >= 0) {
-                int tot = (int)(b >> 32);
-                int mj = 0x7fffffff - (int)(u32)(b & 0xffffffff);
-                r.p2[i] = mj; r.score[i] = tot; r.len[i] = r.len[mj] + 1; r.score2[i] = tot;
-                r.root[i] = r.root[mj]; r.leaf[i] = 1; r.leaf[mj] = 0;
-            } else {
-                r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = (i32)i; r.leaf[i] = 1;
+        // ---- phase A: predecessors before the tile
+        for (u32 k = wave; k < tn; k += NW) {
+            u32 xi = tx[k], yi = ty[k];
+            int jl = tjlo[k];
+            i64 best = -1;
+            for (int jj = (int)t0 - 1 - lane; jj >= jl; jj -= 64) {
+                int sc = score_type ? chain_score0(xs[jj], ys[jj], xi, yi) : chain_score(xs[jj], ys[jj], xi, yi);
+                if (sc > 0) { i64 key = ((i64)(sc + r.score[jj]) << 32) | (i64)(u32)(0x7fffffff - jj); best = key > best ? key : best; }
+            }
+            best = wave_max_i64(best);
+            if (lane == 0) {
+                tkey[k] = best;
+                if (best >= 0) { int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff); talen[k] = r.len[mj]; taroot[k] = r.root[mj]; }
             }
         }
         __syncthreads();
+        // ---- phase B: in-tile dependencies, wave 0, LDS only
+        if (wave == 0) {
+            for (u32 k = 0; k < tn; k++) {
+                u32 xi = tx[k], yi = ty[k];
+                int jl = tjlo[k];
+                i64 best = -1;
+                if ((u32)lane < k && (int)(t0 + lane) >= jl) {
+                    int sc = score_type ? chain_score0(tx[lane], ty[lane], xi, yi) : chain_score(tx[lane], ty[lane], xi, yi);
+                    if (sc > 0) best = ((i64)(sc + ts[lane]) << 32) | (i64)(u32)(0x7fffffff - (int)(t0 + lane));
+                }
+                best = wave_max_i64(best);
+                if (lane == 0) {
+                    i64 ka = tkey[k];
+                    u32 i = t0 + k;
+                    if (ka > best) {   // the before-tile candidate wins (keys are distinct: they encode j)
+                        int mj = 0x7fffffff - (int)(u32)(ka & 0xffffffff);
+                        ts[k] = (int)(ka >> 32); tlen[k] = talen[k] + 1; troot[k] = taroot[k];
+                        r.p2[i] = mj; r.leaf[i] = 1; r.leaf[mj] = 0;
+                    } else if (best >= 0) {
+                        int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff);
+                        int l = mj - (int)t0;
+                        ts[k] = (int)(best >> 32); tlen[k] = tlen[l] + 1; troot[k] = troot[l];
+                        r.p2[i] = mj; r.leaf[i] = 1; r.leaf[mj] = 0;
+                    } else {
+                        ts[k] = 0; tlen[k] = 1; troot[k] = (i32)i;
+                        r.p2[i] = -1; r.leaf[i] = 1;
+                    }
+                }
+                __threadfence_block();   // LDS/global stores of the leader ordered before the next step's loads (one wave)
+            }
+            if ((u32)lane < tn) { u32 i = t0 + lane; i32 v = ts[lane]; r.score[i] = v; r.score2[i] = v; r.len[i] = tlen[lane]; r.root[i] = troot[lane]; }
+        }
+#ifdef LNR_PROF
+        if (tid == 0) for (u32 k = 0; k < tn; k++) wsum += (unsigned long long)((int)(t0 + k) - tjlo[k]);
+#endif
+        __syncthreads();
     }
+#ifdef LNR_PROF
+    if (tid == 0 && A.prof) {
+        unsigned long long dt = clock64() - t_begin;
+        unsigned long long old = atomicMax(&A.prof[12], dt);
+        if (dt > old) { A.prof[13] = m; A.prof[14] = wsum; A.prof[15] = n; }   // (racy, diagnostic only)
+        atomicAdd(&A.prof[11], wsum);
+    }
+#endif
 }
 
 // =================================================================== tails ====

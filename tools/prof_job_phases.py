@@ -28,3 +28,4 @@ print("stats", f.stats())
 for i, nm in enumerate(names):
     print(f"{nm:45s} {out[i] / 1e6:12.1f} Mcycles  {100.0 * out[i] / max(tot, 1):5.1f} %   max single job-phase {out[16 + i] / 1e6:9.2f} Mcycles")
 print("cycles per job (lane 0 sum):", tot / max(f.stats()['jobs'], 1))
+print(f"k_dp_big: slowest block {out[12] / 1e6:.1f} Mcycles, its m = {out[13]}, its sum of windows = {out[14]} (avg window {out[14] / max(out[13], 1):.0f}), n after binning = {out[15]}; sum of windows over all heavy jobs = {out[11]}")
