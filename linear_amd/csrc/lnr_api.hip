@@ -61,8 +61,9 @@ struct lnr_ctx {
     std::vector<u64> seq_len, seq_off, f2_off;
     u32 nbins = 0;
     size_t job_lds_bytes = 8 * 1024;    // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
-    u32 heavy_cap = 4096;               // jobs with at least this many bucket entries take the heavy path (LNR_HEAVY_CAP overrides)
-    u32 dp_lds_kb = 0;                  // LDS-resident DP state in k_dp_big (LNR_DP_LDS_KB; 0 = global arrays)
+    size_t job_stage_bytes = 0;         // LDS stage of the blocked DP's predecessor window in the fused k_job (LNR_JOB_STAGE_KB; measured slower, off)
+    u32 dp_stage_kb = 0;                // same for k_dp_big (LNR_DP_STAGE_KB)
+    u32 heavy_cap = 8192;               // jobs with at least this many bucket entries take the heavy path (LNR_HEAVY_CAP overrides)
     hipStream_t stream2 = nullptr;      // heavy path runs here, concurrently with the fused k_job
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off;
@@ -287,11 +288,11 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             if (!ctx->prof.p) { if (!ctx->prof.ensure(32 * 8)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->prof.p, 0, 32 * 8, ctx->stream); }
             A.prof = ctx->prof.as<unsigned long long>();
 #endif
-            size_t lds = std::max<size_t>((size_t)((ctx->nbins + 1) / 2) * 4, ctx->job_lds_bytes);
-            lds = (lds + 15) & ~(size_t)15;
             size_t lds_min = (((size_t)((ctx->nbins + 1) / 2) * 4) + 15) & ~(size_t)15;
+            size_t arena = (ctx->job_lds_bytes + 15) & ~(size_t)15;
+            size_t lds = std::max<size_t>(lds_min, arena + ctx->job_stage_bytes);
             A.lds_bytes = (u32)lds;
-            A.arena_lds = (u32)lds;
+            A.arena_lds = (u32)arena;
             A.phase = 0;
             ENSURE(ctx->j_nbin, (size_t)nj * 4);
             ENSURE(ctx->j_m, (size_t)nj * 4);
@@ -317,7 +318,8 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
                 H.phase = 1;
                 hipLaunchKernelGGL(k_job, dim3(gh - g0), dim3(64), H.lds_bytes, ctx->stream2, H);
                 KCHECK();
-                hipLaunchKernelGGL(k_dp_big<1024>, dim3((u32)hjobs.size()), dim3(1024), 0, ctx->stream2, H, ctx->heavy_jobs.as<u32>(), (u32)hjobs.size(), 0u);
+                const u32 stage_bytes = ctx->dp_stage_kb * 1024;   // LDS stage of the tile's predecessor window (20 B per anchor)
+                hipLaunchKernelGGL(k_dp_big<1024>, dim3((u32)hjobs.size()), dim3(1024), stage_bytes, ctx->stream2, H, ctx->heavy_jobs.as<u32>(), (u32)hjobs.size(), stage_bytes);
                 KCHECK();
                 H.phase = 2;
                 hipLaunchKernelGGL(k_job, dim3(gh - g0), dim3(64), H.lds_bytes, ctx->stream2, H);
@@ -648,8 +650,9 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     ctx->device = dev;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }
+    if (const char *e = getenv("LNR_JOB_STAGE_KB")) { long kb = atol(e); if (kb >= 0 && kb <= 60) ctx->job_stage_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_HEAVY_CAP")) { long v = atol(e); if (v >= 64) ctx->heavy_cap = (u32)v; }
-    if (const char *e = getenv("LNR_DP_LDS_KB")) { long v = atol(e); if (v >= 0 && v <= 63) ctx->dp_lds_kb = (u32)v; }
+    if (const char *e = getenv("LNR_DP_STAGE_KB")) { long v = atol(e); if (v >= 0 && v <= 60) ctx->dp_stage_kb = (u32)v; }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     ctx->t_prep.init(); ctx->t_sc.init(); ctx->t_sg.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();

@@ -591,75 +591,126 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
     __syncthreads();
 }
 
-// wave-parallel twin of best_chains_serial (getBestChains, cluster_util.cpp:53-111): serial over i, lanes over
-// the predecessor window, max-reduce with "smallest j wins among equal totals".
-// Exact pruning for long windows: a pair score never exceeds 100 (cluster_util.cpp:435-441), so a 64-anchor chunk
-// whose best chain score + 100 is below the best total found among the nearest 128 predecessors cannot win or tie;
-// a chunk whose largest y is below y_i + dy_min has no admissible predecessor at all.  cmax / cymax hold those
-// per-chunk maxima (chunk = index >> 6).
-__device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type, i32 *cmax, u32 *cymax) {
-    int lane = lane_id();
-    u32 nchunk = (m + 63) >> 6;
-    for (u32 c = lane; c < nchunk; c += 64) cmax[c] = 0;
-    for (u32 c = 0; c < nchunk; c++) {   // per-chunk max y
-        u32 j = c * 64 + lane;
-        u32 y = j < m ? ys[j] : 0;
-        for (int o = 32; o > 0; o >>= 1) { u32 t = __shfl_xor(y, o); y = t > y ? t : y; }
-        if (lane == 0) cymax[c] = y;
+// ---- blocked chaining DP (getBestChains, cluster_util.cpp:53-111) ------------------------------------------
+// The recurrence is serial in i only through predecessors a short distance back, so anchors are processed in tiles
+// of 64:
+//   phase A (no dependencies): for every anchor of the tile, the best (total, smallest j) over its predecessors that
+//            lie BEFORE the tile -- their chain scores are final;
+//   phase B (one wave, LDS only): the anchors of the tile in order, lanes over the in-tile predecessors, merged with
+//            the phase-A candidate under the same key (max total, ties -> smallest j);
+//   flush : the tile's score/len/root/p2/leaf go to the job's arrays once.
+// Window bounds j_lo(i) depend on x only (dp_window_bounds).
+#define DP_TILE 64
+struct DpTile {
+    u32 tx[DP_TILE], ty[DP_TILE];
+    i32 ts[DP_TILE], tlen[DP_TILE], troot[DP_TILE], tjlo[DP_TILE], tp2[DP_TILE], tleaf[DP_TILE];
+    long long tkey[DP_TILE];
+    i32 talen[DP_TILE], taroot[DP_TILE];   // len / root of the phase-A candidate (prefetched)
+};
+// j_lo(i) = min(first j with xs[j] - xs[i] < 300, max(0, i - 20)); xs is non-increasing -> binary search
+__device__ __forceinline__ void dp_window_bounds(const u32 *xs, u32 m, i32 *jlo, int tid, int nthreads) {
+    for (u32 i = tid; i < m; i += nthreads) {
+        u32 lim = xs[i] + 300;
+        u32 lo = 0, hi = i;
+        while (lo < hi) { u32 mid = (lo + hi) >> 1; if (xs[mid] < lim) hi = mid; else lo = mid + 1; }
+        int js = (int)i - 20 < 0 ? 0 : (int)i - 20;
+        jlo[i] = (int)lo < js ? (int)lo : js;
     }
-    __syncthreads();
-    const u32 dy_min = score_type ? 5u : 10u;
-    u32 p300 = 0;
-    for (u32 i = 0; i < m; i++) {
-        u32 xi = xs[i], yi = ys[i];
-        int j_str = (int)i - 20 < 0 ? 0 : (int)i - 20;
-        while (p300 < i && xs[p300] - xi >= 300) p300++;
-        int j_lo = (int)p300 < j_str ? (int)p300 : j_str;
-        i64 best = -1;
-        int near_lo = (int)i - 128 > j_lo ? (int)i - 128 : j_lo;
-        for (int jb = (int)i - 1; jb >= near_lo; jb -= 64) {
-            int j = jb - lane;
-            if (j >= near_lo) {
-                int sc = score_type ? chain_score0(xs[j], ys[j], xi, yi) : chain_score(xs[j], ys[j], xi, yi);
-                if (sc > 0) { i64 key = ((i64)(sc + r.score[j]) << 32) | (i64)(u32)(0x7fffffff - j); best = key > best ? key : best; }
-            }
+}
+__device__ __forceinline__ i64 dp_key(int total, int j) { return ((i64)total << 32) | (i64)(u32)(0x7fffffff - j); }
+// Staged predecessor range of a tile.  j_lo is non-decreasing in i, so the union of the tile's windows is the
+// contiguous range [tjlo[0], t0); its x / y / score / len / root are copied to LDS once per tile (coalesced) and
+// phase A reads only LDS.  Entries below st0 (window longer than the stage) are read from the global arrays.
+struct DpStage { u32 *x, *y; i32 *sc, *len, *root; u32 cap; int st0; };
+__device__ __forceinline__ void dp_stage_carve(DpStage &G, u32 *lds, u32 bytes) {
+    G.cap = bytes / 20;
+    G.x = lds; G.y = lds + G.cap; G.sc = (i32 *)(lds + 2 * (size_t)G.cap); G.len = (i32 *)(lds + 3 * (size_t)G.cap); G.root = (i32 *)(lds + 4 * (size_t)G.cap);
+    G.st0 = 0;
+}
+__device__ __forceinline__ void dp_stage_load(DpStage &G, int rlo, u32 t0, const u32 *xs, const u32 *ys, const Rec &r, int tid, int nthreads) {
+    int st0 = (int)t0 - (int)G.cap;
+    if (st0 < rlo) st0 = rlo;
+    G.st0 = st0;
+    for (int jj = st0 + tid; jj < (int)t0; jj += nthreads) {
+        int o = jj - st0;
+        G.x[o] = xs[jj]; G.y[o] = ys[jj]; G.sc[o] = r.score[jj]; G.len[o] = r.len[jj]; G.root[o] = r.root[jj];
+    }
+}
+// phase A for tile anchor k by one wave
+__device__ __forceinline__ void dp_phase_a(DpTile &T, const DpStage &G, u32 k, u32 t0, const u32 *xs, const u32 *ys, const Rec &r, int score_type, int lane) {
+    u32 xi = T.tx[k], yi = T.ty[k];
+    int jl = T.tjlo[k];
+    i64 best = -1;
+    int jstage = jl > G.st0 ? jl : G.st0;
+    for (int jj = (int)t0 - 1 - lane; jj >= jstage; jj -= 64) {
+        int o = jj - G.st0;
+        int sc = score_type ? chain_score0(G.x[o], G.y[o], xi, yi) : chain_score(G.x[o], G.y[o], xi, yi);
+        if (sc > 0) { i64 key = dp_key(sc + G.sc[o], jj); best = key > best ? key : best; }
+    }
+    for (int jj = G.st0 - 1 - lane; jj >= jl; jj -= 64) {   // rare: part of the window below the stage
+        int sc = score_type ? chain_score0(xs[jj], ys[jj], xi, yi) : chain_score(xs[jj], ys[jj], xi, yi);
+        if (sc > 0) { i64 key = dp_key(sc + r.score[jj], jj); best = key > best ? key : best; }
+    }
+    best = wave_max_i64(best);
+    if (lane == 0) {
+        T.tkey[k] = best;
+        if (best >= 0) {
+            int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff);
+            if (mj >= G.st0) { T.talen[k] = G.len[mj - G.st0]; T.taroot[k] = G.root[mj - G.st0]; }
+            else { T.talen[k] = r.len[mj]; T.taroot[k] = r.root[mj]; }
         }
-        if (near_lo > j_lo) {
-            // far part [j_lo, near_lo): visit only the chunks that can still matter
-            i64 bw = wave_max_i64(best);
-            int bt = bw >= 0 ? (int)(bw >> 32) : -1;
-            int far_hi = near_lo - 1;
-            int c_lo = j_lo >> 6, c_hi = far_hi >> 6;
-            for (int cb = c_hi; cb >= c_lo; cb -= 64) {
-                int c = cb - lane;
-                bool cand = c >= c_lo && cmax[c] + 100 >= bt && cymax[c] >= yi + dy_min;
-                u64 mask = __ballot(cand);
-                while (mask) {
-                    int l = __builtin_ctzll(mask);   // lane l holds chunk cb - l: nearest remaining chunk first
-                    mask &= mask - 1;
-                    int cc = cb - l;
-                    int j = cc * 64 + lane;
-                    if (j >= j_lo && j <= far_hi) {
-                        int sc = score_type ? chain_score0(xs[j], ys[j], xi, yi) : chain_score(xs[j], ys[j], xi, yi);
-                        if (sc > 0) { i64 key = ((i64)(sc + r.score[j]) << 32) | (i64)(u32)(0x7fffffff - j); best = key > best ? key : best; }
-                    }
-                }
-            }
+    }
+}
+// phase B + flush by one wave; before-tile leaf clears are plain global stores nobody reads during the DP
+__device__ __forceinline__ void dp_phase_b_flush(DpTile &T, u32 tn, u32 t0, Rec &r, int score_type, int lane) {
+    if ((u32)lane < tn) T.tleaf[lane] = 1;
+    for (u32 k = 0; k < tn; k++) {
+        u32 xi = T.tx[k], yi = T.ty[k];
+        int jl = T.tjlo[k];
+        i64 best = -1;
+        if ((u32)lane < k && (int)(t0 + lane) >= jl) {
+            int sc = score_type ? chain_score0(T.tx[lane], T.ty[lane], xi, yi) : chain_score(T.tx[lane], T.ty[lane], xi, yi);
+            if (sc > 0) best = dp_key(sc + T.ts[lane], (int)(t0 + lane));
         }
         best = wave_max_i64(best);
         if (lane == 0) {
-            int tot;
-            if (best >= 0) {
-                tot = (int)(best >> 32);
+            i64 ka = T.tkey[k];
+            if (ka > best) {   // the before-tile candidate wins (keys are distinct: they encode j)
+                int mj = 0x7fffffff - (int)(u32)(ka & 0xffffffff);
+                T.ts[k] = (int)(ka >> 32); T.tlen[k] = T.talen[k] + 1; T.troot[k] = T.taroot[k]; T.tp2[k] = mj;
+                r.leaf[mj] = 0;
+            } else if (best >= 0) {
                 int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff);
-                r.p2[i] = mj; r.score[i] = tot; r.len[i] = r.len[mj] + 1; r.score2[i] = tot;
-                r.root[i] = r.root[mj]; r.leaf[i] = 1; r.leaf[mj] = 0;
+                int l = mj - (int)t0;
+                T.ts[k] = (int)(best >> 32); T.tlen[k] = T.tlen[l] + 1; T.troot[k] = T.troot[l]; T.tp2[k] = mj;
+                T.tleaf[l] = 0;
             } else {
-                tot = 0;
-                r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = (i32)i; r.leaf[i] = 1;
+                T.ts[k] = 0; T.tlen[k] = 1; T.troot[k] = (i32)(t0 + k); T.tp2[k] = -1;
             }
-            if (tot > cmax[i >> 6]) cmax[i >> 6] = tot;
         }
+        __builtin_amdgcn_wave_barrier();   // LDS is in-order per wave: later lanes' reads see the leader's writes
+    }
+    if ((u32)lane < tn) {
+        u32 i = t0 + lane;
+        i32 v = T.ts[lane];
+        r.score[i] = v; r.score2[i] = v; r.len[i] = T.tlen[lane]; r.root[i] = T.troot[lane]; r.p2[i] = T.tp2[lane]; r.leaf[i] = T.tleaf[lane];
+    }
+}
+// one-wave driver (fused k_job)
+__device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type, i32 *jlo, DpTile &T, u32 *stage_lds, u32 stage_bytes) {
+    int lane = lane_id();
+    DpStage G;
+    dp_stage_carve(G, stage_lds, stage_bytes);
+    dp_window_bounds(xs, m, jlo, lane, 64);
+    __syncthreads();
+    for (u32 t0 = 0; t0 < m; t0 += DP_TILE) {
+        u32 tn = m - t0 < DP_TILE ? m - t0 : DP_TILE;
+        if ((u32)lane < tn) { T.tx[lane] = xs[t0 + lane]; T.ty[lane] = ys[t0 + lane]; T.tjlo[lane] = jlo[t0 + lane]; }
+        dp_stage_load(G, jlo[t0], t0, xs, ys, r, lane, 64);
+        __syncthreads();
+        for (u32 k = 0; k < tn; k++) dp_phase_a(T, G, k, t0, xs, ys, r, score_type, lane);
+        __syncthreads();
+        dp_phase_b_flush(T, tn, t0, r, score_type, lane);
         __syncthreads();
     }
 }
@@ -720,6 +771,7 @@ __global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
     __shared__ u64 *s_H;
     __shared__ u32 s_nH;
     __shared__ LeaderScratch s_ls;   // introsort stack + tree table: one per wave, in LDS
+    __shared__ DpTile s_tile;        // tile state of the blocked chaining DP
     if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
     u32 grp = A.grp_order[A.grp_lo + blockIdx.x];
     int lane = lane_id();
@@ -791,10 +843,11 @@ __global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
             continue;
         }
         if (m >= 2 && A.phase == 0) {
-            u32 nchunk = (m + 63) >> 6;
-            i32 *cmax = ar.get<i32>(nchunk + 1);
-            u32 *cymax = ar.get<u32>(nchunk + 1);
-            best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, cmax, cymax);
+            // stage region of the blocked DP: what is left of the dynamic LDS behind the arena's fast half
+            u32 used = (u32)((ar.off + 15) & ~15ULL);
+            u32 *stage = (u32 *)((char *)dyn_lds + used);
+            u32 stage_bytes = A.lds_bytes > used ? A.lds_bytes - used : 0;
+            best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, S.cnt, s_tile, stage, stage_bytes);
         }
         LNR_TICK(prof, 4, tk_);
         // traceback of the anchor chains -> hits (the leader owns S.hits / S.hscore from here on)
@@ -838,23 +891,12 @@ __global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
     if (lane == 0) { A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
 }
 
-// Heavy path, middle kernel: the chaining DP (getBestChains, cluster_util.cpp:53-111) of one large job, blocked.
-// The recurrence is serial in i only through predecessors inside a short distance, so anchors are processed in
-// tiles of 64:
-//   phase A (16 waves, no dependencies): for every anchor of the tile, the best (total, smallest j) over its
-//            predecessors that lie BEFORE the tile -- their chain scores are final;
-//   phase B (wave 0, all state in LDS): the 64 anchors in order, lanes over the in-tile predecessors, merged with the
-//            phase-A candidate under the same key (max total, ties -> smallest j).
-// Per-anchor cost drops from a chain of dependent global loads plus two block barriers to ~1/64 of two barriers
-// plus one LDS round.  Window bounds j_lo(i) depend on x only and are precomputed for the whole job.
-#define DP_TILE 64
+// Heavy path, middle kernel: the blocked chaining DP of one large job with 16 waves (phase A spread over the
+// waves, phase B + flush on wave 0).  Pointers are recovered by replaying the job's (global-only) arena allocations.
 template <int NT>
-__global__ void __launch_bounds__(NT) k_dp_big(JobArgs A, const u32 *jobs, u32 njobs, u32 unused_) {
-    __shared__ u32 tx[DP_TILE], ty[DP_TILE];
-    __shared__ i32 ts[DP_TILE], tlen[DP_TILE], troot[DP_TILE], tjlo[DP_TILE];
-    __shared__ long long tkey[DP_TILE];
-    __shared__ i32 talen[DP_TILE], taroot[DP_TILE];   // len / root of the phase-A candidate (prefetched)
-    (void)unused_;
+__global__ void __launch_bounds__(NT) k_dp_big(JobArgs A, const u32 *jobs, u32 njobs, u32 stage_bytes) {
+    extern __shared__ u32 dp_dyn_lds[];
+    __shared__ DpTile T;
     if (blockIdx.x >= njobs) return;
     u32 j = jobs[blockIdx.x];
     u32 n = A.job_nbin[j], m = A.job_m[j];
@@ -875,69 +917,20 @@ __global__ void __launch_bounds__(NT) k_dp_big(JobArgs A, const u32 *jobs, u32 n
 #ifdef LNR_PROF
     unsigned long long t_begin = clock64(), wsum = 0;
 #endif
-    // j_lo(i) = min(first j with xs[j] - xs[i] < 300, max(0, i - 20)); xs is non-increasing -> binary search
-    for (u32 i = tid; i < m; i += NT) {
-        u32 lim = xs[i] + 300;
-        u32 lo = 0, hi = i;   // first j in [0,i] with xs[j] < lim (j = i always qualifies)
-        while (lo < hi) { u32 mid = (lo + hi) >> 1; if (xs[mid] < lim) hi = mid; else lo = mid + 1; }
-        int js = (int)i - 20 < 0 ? 0 : (int)i - 20;
-        jlo[i] = (int)lo < js ? (int)lo : js;
-    }
+    DpStage G;
+    dp_stage_carve(G, dp_dyn_lds, stage_bytes);
+    dp_window_bounds(xs, m, jlo, tid, NT);
     __syncthreads();
     for (u32 t0 = 0; t0 < m; t0 += DP_TILE) {
         u32 tn = m - t0 < DP_TILE ? m - t0 : DP_TILE;
-        if (tid < (int)tn) { tx[tid] = xs[t0 + tid]; ty[tid] = ys[t0 + tid]; tjlo[tid] = jlo[t0 + tid]; }
+        if (tid < (int)tn) { T.tx[tid] = xs[t0 + tid]; T.ty[tid] = ys[t0 + tid]; T.tjlo[tid] = jlo[t0 + tid]; }
+        dp_stage_load(G, jlo[t0], t0, xs, ys, r, tid, NT);
         __syncthreads();
-        // ---- phase A: predecessors before the tile
-        for (u32 k = wave; k < tn; k += NW) {
-            u32 xi = tx[k], yi = ty[k];
-            int jl = tjlo[k];
-            i64 best = -1;
-            for (int jj = (int)t0 - 1 - lane; jj >= jl; jj -= 64) {
-                int sc = score_type ? chain_score0(xs[jj], ys[jj], xi, yi) : chain_score(xs[jj], ys[jj], xi, yi);
-                if (sc > 0) { i64 key = ((i64)(sc + r.score[jj]) << 32) | (i64)(u32)(0x7fffffff - jj); best = key > best ? key : best; }
-            }
-            best = wave_max_i64(best);
-            if (lane == 0) {
-                tkey[k] = best;
-                if (best >= 0) { int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff); talen[k] = r.len[mj]; taroot[k] = r.root[mj]; }
-            }
-        }
+        for (u32 k = wave; k < tn; k += NW) dp_phase_a(T, G, k, t0, xs, ys, r, score_type, lane);
         __syncthreads();
-        // ---- phase B: in-tile dependencies, wave 0, LDS only
-        if (wave == 0) {
-            for (u32 k = 0; k < tn; k++) {
-                u32 xi = tx[k], yi = ty[k];
-                int jl = tjlo[k];
-                i64 best = -1;
-                if ((u32)lane < k && (int)(t0 + lane) >= jl) {
-                    int sc = score_type ? chain_score0(tx[lane], ty[lane], xi, yi) : chain_score(tx[lane], ty[lane], xi, yi);
-                    if (sc > 0) best = ((i64)(sc + ts[lane]) << 32) | (i64)(u32)(0x7fffffff - (int)(t0 + lane));
-                }
-                best = wave_max_i64(best);
-                if (lane == 0) {
-                    i64 ka = tkey[k];
-                    u32 i = t0 + k;
-                    if (ka > best) {   // the before-tile candidate wins (keys are distinct: they encode j)
-                        int mj = 0x7fffffff - (int)(u32)(ka & 0xffffffff);
-                        ts[k] = (int)(ka >> 32); tlen[k] = talen[k] + 1; troot[k] = taroot[k];
-                        r.p2[i] = mj; r.leaf[i] = 1; r.leaf[mj] = 0;
-                    } else if (best >= 0) {
-                        int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff);
-                        int l = mj - (int)t0;
-                        ts[k] = (int)(best >> 32); tlen[k] = tlen[l] + 1; troot[k] = troot[l];
-                        r.p2[i] = mj; r.leaf[i] = 1; r.leaf[mj] = 0;
-                    } else {
-                        ts[k] = 0; tlen[k] = 1; troot[k] = (i32)i;
-                        r.p2[i] = -1; r.leaf[i] = 1;
-                    }
-                }
-                __threadfence_block();   // LDS/global stores of the leader ordered before the next step's loads (one wave)
-            }
-            if ((u32)lane < tn) { u32 i = t0 + lane; i32 v = ts[lane]; r.score[i] = v; r.score2[i] = v; r.len[i] = tlen[lane]; r.root[i] = troot[lane]; }
-        }
+        if (wave == 0) dp_phase_b_flush(T, tn, t0, r, score_type, lane);
 #ifdef LNR_PROF
-        if (tid == 0) for (u32 k = 0; k < tn; k++) wsum += (unsigned long long)((int)(t0 + k) - tjlo[k]);
+        if (tid == 0) for (u32 k = 0; k < tn; k++) wsum += (unsigned long long)((int)(t0 + k) - T.tjlo[k]);
 #endif
         __syncthreads();
     }
