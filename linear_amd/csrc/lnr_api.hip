@@ -66,15 +66,16 @@ struct lnr_ctx {
     u32 heavy_cap = 8192;               // jobs with at least this many bucket entries take the heavy path (LNR_HEAVY_CAP overrides)
     hipStream_t stream2 = nullptr;      // heavy path runs here, concurrently with the fused k_job
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    DevBuf g, dir, hs, f2, d_seq_off, d_f2_off;
+    DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm;   // bm: bucket-non-empty bitmap (derived from dir)
     // ---- batch inputs / per-read arrays
     DevBuf in_reads, in_off;                       // staging for the host-buffer entry points
-    DevBuf reads_p, rp_off, lpad, rlen, rks, nf, f1_off, f1;
+    DevBuf reads_p, rp_off, lpad, rlen, rks, nf, f1_off, f1, pk, nm, pk_off;
     DevBuf cords, out_str, out_end, cords_off, cords_cap, ncords, nout, read_err;
     DevBuf tail_scr, tail_off, tail_cap, gaps, gaps_off, gaps_cap, ngaps, remap;
     // ---- jobs
-    DevBuf j_read, j_str, j_end, j_mode, j_samp_off, j_cap, j_look, j_anc_off, j_scr_off, j_nanc, grp_beg, grp_order, job_list;
-    DevBuf samp, anchors, job_scr, prof, j_nbin, j_m, heavy_jobs;
+    DevBuf j_read, j_str, j_end, j_mode, j_cap, j_look, j_anc_off, j_scr_off, j_nanc, grp_beg, grp_order, job_list;
+    DevBuf anchors, job_scr, prof, j_nbin, j_m, heavy_jobs, seed_ctl;   // seed_ctl: allocator cursor + overflow flag
+    u64 anc_slots_per_job = 1536;       // running estimate of anchor slots per job (grows on overflow)
     // ---- results
     DevBuf r_off, r_str, r_end;
     std::vector<u64> h_cord_off, h_cords_str, h_cords_end, h_anchor_off, h_anchors;
@@ -156,11 +157,9 @@ lnr_status upload_index_layout(lnr_ctx *ctx) {
 // ------------------------------------------------------------------ jobs ----
 struct HostJobs {
     std::vector<u32> read, str, end, mode, grp_beg;
-    std::vector<u64> samp_off;
     u64 nsamp = 0;
     void add(u32 r, u32 s, u32 e, u32 m) {
         read.push_back(r); str.push_back(s); end.push_back(e); mode.push_back(m);
-        samp_off.push_back(nsamp);
         nsamp += seed_num_samples(s, e, (u32)job_parm((int)m).alpha);
     }
     u32 size() const { return (u32)read.size(); }
@@ -170,18 +169,18 @@ struct BatchHost {
     u32 n = 0;
     std::vector<u64> off;
     std::vector<u32> len, lpad, nf, cords_cap, gaps_cap;
-    std::vector<u64> rp_off, f1_off, cords_off, gaps_off;
+    std::vector<u64> rp_off, f1_off, cords_off, gaps_off, pk_off;
 };
 
 JobArrays job_arrays(lnr_ctx *ctx) {
     JobArrays J;
     J.read = ctx->j_read.as<u32>(); J.str = ctx->j_str.as<u32>(); J.end = ctx->j_end.as<u32>(); J.mode = ctx->j_mode.as<u32>();
-    J.samp_off = ctx->j_samp_off.as<u64>();
     return J;
 }
 ReadArrays read_arrays(lnr_ctx *ctx) {
     ReadArrays R;
     R.bases = ctx->reads_p.as<u8>(); R.rp_off = ctx->rp_off.as<u64>(); R.lpad = ctx->lpad.as<u32>(); R.len = ctx->rlen.as<u32>(); R.ks = ctx->rks.as<i32>();
+    R.pk = ctx->pk.as<u64>(); R.nm = ctx->nm.as<u32>(); R.pk_off = ctx->pk_off.as<u64>();
     return R;
 }
 
@@ -195,27 +194,60 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
     if ((s = upload(ctx, ctx->j_str, hj.str)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->j_end, hj.end)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->j_mode, hj.mode)) != LNR_OK) return s;
-    if ((s = upload(ctx, ctx->j_samp_off, hj.samp_off)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->grp_beg, hj.grp_beg)) != LNR_OK) return s;
-    ENSURE(ctx->samp, std::max<size_t>(hj.nsamp * sizeof(SampRec), 16));
     ENSURE(ctx->j_cap, (size_t)nj * 4);
     ENSURE(ctx->j_look, (size_t)nj * 4);
     ENSURE(ctx->j_nanc, (size_t)nj * 4);
+    ENSURE(ctx->j_anc_off, (size_t)nj * 8);
+    ENSURE(ctx->j_scr_off, (size_t)nj * 8);
+    ENSURE(ctx->seed_ctl, 64);
     JobArrays J = job_arrays(ctx);
     ReadArrays R = read_arrays(ctx);
-    ctx->t_sc.start(ctx->stream);
-    hipLaunchKernelGGL(k_seed_count, dim3(nj), dim3(64), 0, ctx->stream, J, R, ctx->dir.as<i32>(), nj, ctx->samp.as<SampRec>(), ctx->j_cap.as<u32>(), ctx->j_look.as<u32>());
-    KCHECK();
-    ctx->t_sc.stop(ctx->stream);
-    std::vector<u32> cap(nj), look(nj);
-    HIPCK(hipMemcpyAsync(cap.data(), ctx->j_cap.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCK(hipMemcpyAsync(look.data(), ctx->j_look.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCK(hipStreamSynchronize(ctx->stream));
-    ctx->stats.seed_count_ms += ctx->t_sc.ms();
-    ctx->stats.seed_count_launches++;
+    std::vector<u32> cap(nj), look(nj), nanc_all(nj);
+    std::vector<u64> anc_off(nj);
+    u64 anc_slots = std::max<u64>(ctx->anc_slots_per_job * nj, 1024);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        ENSURE(ctx->anchors, anc_slots * 8);
+        HIPCK(hipMemsetAsync(ctx->seed_ctl.p, 0, 64, ctx->stream));
+        SeedOutArrays O;
+        O.cursor = ctx->seed_ctl.as<unsigned long long>(); O.overflow = (int *)(ctx->seed_ctl.as<char>() + 16); O.capacity = anc_slots;
+        O.anchors = ctx->anchors.as<u64>(); O.anc_off = ctx->j_anc_off.as<u64>(); O.job_cap = ctx->j_cap.as<u32>(); O.job_look = ctx->j_look.as<u32>();
+        O.n_anchors = ctx->j_nanc.as<u32>();
+        ctx->t_sc.start(ctx->stream);
+        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, ctx->stream, J, R, ctx->dir.as<i32>(), ctx->bm.as<u32>(), ctx->hs.as<u64>(), nj, O);
+        KCHECK();
+        ctx->t_sc.stop(ctx->stream);
+        int ovf = 0;
+        HIPCK(hipMemcpyAsync(cap.data(), ctx->j_cap.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipMemcpyAsync(look.data(), ctx->j_look.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipMemcpyAsync(nanc_all.data(), ctx->j_nanc.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipMemcpyAsync(anc_off.data(), ctx->j_anc_off.p, (size_t)nj * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipMemcpyAsync(&ovf, ctx->seed_ctl.as<char>() + 16, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        ctx->stats.seed_count_ms += ctx->t_sc.ms();
+        ctx->stats.seed_count_launches++;
+        if (!ovf) break;
+        if (attempt == 1) { ctx->err = "anchor buffer overflow after resize"; return LNR_ERR_INTERNAL; }
+        u64 need = 0;
+        for (u32 j = 0; j < nj; j++) need += ((u64)cap[j] + 1) & ~1ULL;   // cap already includes the dummy
+        anc_slots = need + 1024;
+        ctx->anc_slots_per_job = std::max<u64>(ctx->anc_slots_per_job, (need / nj) * 5 / 4 + 64);
+    }
     ctx->stats.jobs += nj;
     ctx->stats.samples += hj.nsamp;
-    for (u32 j = 0; j < nj; j++) { ctx->stats.lookups += look[j]; ctx->stats.bucket_entries += cap[j] - 1; }
+    for (u32 j = 0; j < nj; j++) { ctx->stats.lookups += look[j]; ctx->stats.bucket_entries += cap[j] - 1; ctx->stats.anchors += nanc_all[j] - 1; }
+    if (keep_anchor_layout) {
+        // export CSR of the raw anchors to the host arrays
+        ctx->h_anchor_off.assign(nj + 1, 0);
+        for (u32 j = 0; j < nj; j++) ctx->h_anchor_off[j + 1] = ctx->h_anchor_off[j] + nanc_all[j];
+        ctx->h_anchors.resize(ctx->h_anchor_off[nj]);
+        u64 used = 0;
+        for (u32 j = 0; j < nj; j++) used = std::max<u64>(used, anc_off[j] + nanc_all[j]);
+        std::vector<u64> all(used);
+        if (used) HIPCK(hipMemcpy(all.data(), ctx->anchors.p, used * 8, hipMemcpyDeviceToHost));
+        for (u32 j = 0; j < nj; j++) memcpy(ctx->h_anchors.data() + ctx->h_anchor_off[j], all.data() + anc_off[j], (size_t)nanc_all[j] * 8);
+    }
+    if (!with_job_kernel) return LNR_OK;
 
     // launch order: heaviest group first (sum of bucket entries is the work proxy), so the long tail of
     // repeat-rich reads starts at once instead of at the end of the grid
@@ -240,39 +272,22 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
     if ((s = upload(ctx, ctx->grp_order, order)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->job_list, job_list)) != LNR_OK) return s;
     // slices of (ordered) groups under the scratch budget
-    std::vector<u64> anc_off(nj), scr_off(nj);
+    std::vector<u64> scr_off(nj);
     u32 g0 = 0;
     while (g0 < ngrp) {
-        u64 anc = 0, scr = 0;
+        u64 scr = 0;
         u32 g1 = g0;
         while (g1 < ngrp) {
-            u64 a2 = anc, s2 = scr;
-            for (u32 q = ord_job_beg[g1]; q < ord_job_beg[g1 + 1]; q++) {
-                u32 j = job_list[q];
-                a2 += align_up((u64)cap[j] + 2, 2);
-                if (with_job_kernel) s2 += align_up(job_scratch_bytes((u64)cap[j] + 2), 256);
-            }
-            if (g1 > g0 && a2 * 8 + s2 > budget) break;
-            anc = a2; scr = s2; g1++;
+            u64 s2 = scr;
+            for (u32 q = ord_job_beg[g1]; q < ord_job_beg[g1 + 1]; q++) s2 += align_up(job_scratch_bytes((u64)cap[job_list[q]] + 2), 256);
+            if (g1 > g0 && s2 > budget) break;
+            scr = s2; g1++;
         }
-        u64 ao = 0, so = 0;
+        u64 so = 0;
         u32 j0 = ord_job_beg[g0], j1 = ord_job_beg[g1];   // positions in job_list
-        for (u32 q = j0; q < j1; q++) {
-            u32 j = job_list[q];
-            anc_off[j] = ao; ao += align_up((u64)cap[j] + 2, 2);
-            scr_off[j] = so; if (with_job_kernel) so += align_up(job_scratch_bytes((u64)cap[j] + 2), 256);
-        }
-        ENSURE(ctx->anchors, std::max<u64>(ao * 8, 16));
-        if (with_job_kernel) ENSURE(ctx->job_scr, std::max<u64>(so, 16));
-        ENSURE(ctx->j_anc_off, (size_t)nj * 8);
-        ENSURE(ctx->j_scr_off, (size_t)nj * 8);
-        HIPCK(hipMemcpyAsync(ctx->j_anc_off.p, anc_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, ctx->stream));
+        for (u32 q = j0; q < j1; q++) { u32 j = job_list[q]; scr_off[j] = so; so += align_up(job_scratch_bytes((u64)cap[j] + 2), 256); }
+        ENSURE(ctx->job_scr, std::max<u64>(so, 16));
         HIPCK(hipMemcpyAsync(ctx->j_scr_off.p, scr_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, ctx->stream));
-        ctx->t_sg.start(ctx->stream);
-        hipLaunchKernelGGL(k_seed_gather, dim3(j1 - j0), dim3(64), 0, ctx->stream, J, R, ctx->hs.as<u64>(), ctx->job_list.as<u32>(), j0, j1, ctx->samp.as<SampRec>(),
-                           ctx->j_anc_off.as<u64>(), ctx->anchors.as<u64>(), ctx->j_nanc.as<u32>());
-        KCHECK();
-        ctx->t_sg.stop(ctx->stream);
         if (with_job_kernel) {
             JobArgs A;
             A.grp_order = ctx->grp_order.as<u32>(); A.grp_beg = ctx->grp_beg.as<u32>(); A.J = J;
@@ -334,25 +349,8 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             if (gh > g0) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             ctx->t_job.stop(ctx->stream);
         }
-        std::vector<u32> nanc_all(nj);
-        HIPCK(hipMemcpyAsync(nanc_all.data(), ctx->j_nanc.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCK(hipStreamSynchronize(ctx->stream));
-        std::vector<u32> nanc(j1 - j0);
-        for (u32 q = j0; q < j1; q++) nanc[q - j0] = nanc_all[job_list[q]];
-        ctx->stats.seed_gather_ms += ctx->t_sg.ms();
-        ctx->stats.seed_gather_launches++;
         if (with_job_kernel) { ctx->stats.job_ms += ctx->t_job.ms(); ctx->stats.job_launches++; }
-        for (u32 j = 0; j < j1 - j0; j++) ctx->stats.anchors += nanc[j] - 1;
-        if (keep_anchor_layout) {
-            if (g0 != 0 || g1 != ngrp) { ctx->err = "anchor export needs the batch to fit one slice; lower the read count"; return LNR_ERR_LIMIT; }
-            // export CSR of the raw anchors to the host arrays
-            ctx->h_anchor_off.assign(nj + 1, 0);
-            for (u32 j = 0; j < nj; j++) ctx->h_anchor_off[j + 1] = ctx->h_anchor_off[j] + nanc_all[j];
-            ctx->h_anchors.resize(ctx->h_anchor_off[nj]);
-            std::vector<u64> all(ao);
-            HIPCK(hipMemcpy(all.data(), ctx->anchors.p, ao * 8, hipMemcpyDeviceToHost));
-            for (u32 j = 0; j < nj; j++) memcpy(ctx->h_anchors.data() + ctx->h_anchor_off[j], all.data() + anc_off[j], (size_t)nanc_all[j] * 8);
-        }
         g0 = g1;
     }
     return LNR_OK;
@@ -365,8 +363,8 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     HIPCK(hipMemcpyAsync(B.off.data(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCK(hipStreamSynchronize(ctx->stream));
     B.len.resize(n); B.lpad.resize(n); B.nf.resize(n); B.cords_cap.resize(n); B.gaps_cap.resize(n);
-    B.rp_off.resize(n); B.f1_off.resize(n); B.cords_off.resize(n); B.gaps_off.resize(n);
-    u64 rp = 0, fo = 0, co = 0, go = 0;
+    B.rp_off.resize(n); B.f1_off.resize(n); B.cords_off.resize(n); B.gaps_off.resize(n); B.pk_off.resize(n);
+    u64 rp = 0, fo = 0, co = 0, go = 0, po = 0;
     for (u32 i = 0; i < n; i++) {
         if (B.off[i + 1] < B.off[i]) { ctx->err = "read offsets not monotone"; return LNR_ERR_ARG; }
         u64 L = B.off[i + 1] - B.off[i];
@@ -374,6 +372,7 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
         B.len[i] = (u32)L;
         B.lpad[i] = (u32)align_up(L + SEQ_PAD, 16);
         B.rp_off[i] = rp; rp += 2ULL * B.lpad[i];
+        B.pk_off[i] = po; po += packed_words(L);
         B.nf[i] = L > 200 ? read_feature_count(L) : 0;
         B.f1_off[i] = fo; fo += 2ULL * B.nf[i];
         B.cords_cap[i] = L > 200 ? (u32)(16 * (L / 64) + 256) : 0;
@@ -385,6 +384,9 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     if ((s = upload(ctx, ctx->rlen, B.len)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->lpad, B.lpad)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->rp_off, B.rp_off)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->pk_off, B.pk_off)) != LNR_OK) return s;
+    ENSURE(ctx->pk, std::max<u64>(po * 8, 16));
+    ENSURE(ctx->nm, std::max<u64>(po * 4, 16));
     if ((s = upload(ctx, ctx->nf, B.nf)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->f1_off, B.f1_off)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->cords_cap, B.cords_cap)) != LNR_OK) return s;
@@ -406,7 +408,8 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     HIPCK(hipMemsetAsync(ctx->ncords.p, 0, (size_t)n * 4, ctx->stream));
     HIPCK(hipMemsetAsync(ctx->read_err.p, 0, (size_t)n * 4, ctx->stream));
     ctx->t_prep.start(ctx->stream);
-    hipLaunchKernelGGL(k_prep, dim3(n), dim3(256), 0, ctx->stream, d_reads, d_off, ctx->rp_off.as<u64>(), ctx->lpad.as<u32>(), n, ctx->reads_p.as<u8>(), ctx->rks.as<i32>());
+    hipLaunchKernelGGL(k_prep, dim3(n), dim3(256), 0, ctx->stream, d_reads, d_off, ctx->rp_off.as<u64>(), ctx->lpad.as<u32>(), ctx->pk_off.as<u64>(), n, ctx->reads_p.as<u8>(),
+                       ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
     KCHECK();
     hipLaunchKernelGGL(k_f1, dim3(n), dim3(256), 0, ctx->stream, ctx->reads_p.as<u8>(), ctx->rp_off.as<u64>(), ctx->lpad.as<u32>(), ctx->nf.as<u32>(), ctx->f1_off.as<u64>(), n, ctx->f1.as<F96>());
     KCHECK();
@@ -664,11 +667,11 @@ void lnr_destroy(lnr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->g, &ctx->dir, &ctx->hs, &ctx->f2, &ctx->d_seq_off, &ctx->d_f2_off, &ctx->in_reads, &ctx->in_off, &ctx->reads_p, &ctx->rp_off,
+    DevBuf *bufs[] = {&ctx->g, &ctx->dir, &ctx->hs, &ctx->f2, &ctx->d_seq_off, &ctx->d_f2_off, &ctx->bm, &ctx->pk, &ctx->nm, &ctx->pk_off, &ctx->in_reads, &ctx->in_off, &ctx->reads_p, &ctx->rp_off,
                       &ctx->lpad, &ctx->rlen, &ctx->rks, &ctx->nf, &ctx->f1_off, &ctx->f1, &ctx->cords, &ctx->out_str, &ctx->out_end, &ctx->cords_off,
                       &ctx->cords_cap, &ctx->ncords, &ctx->nout, &ctx->read_err, &ctx->tail_scr, &ctx->tail_off, &ctx->tail_cap, &ctx->gaps, &ctx->gaps_off,
-                      &ctx->gaps_cap, &ctx->ngaps, &ctx->remap, &ctx->j_read, &ctx->j_str, &ctx->j_end, &ctx->j_mode, &ctx->j_samp_off, &ctx->j_cap,
-                      &ctx->j_look, &ctx->j_anc_off, &ctx->j_scr_off, &ctx->j_nanc, &ctx->grp_beg, &ctx->samp, &ctx->anchors, &ctx->job_scr, &ctx->r_off,
+                      &ctx->gaps_cap, &ctx->ngaps, &ctx->remap, &ctx->j_read, &ctx->j_str, &ctx->j_end, &ctx->j_mode, &ctx->j_cap,
+                      &ctx->j_look, &ctx->j_anc_off, &ctx->j_scr_off, &ctx->j_nanc, &ctx->grp_beg, &ctx->anchors, &ctx->job_scr, &ctx->r_off,
                       &ctx->r_str, &ctx->r_end};
     for (DevBuf *b : bufs) b->release();
     ctx->t_prep.destroy(); ctx->t_sc.destroy(); ctx->t_sg.destroy(); ctx->t_job.destroy(); ctx->t_tail.destroy(); ctx->t_total.destroy();
@@ -771,6 +774,13 @@ lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64
             IXHIP(hipGetLastError());
         }
     }
+    // bucket-non-empty bitmap for the seed kernel
+    {
+        u64 nb = dir_len - 1, nwords = (nb + 31) / 32;
+        ENSURE(ctx->bm, nwords * 4 + 16);
+        hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
+        IXHIP(hipGetLastError());
+    }
     // genome window features
     ENSURE(ctx->f2, std::max<u64>(ctx->info.f2_len * sizeof(F96), 16));
     if (ctx->info.f2_len) {
@@ -844,6 +854,12 @@ lnr_status lnr_index_blob(lnr_ctx *ctx, uint32_t which, void **d_ptr, uint64_t *
 lnr_status lnr_index_adopt(lnr_ctx *ctx) {
     if (!ctx) return LNR_ERR_ARG;
     if (!ctx->g.p || !ctx->dir.p || !ctx->hs.p || !ctx->f2.p) return LNR_ERR_NO_INDEX;
+    HIPCK(hipSetDevice(ctx->device));
+    u64 nb = ctx->info.dir_len - 1, nwords = (nb + 31) / 32;   // derived structure: rebuilt from the received dir
+    ENSURE(ctx->bm, nwords * 4 + 16);
+    hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
+    KCHECK();
+    HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->has_index = true;
     return LNR_OK;
 }

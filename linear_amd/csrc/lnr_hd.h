@@ -162,6 +162,72 @@ LNR_HD inline SeedOut seed_sample(const u8 *s, u64 k, u64 k0, u64 init_at, int k
     SeedOut o; o.X = (u32)X; o.Y = (u32)Y; o.strand = x > 0 ? 0 : 1;
     return o;
 }
+// --- the same sample from a 2-bit packed read ---------------------------------------------------------------
+// pk: bases packed LSB-first, 32 per u64 (N stored as 0); nm: one bit per base, set for N.  A sample at k needs the
+// 29 bases [k-4, k+25): the 21-mer plus the four flanking bases either side that YValue may read
+// (shape_extend.cpp:290-327).  With the window w (base p at bits 2p):
+//   crh = ~w (complement, first base least significant),  h = w with its 21 base pairs reversed,
+//   sum of bases = popc(w & 01..) + 2*popc(w & 10..).
+// Returns false when the packed form does not apply (an N inside the span, or the first samples of a job whose
+// rolling state still holds hashInit bases): the caller then uses seed_sample on the byte copy.
+LNR_HD inline u64 lnr_brev64(u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(v);
+#else
+    v = ((v >> 1) & 0x5555555555555555ULL) | ((v & 0x5555555555555555ULL) << 1);
+    v = ((v >> 2) & 0x3333333333333333ULL) | ((v & 0x3333333333333333ULL) << 2);
+    v = ((v >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((v & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    v = ((v >> 8) & 0x00FF00FF00FF00FFULL) | ((v & 0x00FF00FF00FF00FFULL) << 8);
+    v = ((v >> 16) & 0x0000FFFF0000FFFFULL) | ((v & 0x0000FFFF0000FFFFULL) << 16);
+    return (v >> 32) | (v << 32);
+#endif
+}
+LNR_HD inline int lnr_popc64(u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(v);
+#else
+    return __builtin_popcountll(v);
+#endif
+}
+LNR_HD inline bool seed_sample_packed(const u64 *pk, const u32 *nm, u64 k, u64 k0, int C, SeedOut &o) {
+    if (k - k0 + 1 < 21 || k < 4) return false;
+    u64 s0 = k - 4;
+    u64 w = s0 >> 5;
+    u32 sh = (u32)(s0 & 31);
+    u64 nbits = (((u64)nm[w + 1] << 32) | nm[w]) >> sh;
+    if (nbits & ((1ULL << 29) - 1)) return false;
+    u64 lo = pk[w], hi = pk[w + 1];
+    u64 span = sh ? (lo >> (2 * sh)) | (hi << (64 - 2 * sh)) : lo;     // 29 bases, base (k-4+q) at bits 2q
+    const u64 M42 = (1ULL << 42) - 1;
+    u64 win = (span >> 8) & M42;
+    int W = lnr_popc64(win & 0x5555555555555555ULL) + 2 * lnr_popc64(win & 0xAAAAAAAAAAAAAAAAULL);
+    int x = C + 2 * W;
+    u64 v2;
+    if (x > 0) {
+        u64 r = lnr_brev64(win) >> 22;                                    // pair order reversed, bits inside pairs swapped
+        v2 = ((r & 0x2AAAAAAAAAAULL) >> 1) | ((r & 0x15555555555ULL) << 1);
+    } else v2 = (~win) & M42;
+    u64 X = M42, t = 0;
+    for (unsigned kk = 22; kk <= 38; kk += 2) {
+        u64 v1 = v2 << kk >> 38;
+        if (X > v1) { X = v1; t = kk; }
+    }
+    u32 Y;
+    if (x > 0) {
+        u32 q = (u32)(t >> 1) + 2 + 4;                                   // span index of the first flank base
+        u32 b = (u32)(span >> (2 * q)) & 0xFF;
+        Y = ((b & 3) << 6) | (((b >> 2) & 3) << 4) | (((b >> 4) & 3) << 2) | ((b >> 6) & 3);
+    } else {
+        u32 q = (u32)(18 - (int)(t >> 1) - 3 + 4);
+        u32 b = (u32)(span >> (2 * q)) & 0xFF;
+        Y = (~b) & 0xFF;
+    }
+    o.X = (u32)X; o.Y = Y; o.strand = x > 0 ? 0 : 1;
+    return true;
+}
+// words of the packed form of a read of L bases (one u64 / u32 of slack so that w+1 is always readable)
+LNR_HD inline u64 packed_words(u64 L) { return (L + 63) / 32 + 2; }
+
 LNR_HD inline bool y_match(u64 hs_y, u64 Y) {   // pmpfinder.cpp:1893-1894, ctz(0) pinned to "match"
     u64 v = hs_y ^ Y;
     if (v == 0) return true;

@@ -7,8 +7,8 @@
 //   index build  [a3-a5]: k_ix_chunk_const, k_ix_sample, k_ix_start_blk, k_max_top, k_ix_rec,
 //                         k_ix_omit, k_scan_*, k_ix_scatter, k_ix_sort_small, k_ix_sort_big
 //   features     [a6]   : k_f2 (genome), k_f1 (reads, both strands)
-//   read prep    [a1,a2]: k_prep (padded copy + reverse complement + hashInit N-skip)
-//   seed lookup  [a3,a4,a7]: k_seed_count, k_seed_gather
+//   read prep    [a1,a2]: k_prep (padded copy + reverse complement + 2-bit packing + hashInit N-skip)
+//   seed lookup  [a3,a4,a7]: k_seed_fused (+ k_ix_bitmap at index time)
 //   per-read job [a8-a16]: k_job (binning, radix sort, filter, introsort, DP, traceback, blocks, windows)
 //   tails        [a17-a20]: k_tail_a, k_tail_b, k_gather_out
 #pragma once
@@ -282,9 +282,11 @@ __global__ void __launch_bounds__(256) k_f2(const u8 *g, const u64 *seq_off, con
 }
 
 // ================================================================ read prep ====
-// Padded forward copy + reverse complement (_compltRvseStr, base.cpp:335-344) of every read, and the
-// N-skip hashInit would take at the read start.  One block per read.
-__global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, const u64 *rp_off, const u32 *lpad, u32 n, u8 *dst, i32 *read_ks) {
+// Padded forward copy + reverse complement (_compltRvseStr, base.cpp:335-344) of every read, the 2-bit packed
+// forward strand (+ N bitmap) the seed kernel hashes from, and the N-skip hashInit would take at the read start.
+// One block per read.
+__global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, const u64 *rp_off, const u32 *lpad, const u64 *pk_off, u32 n, u8 *dst, u64 *pk, u32 *nm,
+                                             i32 *read_ks) {
     u32 r = blockIdx.x;
     if (r >= n) return;
     u64 o = off[r];
@@ -300,6 +302,20 @@ __global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, con
         }
         fwd[i] = a;
         rev[i] = b;
+    }
+    u32 nw = (u32)packed_words(L);
+    u64 *pw = pk + pk_off[r];
+    u32 *nw_ = nm + pk_off[r];
+    for (u32 w = threadIdx.x; w < nw; w += blockDim.x) {
+        u64 bits = 0; u32 nb = 0;
+        u32 base = w * 32;
+        for (u32 q = 0; q < 32; q++) {
+            u32 i = base + q;
+            u8 a = 0;
+            if (i < L) { a = src[o + i]; if (a > 4) a = 4; }
+            if (a == 4) nb |= 1u << q; else bits |= (u64)a << (2 * q);
+        }
+        pw[w] = bits; nw_[w] = nb;
     }
     __syncthreads();
     if (threadIdx.x == 0) read_ks[r] = shape_init_skip(fwd);
@@ -324,97 +340,135 @@ __global__ void __launch_bounds__(256) k_f1(const u8 *reads_p, const u64 *rp_off
 }
 
 // ============================================================== seed lookup ====
-struct SampRec { u32 xs; u32 y; i32 dstart; u32 dlen; };   // xs = X | strand<<26 | lookup<<27
 struct JobArrays {
     const u32 *read, *str, *end, *mode;   // per job
-    const u64 *samp_off;                  // per job: first sample record
 };
 struct ReadArrays {
     const u8 *bases; const u64 *rp_off; const u32 *lpad; const u32 *len; const i32 *ks;
+    const u64 *pk; const u32 *nm; const u64 *pk_off;   // 2-bit packed forward strand + N bitmap
+};
+struct SeedOutArrays {
+    unsigned long long *cursor; u64 capacity; int *overflow;   // bump allocator over the anchor buffer (u64 slots)
+    u64 *anchors; u64 *anc_off; u32 *job_cap; u32 *job_look; u32 *n_anchors;
 };
 
-// pass 1: one wave per job.  Minimizers of all samples, the "minimizer changed" lookup rule
-// (xpre of pmpfinder.cpp:1882,1906 is always the previous sample's X), bucket bounds from dir.
-__global__ void __launch_bounds__(64) k_seed_count(JobArrays J, ReadArrays R, const i32 *dir, u32 njobs, SampRec *samp, u32 *job_cap, u32 *job_look) {
+// bucket-non-empty bitmap (1 bit per minimizer bucket, 8 MB): most read minimizers of an error-prone read hit an empty
+// bucket; the bitmap answers that from cache instead of a random 64-byte `dir` sector from HBM.
+__global__ void __launch_bounds__(256) k_ix_bitmap(const i32 *dir, u64 nbuckets, u32 *bm) {
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 b0 = w * 32;
+    if (b0 >= nbuckets) return;
+    u32 bits = 0;
+    i32 prev = dir[b0];
+    for (u32 q = 0; q < 32 && b0 + q < nbuckets; q++) { i32 nx = dir[b0 + q + 1]; if (nx > prev) bits |= 1u << q; prev = nx; }
+    bm[w] = bits;
+}
+
+// Seed lookup of one job per wave (getDIndexMatchAll, pmpfinder.cpp:1856-1913), one kernel:
+//   1. minimizer of every sample (2-bit packed path; byte path where an N or hashInit state intervenes), the
+//      "minimizer changed" lookup rule (xpre == previous sample's X), bitmap test, bucket bounds from dir -- the sample
+//      records stay in LDS (SEG samples per segment);
+//   2. the job's anchor segment is allocated with one atomicAdd (capacity = sum of bucket lengths + dummy);
+//   3. (sample, bucket entry) pairs are flattened over the lanes, filtered on Y (pmpfinder.cpp:1890-1899) and written in
+//      the reference's order by ballot compaction.
+// Jobs with more samples than one segment count first and recompute the segments for step 3.
+#define SEED_SEG 512
+__global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, const i32 *dir, const u32 *bm, const u64 *hs, u32 njobs, SeedOutArrays O) {
+    __shared__ u32 st_xs[SEED_SEG];    // X | strand << 26
+    __shared__ u32 st_ydl[SEED_SEG];   // Y | bucket length << 8
+    __shared__ i32 st_ds[SEED_SEG];    // bucket start
+    __shared__ u32 s_incl[64];
     u32 j = blockIdx.x;
     if (j >= njobs) return;
     int lane = lane_id();
     u32 r = J.read[j];
     const u8 *s = R.bases + R.rp_off[r];
+    const u64 *pk = R.pk + R.pk_off[r];
+    const u32 *nm = R.nm + R.pk_off[r];
+    u64 L = R.len[r];
     u64 rs = J.str[j], re = J.end[j];
     u32 alpha = (u32)job_parm((int)J.mode[j]).alpha;
     int ks = R.ks[r];
     u64 k0 = rs + 21;
     int C = shape_const(s, 0, ks, k0);
     u32 ns = seed_num_samples(rs, re, alpha);
-    SampRec *out = samp + J.samp_off[j];
-    u32 carry = 0, cap = 0, looks = 0;
-    for (u32 base = 0; base < ns; base += 64) {
-        u32 si = base + lane;
-        bool valid = si < ns;
-        SeedOut o; o.X = 0; o.Y = 0; o.strand = 0;
-        if (valid) o = seed_sample(s, k0 + alpha - 1 + (u64)alpha * si, k0, 0, ks, C);
-        u32 prev = __shfl_up(o.X, 1);
-        if (lane == 0) prev = carry;
-        bool look = valid && o.X != prev;
-        i32 ds = 0; u32 dl = 0;
-        if (look) { ds = dir[o.X]; dl = (u32)(dir[o.X + 1] - ds); }
-        if (valid) { SampRec rec; rec.xs = o.X | (o.strand << 26) | ((u32)look << 27); rec.y = o.Y; rec.dstart = ds; rec.dlen = dl; out[si] = rec; }
-        cap += wave_sum(dl);
-        looks += (u32)__popcll(__ballot(look));
-        carry = __shfl(o.X, 63);
+    u32 nseg = (ns + SEED_SEG - 1) / SEED_SEG;
+    u32 cap = 0, looks = 0, carry = 0;
+    auto fill_segment = [&](u32 seg, u32 &carry_io, u32 &cap_io, u32 &looks_io) {
+        u32 s_lo = seg * SEED_SEG, s_hi = s_lo + SEED_SEG < ns ? s_lo + SEED_SEG : ns;
+        for (u32 base = s_lo; base < s_hi; base += 64) {
+            u32 si = base + lane;
+            bool valid = si < s_hi;
+            SeedOut o; o.X = 0; o.Y = 0; o.strand = 0;
+            if (valid) {
+                u64 k = k0 + alpha - 1 + (u64)alpha * si;
+                if (!seed_sample_packed(pk, nm, k, k0, C, o)) o = seed_sample(s, k, k0, 0, ks, C);
+            }
+            u32 prev = __shfl_up(o.X, 1);
+            if (lane == 0) prev = carry_io;
+            bool look = valid && o.X != prev;
+            i32 ds = 0; u32 dl = 0;
+            if (look && ((bm[o.X >> 5] >> (o.X & 31)) & 1)) { ds = dir[o.X]; dl = (u32)(dir[o.X + 1] - ds); }
+            if (valid) { st_xs[si - s_lo] = o.X | (o.strand << 26); st_ydl[si - s_lo] = o.Y | (dl << 8); st_ds[si - s_lo] = ds; }
+            cap_io += wave_sum(dl);
+            looks_io += (u32)__popcll(__ballot(look));
+            carry_io = __shfl(o.X, 63);
+        }
+        __syncthreads();
+    };
+    for (u32 seg = 0; seg < nseg; seg++) fill_segment(seg, carry, cap, looks);
+    // allocate the anchor segment (dummy + capacity, even-sized)
+    u64 want = ((u64)cap + 1 + 1) & ~1ULL;
+    unsigned long long off = 0;
+    if (lane == 0) off = atomicAdd(O.cursor, (unsigned long long)want);
+    off = __shfl((long long)off, 0);
+    if (lane == 0) { O.job_cap[j] = cap + 1; O.job_look[j] = looks; O.anc_off[j] = off; }
+    if (off + want > O.capacity) {   // the host re-runs with the exact size (it now knows every job_cap)
+        if (lane == 0) { *O.overflow = 1; O.n_anchors[j] = 0; }
+        return;
     }
-    if (lane == 0) { job_cap[j] = cap + 1; job_look[j] = looks; }
-}
-// pass 2: one wave per job.  (sample, bucket entry) pairs are flattened over the lanes, filtered on Y
-// (pmpfinder.cpp:1890-1899) and written in the reference's order by ballot compaction.
-__global__ void __launch_bounds__(64) k_seed_gather(JobArrays J, ReadArrays R, const u64 *hs, const u32 *job_list, u32 job_lo, u32 job_hi, const SampRec *samp,
-                                                    const u64 *anc_off, u64 *anchors, u32 *n_anchors) {
-    __shared__ u32 s_incl[64], s_excl[64], s_xs[64], s_y[64];
-    __shared__ i32 s_ds[64];
-    if (job_lo + blockIdx.x >= job_hi) return;
-    u32 j = job_list[job_lo + blockIdx.x];   // jobs are visited heaviest group first
-    int lane = lane_id();
-    u32 r = J.read[j];
-    u64 L = R.len[r];
-    u64 rs = J.str[j], re = J.end[j];
-    u32 alpha = (u32)job_parm((int)J.mode[j]).alpha;
-    u64 k0 = rs + 21;
-    u32 ns = seed_num_samples(rs, re, alpha);
-    const SampRec *in = samp + J.samp_off[j];
-    u64 *out = anchors + anc_off[j];
+    u64 *out = O.anchors + off;
     if (lane == 0) out[0] = 0;   // the dummy the reference keeps at anchors[0] (base.cpp:272-277)
     u32 nout = 1;
-    for (u32 base = 0; base < ns; base += 64) {
-        u32 si = base + lane;
-        SampRec rec; rec.xs = 0; rec.y = 0; rec.dstart = 0; rec.dlen = 0;
-        if (si < ns) rec = in[si];
-        u32 incl = wave_incl_scan(rec.dlen);
-        u32 total = __shfl(incl, 63);
-        __syncthreads();
-        s_incl[lane] = incl; s_excl[lane] = incl - rec.dlen; s_xs[lane] = rec.xs; s_y[lane] = rec.y; s_ds[lane] = rec.dstart;
-        __syncthreads();
-        for (u32 e0 = 0; e0 < total; e0 += 64) {
-            u32 e = e0 + lane;
-            bool act = e < total;
-            bool match = false;
-            u64 av = 0;
-            if (act) {
-                int lo = 0, hi = 63;   // first sample whose inclusive count exceeds e
-                while (lo < hi) { int mid = (lo + hi) >> 1; if (s_incl[mid] > e) hi = mid; else lo = mid + 1; }
-                u64 ent = hs[s_ds[lo] + (i32)(e - s_excl[lo])];
-                if (y_match(cord_y(ent), s_y[lo])) {
-                    match = true;
-                    u64 k = k0 + alpha - 1 + (u64)alpha * (base + lo);
-                    av = val2anchor(ent, k, L, (s_xs[lo] >> 26) & 1);
+    u32 carry2 = 0, capx = 0, lookx = 0;
+    for (u32 seg = 0; seg < nseg; seg++) {
+        if (nseg > 1) fill_segment(seg, carry2, capx, lookx);
+        u32 s_lo = seg * SEED_SEG, s_hi = s_lo + SEED_SEG < ns ? s_lo + SEED_SEG : ns;
+        for (u32 base = s_lo; base < s_hi; base += 64) {
+            u32 li = base - s_lo + lane;
+            bool valid = base + lane < s_hi;
+            u32 dl = valid ? st_ydl[li] >> 8 : 0;
+            u32 incl = wave_incl_scan(dl);
+            u32 total = __shfl(incl, 63);
+            if (total == 0) continue;
+            __syncthreads();
+            s_incl[lane] = incl;
+            __syncthreads();
+            for (u32 e0 = 0; e0 < total; e0 += 64) {
+                u32 e = e0 + lane;
+                bool match = false;
+                u64 av = 0;
+                if (e < total) {
+                    int lo = 0, hi = 63;   // first sample of the chunk whose inclusive count exceeds e
+                    while (lo < hi) { int mid = (lo + hi) >> 1; if (s_incl[mid] > e) hi = mid; else lo = mid + 1; }
+                    u32 q = base - s_lo + (u32)lo;
+                    u32 ydl = st_ydl[q], xsv = st_xs[q];
+                    u32 excl = s_incl[lo] - (ydl >> 8);
+                    u64 ent = hs[st_ds[q] + (i32)(e - excl)];
+                    if (y_match(cord_y(ent), ydl & 0xff)) {
+                        match = true;
+                        u64 k = k0 + alpha - 1 + (u64)alpha * (base + (u32)lo);
+                        av = val2anchor(ent, k, L, (xsv >> 26) & 1);
+                    }
                 }
+                u64 mask = __ballot(match);
+                if (match) out[nout + __popcll(mask & lanemask_lt())] = av;
+                nout += (u32)__popcll(mask);
             }
-            u64 mask = __ballot(match);
-            if (match) out[nout + __popcll(mask & lanemask_lt())] = av;
-            nout += (u32)__popcll(mask);
         }
+        __syncthreads();
     }
-    if (lane == 0) n_anchors[j] = nout;
+    if (lane == 0) O.n_anchors[j] = nout;
 }
 
 // =================================================================== job =====

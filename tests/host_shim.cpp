@@ -250,6 +250,34 @@ u64 hs_debug_get(void *h, int stage, u64 *out, u64 cap) {
 }
 void hs_get_stats(void *h, u64 *out5) { memcpy(out5, ((Shim *)h)->stats, 40); }
 
+// packed-read form of the minimizer sample against the byte form: returns the number of samples that disagree
+// (samples where the packed form declines are counted separately in *n_fallback)
+u64 hs_packed_vs_bytes(const u8 *read, u64 L, u64 read_str, u64 read_end, int alpha, u64 *n_fallback, u64 *n_samples) {
+    std::vector<u8> s(L + PAD, 0);
+    memcpy(s.data(), read, L);
+    u64 nw = packed_words(L);
+    std::vector<u64> pk(nw, 0);
+    std::vector<u32> nm(nw, 0);
+    for (u64 i = 0; i < L; i++) {
+        u8 b = s[i];
+        if (b > 3) nm[i >> 5] |= 1u << (i & 31);
+        else pk[i >> 5] |= (u64)b << (2 * (i & 31));
+    }
+    int ks = shape_init_skip(s.data());
+    u64 k0 = read_str + 21;
+    int C = shape_const(s.data(), 0, ks, k0);
+    u32 ns = seed_num_samples(read_str, read_end, (u32)alpha);
+    u64 bad = 0, fb = 0;
+    for (u32 q = 0; q < ns; q++) {
+        u64 k = k0 + alpha - 1 + (u64)alpha * q;
+        SeedOut a = seed_sample(s.data(), k, k0, 0, ks, C), b;
+        if (!seed_sample_packed(pk.data(), nm.data(), k, k0, C, b)) { fb++; continue; }
+        if (a.X != b.X || a.Y != b.Y || a.strand != b.strand) bad++;
+    }
+    *n_fallback = fb; *n_samples = ns;
+    return bad;
+}
+
 // fuzz hook for ref_sort: sorts keys (compare on the high 32 bits only, descending when desc != 0)
 void hs_ref_sort_hi32(u64 *a, u64 n, int desc) {
     SortStack st;

@@ -64,3 +64,25 @@ def test_stage_logic_matches_golden(case_inputs, name, T):
         assert np.array_equal(cs, g["cords_str"][int(coff[i]):int(coff[i + 1])]), f"read {i}"
         assert np.array_equal(ce, g["cords_end"][int(coff[i]):int(coff[i + 1])]), f"read {i}"
     s.close()
+
+
+def test_packed_minimizer_equals_byte_form(case_inputs):
+    """2-bit packed read path of the seed kernel == byte path (which is pinned to the reference above)."""
+    shimlib.build()
+    lib = C.CDLL(shimlib.SO)
+    lib.hs_packed_vs_bytes.restype = C.c_uint64
+    lib.hs_packed_vs_bytes.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    tot = fbs = 0
+    for name in ("ont", "edge"):
+        refs, reads, off = case_inputs(name)
+        for i in range(off.size - 1):
+            rd = np.ascontiguousarray(reads[int(off[i]):int(off[i + 1])])
+            if rd.size < 300:
+                continue
+            for (rs, re, al) in ((0, rd.size, 15), (100, rd.size - 37, 7)):
+                fb, ns = C.c_uint64(), C.c_uint64()
+                bad = lib.hs_packed_vs_bytes(rd.ctypes.data_as(C.POINTER(C.c_uint8)), rd.size, rs, re, al, C.byref(fb), C.byref(ns))
+                assert bad == 0, f"{name} read {i}"
+                tot += ns.value
+                fbs += fb.value
+    assert tot > 50_000 and fbs < tot * 0.05
