@@ -62,7 +62,7 @@ struct lnr_ctx {
     u32 nbins = 0;
     size_t job_lds_bytes = 8 * 1024;    // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
     size_t job_stage_bytes = 0;         // LDS stage of the blocked DP's predecessor window in the fused k_job (LNR_JOB_STAGE_KB; measured slower, off)
-    u32 dp_stage_kb = 0;                // same for k_dp_big (LNR_DP_STAGE_KB)
+    u32 heavy_lds_kb = 48;              // LDS arena of k_job_heavy (LNR_HEAVY_LDS_KB)
     u32 heavy_cap = 8192;               // jobs with at least this many bucket entries take the heavy path (LNR_HEAVY_CAP overrides)
     hipStream_t stream2 = nullptr;      // heavy path runs here, concurrently with the fused k_job
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -74,7 +74,7 @@ struct lnr_ctx {
     DevBuf tail_scr, tail_off, tail_cap, gaps, gaps_off, gaps_cap, ngaps, remap;
     // ---- jobs
     DevBuf j_read, j_str, j_end, j_mode, j_cap, j_look, j_anc_off, j_scr_off, j_nanc, grp_beg, grp_order, job_list;
-    DevBuf anchors, job_scr, prof, j_nbin, j_m, heavy_jobs, seed_ctl;   // seed_ctl: allocator cursor + overflow flag
+    DevBuf anchors, job_scr, prof, seed_ctl;   // seed_ctl: allocator cursor + overflow flag
     u64 anc_slots_per_job = 1536;       // running estimate of anchor slots per job (grows on overflow)
     // ---- results
     DevBuf r_off, r_str, r_end;
@@ -308,36 +308,23 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             size_t lds = std::max<size_t>(lds_min, arena + ctx->job_stage_bytes);
             A.lds_bytes = (u32)lds;
             A.arena_lds = (u32)arena;
-            A.phase = 0;
-            ENSURE(ctx->j_nbin, (size_t)nj * 4);
-            ENSURE(ctx->j_m, (size_t)nj * 4);
-            A.job_nbin = ctx->j_nbin.as<u32>(); A.job_m = ctx->j_m.as<u32>();
             // heavy groups = prefix of the (weight-descending) slice
             u32 gh = g0;
-            std::vector<u32> hjobs;
             while (gh < g1) {
                 u64 wsum = 0;
                 for (u32 q = ord_job_beg[gh]; q < ord_job_beg[gh + 1]; q++) wsum += cap[job_list[q]];
                 if (wsum < ctx->heavy_cap) break;
-                for (u32 q = ord_job_beg[gh]; q < ord_job_beg[gh + 1]; q++) hjobs.push_back(job_list[q]);
                 gh++;
             }
             ctx->t_job.start(ctx->stream);
             if (gh > g0) {
-                // heavy path on stream2: pre (1 wave/read) -> DP with 16 waves per job -> post (1 wave/read)
-                if ((s = upload(ctx, ctx->heavy_jobs, hjobs)) != LNR_OK) return s;
+                // heavy reads on stream2: one 16-wave workgroup per read with a large LDS arena
                 HIPCK(hipEventRecord(ctx->ev_fork, ctx->stream));
                 HIPCK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
                 JobArgs H = A;
-                H.grp_lo = g0; H.grp_hi = gh; H.lds_bytes = (u32)std::max<size_t>(lds_min, 16); H.arena_lds = 0;
-                H.phase = 1;
-                hipLaunchKernelGGL(k_job, dim3(gh - g0), dim3(64), H.lds_bytes, ctx->stream2, H);
-                KCHECK();
-                const u32 stage_bytes = ctx->dp_stage_kb * 1024;   // LDS stage of the tile's predecessor window (20 B per anchor)
-                hipLaunchKernelGGL(k_dp_big<1024>, dim3((u32)hjobs.size()), dim3(1024), stage_bytes, ctx->stream2, H, ctx->heavy_jobs.as<u32>(), (u32)hjobs.size(), stage_bytes);
-                KCHECK();
-                H.phase = 2;
-                hipLaunchKernelGGL(k_job, dim3(gh - g0), dim3(64), H.lds_bytes, ctx->stream2, H);
+                size_t hl = std::max<size_t>(lds_min, (size_t)ctx->heavy_lds_kb * 1024);
+                H.grp_lo = g0; H.grp_hi = gh; H.lds_bytes = (u32)hl; H.arena_lds = (u32)hl;
+                hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, ctx->stream2, H);
                 KCHECK();
                 HIPCK(hipEventRecord(ctx->ev_join, ctx->stream2));
             }
@@ -655,7 +642,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_JOB_STAGE_KB")) { long kb = atol(e); if (kb >= 0 && kb <= 60) ctx->job_stage_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_HEAVY_CAP")) { long v = atol(e); if (v >= 64) ctx->heavy_cap = (u32)v; }
-    if (const char *e = getenv("LNR_DP_STAGE_KB")) { long v = atol(e); if (v >= 0 && v <= 60) ctx->dp_stage_kb = (u32)v; }
+    if (const char *e = getenv("LNR_HEAVY_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->heavy_lds_kb = (u32)v; }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     ctx->t_prep.init(); ctx->t_sc.init(); ctx->t_sg.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();

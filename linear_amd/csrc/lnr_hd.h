@@ -70,7 +70,9 @@ LNR_HD inline bool lnr_is_leader() {
 // make the leader's stores visible to the other lanes of the wave (workgroup = one wave in k_job)
 LNR_HD inline void lnr_wave_sync() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #endif
 }
 // bounded vector view over caller-provided storage; overflow is recorded, never written past cap
@@ -678,16 +680,23 @@ LNR_HD inline void best_chains2(const u64 *hits, const UP *sep, const i32 *sep_s
     }
 }
 struct BlockScratch { u32 *ptr; UP *sep_tmp; i32 *score_tmp; Rec rec; i32 *chain, *chain_sc, *cnt; LeaderScratch *ls; };
-// chainBlocksBase cluster_util.cpp:533-577
-LNR_HD inline void chain_blocks_base(BlockSink &sink, const u64 *records, const UP *sep, const i32 *sep_score, u32 nb, u64 L, int which, int strand,
-                                     int f_sort, BlockScratch s) {
-    if (nb < 2) return;
+// chainBlocksBase cluster_util.cpp:533-577, in three steps so that the kernel can run the middle one with all lanes:
+//   prepare (tie-sensitive sort of the blocks by first-x + gather), DP (getBestChains2), traceback.
+LNR_HD inline void chain_blocks_prepare(const u64 *records, const UP *sep, const i32 *sep_score, u32 nb, int f_sort, BlockScratch s) {
     for (u32 i = 0; i < nb; i++) s.ptr[i] = i;
     if (f_sort) ref_sort(s.ptr, (long)nb, [records, sep](const u32 &a, const u32 &b) { return cord_x40(records[sep[a].first]) > cord_x40(records[sep[b].first]); }, s.ls->st);
     for (u32 i = 0; i < nb; i++) { s.sep_tmp[i] = sep[s.ptr[i]]; s.score_tmp[i] = sep_score[s.ptr[i]]; }
-    best_chains2(records, s.sep_tmp, s.score_tmp, nb, s.rec, L, which, strand);
+}
+LNR_HD inline void chain_blocks_trace(BlockSink &sink, u32 nb, BlockScratch s) {
     sink.elements = s.sep_tmp;
     traceback(s.rec, nb, sink, s.chain, s.chain_sc, s.cnt, 1, 0, 3, 0.7f, *s.ls);
+}
+LNR_HD inline void chain_blocks_base(BlockSink &sink, const u64 *records, const UP *sep, const i32 *sep_score, u32 nb, u64 L, int which, int strand,
+                                     int f_sort, BlockScratch s) {
+    if (nb < 2) return;
+    chain_blocks_prepare(records, sep, sep_score, nb, f_sort, s);
+    best_chains2(records, s.sep_tmp, s.score_tmp, nb, s.rec, L, which, strand);
+    chain_blocks_trace(sink, nb, s);
 }
 // _filterBlocksHits cluster_util.cpp:633-719: rewrites hits from the chained blocks (note: the dummy hits[0] is dropped)
 LNR_HD inline u32 filter_blocks_hits(const BlockSink &ch, const u64 *hits, u64 *out) {
@@ -1040,18 +1049,40 @@ LNR_HD inline void job_fill_xy(const u64 *a, u32 m, JobScratch &S, u32 first, u3
 // (between the phases: the chaining DP over S.xs/S.ys into S.rec -- best_chains_serial here,
 //  its wave-parallel twin in the kernel -- only when m >= 2, chainAnchorsBase cluster_util.cpp:450)
 
-// Phase 3a (serial, leader): traceback -> hits, hit blocks, block chaining.  Leaves the surviving hits in
-// (H, nH).  Returns 0, or 1 on capacity overflow.  The caller continues with filter_hits_flags (elementwise),
-// filter_hits_apply (leader) and path_dst_2 (SIMT-uniform) -- path_dst alg 2, pmpfinder.cpp:1447-1469.
+// Phase 3a: traceback -> hits, hit blocks, block chaining; leaves the surviving hits in (H, nH).  The caller
+// continues with filter_hits_flags (elementwise), filter_hits_apply (leader) and path_dst_2 (SIMT-uniform) --
+// path_dst alg 2, pmpfinder.cpp:1447-1469.  It comes in pieces so that the kernel can run the two quadratic
+// middle steps (prefilter_chains2, getBestChains2) with all lanes; job_phase3a is the serial composition.
+LNR_HD inline void job_blocks_gather(JobScratch &S, const JobCtx &c) {           // gather_blocks_ of pmpfinder.cpp:2535
+    S.sep.n = 0; S.tmp.n = 0;
+    gather_blocks(S.hits.p, S.hits.n, nullptr, S.sep, 1, S.hits.n, c.L, 600, 0, 0);
+}
+LNR_HD inline BlockScratch job_block_scratch(JobScratch &S, LeaderScratch &ls) {   // arrays of the anchor DP are dead and reused
+    BlockScratch s; s.ptr = S.xs; s.sep_tmp = (UP *)S.cuts; s.score_tmp = (i32 *)S.ys; s.rec = S.rec; s.chain = S.chain_sc; s.chain_sc = (i32 *)S.xy_strs; s.cnt = S.cnt; s.ls = &ls;
+    return s;
+}
+LNR_HD inline void job_blocks_scores(JobScratch &S, u32 first, u32 step) {       // pmpfinder.cpp:2540-2544
+    for (u32 i = first; i < S.sep.n; i += step) S.sep_score[i] = S.hscore[(u32)S.sep[i].first] - S.hscore[(u32)S.sep[i].second - 1];
+}
+LNR_HD inline int job_blocks_finish(u64 *a, JobScratch &S, BlockSink &bs, JobDebug *dbg, u64 *&H, u32 &nH) {   // _filterBlocksHits
+    Vec<u64> &hits = S.hits;
+    u64 *hits2 = a;   // anchors are dead by now; hits never outnumber them
+    u32 nh2 = filter_blocks_hits(bs, hits.p, hits2);
+    if (nh2 == 0xffffffffu) { H = hits.p; nH = hits.n; } else { H = hits2; nH = nh2; }
+    if (dbg && dbg->hits_blocks) { for (u32 i = 0; i < nH; i++) dbg->hits_blocks[i] = H[i]; *dbg->nhits_blocks = nH; }
+    return *S.hits.ovf ? 1 : 0;
+}
+LNR_HD inline BlockSink job_block_sink(JobScratch &S) {
+    BlockSink bs; bs.el = S.tmp.p; bs.off = S.chain; bs.nchains = 0; bs.nel = 0; bs.cap = S.tmp.cap; bs.ovf = S.hits.ovf; bs.first_len = 0; bs.off[0] = 0; bs.elements = nullptr;
+    return bs;
+}
 LNR_HD inline int job_phase3a(u64 *a, u32 m, JobScratch &S, const JobCtx &c, JobDebug *dbg, u64 *&H, u32 &nH, LeaderScratch &ls) {
-    int *ovf = S.hits.ovf;
     Vec<u64> &hits = S.hits;
     unsigned long long tl_ = 0;
 #if defined(LNR_PROF) && defined(__HIP_DEVICE_COMPILE__)
     tl_ = clock64();
 #endif
     (void)tl_;
-    S.sep.n = 0; S.tmp.n = 0;
     if (!c.traceback_done) {
         hits.n = 0; S.hscore.n = 0;
         hits.push(F_END);        // initHits
@@ -1063,21 +1094,16 @@ LNR_HD inline int job_phase3a(u64 *a, u32 m, JobScratch &S, const JobCtx &c, Job
     }
     if (dbg && dbg->hits_chain) { for (u32 i = 0; i < hits.n; i++) dbg->hits_chain[i] = hits[i]; *dbg->nhits_chain = hits.n; }
     if (!c.traceback_done) LNR_TICK(c.prof, 5, tl_);
-    // getAnchorHitsChains pmpfinder.cpp:2535-2545
-    gather_blocks(hits.p, hits.n, nullptr, S.sep, 1, hits.n, c.L, 600, 0, 0);
+    job_blocks_gather(S, c);
     prefilter_chains2(hits.p, hits.n, S.sep, S.cuts, S.xy_strs, S.tmp, ls);
     LNR_TICK(c.prof, 6, tl_);
-    for (u32 i = 0; i < S.sep.n; i++) S.sep_score[i] = S.hscore[(u32)S.sep[i].first] - S.hscore[(u32)S.sep[i].second - 1];
-    // chainBlocksHits cluster_util.cpp:721-732 (scratch arrays of the anchor DP are dead and reused)
-    BlockSink bs; bs.el = S.tmp.p; bs.off = S.chain; bs.nchains = 0; bs.nel = 0; bs.cap = S.tmp.cap; bs.ovf = ovf; bs.first_len = 0; bs.off[0] = 0;
-    BlockScratch s; s.ptr = S.xs; s.sep_tmp = (UP *)S.cuts; s.score_tmp = (i32 *)S.ys; s.rec = S.rec; s.chain = S.chain_sc; s.chain_sc = (i32 *)S.xy_strs; s.cnt = S.cnt; s.ls = &ls;
-    chain_blocks_base(bs, hits.p, S.sep.p, S.sep_score, S.sep.n, c.L, 2, 0, 1, s);
-    u64 *hits2 = a;   // anchors are dead by now; hits never outnumber them
-    u32 nh2 = filter_blocks_hits(bs, hits.p, hits2);
-    if (nh2 == 0xffffffffu) { H = hits.p; nH = hits.n; } else { H = hits2; nH = nh2; }
-    if (dbg && dbg->hits_blocks) { for (u32 i = 0; i < nH; i++) dbg->hits_blocks[i] = H[i]; *dbg->nhits_blocks = nH; }
+    job_blocks_scores(S, 0, 1);
+    BlockSink bs = job_block_sink(S);
+    BlockScratch s = job_block_scratch(S, ls);
+    chain_blocks_base(bs, hits.p, S.sep.p, S.sep_score, S.sep.n, c.L, 2, 0, 1, s);   // chainBlocksHits cluster_util.cpp:721-732
+    int rc = job_blocks_finish(a, S, bs, dbg, H, nH);
     LNR_TICK(c.prof, 7, tl_);
-    return *ovf ? 1 : 0;
+    return rc;
 }
 
 // ==================================================================== tails ====

@@ -9,7 +9,8 @@
 //   features     [a6]   : k_f2 (genome), k_f1 (reads, both strands)
 //   read prep    [a1,a2]: k_prep (padded copy + reverse complement + 2-bit packing + hashInit N-skip)
 //   seed lookup  [a3,a4,a7]: k_seed_fused (+ k_ix_bitmap at index time)
-//   per-read job [a8-a16]: k_job (binning, radix sort, filter, introsort, DP, traceback, blocks, windows)
+//   per-read job [a8-a16]: k_job (1 wave per read) / k_job_heavy (16 waves per heavy read): binning, radix sort, filter,
+//                         introsort, blocked chaining DP, traceback, blocks, windows
 //   tails        [a17-a20]: k_tail_a, k_tail_b, k_gather_out
 #pragma once
 #include <hip/hip_runtime.h>
@@ -19,6 +20,14 @@ namespace lnr {
 
 #define WAVE 64
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// Ordering point inside ONE wave: the leader's LDS / global stores become visible to the other lanes' later loads.
+// Lanes of a wave run in lockstep, so no s_barrier is needed -- only the memory waits; this also lets single-wave
+// code run inside a multi-wave workgroup (heavy path) without involving the other waves.
+__device__ __forceinline__ void WSYNC() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ u64 lanemask_lt() { return (1ULL << lane_id()) - 1ULL; }
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
     for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(v, o); if (lane_id() >= o) v += t; }
@@ -483,9 +492,7 @@ struct JobArgs {
     u64 *cords; const u64 *cords_off; const u32 *cords_cap; u32 *ncords; i32 *read_err;
     u32 nbins; u32 grp_lo, grp_hi;
     u32 lds_bytes;          // dynamic LDS per block: binning histogram first, then the fast half of the job arena
-    u32 arena_lds;          // bytes of that LDS the arena may use (0 on the heavy path: its three kernels must replay identical global addresses)
-    u32 phase;              // 0 = whole job in one launch; heavy path: 1 = up to the x/y fill (state saved), 2 = from the traceback on
-    u32 *job_nbin, *job_m;  // heavy path: per-job anchor counts after binning / after filtering
+    u32 arena_lds;          // bytes of that LDS the job arena may use
     unsigned long long *prof;   // diagnostic build (-DLNR_PROF) only: per-phase cycle sums of lane 0
 };
 
@@ -495,7 +502,7 @@ __device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 nbins) {
     int lane = lane_id();
     u32 nw = (nbins + 1) >> 1;
     for (u32 w = lane; w < nw; w += 64) binw[w] = 0;
-    __syncthreads();
+    WSYNC();
     for (u32 i = lane; i < n; i += 64) {
         u32 b = (u32)(cord_x(a[i]) / 30000);
         if (b < nbins) {
@@ -505,7 +512,7 @@ __device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 nbins) {
             if (half >= 0x8000u) atomicSub(&binw[b >> 1], inc);   // saturate well below carry into the neighbour half
         }
     }
-    __syncthreads();
+    WSYNC();
     u32 ii = 0;
     for (u32 base = 0; base < n; base += 64) {
         u32 i = base + lane;
@@ -519,7 +526,7 @@ __device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 nbins) {
         if (keep) a[ii + __popcll(mask & lanemask_lt())] = v;
         ii += (u32)__popcll(mask);
     }
-    __syncthreads();
+    WSYNC();
     return ii ? ii : n;   // nothing survives -> everything is kept (pmpfinder.cpp:2007-2010)
 }
 
@@ -531,18 +538,18 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
     for (int pass = 0; pass < 8; pass++) {
         int shift = pass * 8;
         for (int b = lane; b < 256; b += 64) hist[b] = 0;
-        __syncthreads();
+        WSYNC();
         for (u32 i = lane; i < n; i += 64) atomicAdd(&hist[(src[i] >> shift) & 255], 1u);
-        __syncthreads();
+        WSYNC();
         // exclusive prefix over the 256 bins: 4 bins per lane
         u32 c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
         bool uniform = (c0 == n) || (c1 == n) || (c2 == n) || (c3 == n);
-        if (__ballot(uniform)) { __syncthreads(); continue; }   // every key has the same digit: pass is the identity
+        if (__ballot(uniform)) { WSYNC(); continue; }   // every key has the same digit: pass is the identity
         u32 s4 = c0 + c1 + c2 + c3;
         u32 ex = wave_incl_scan(s4) - s4;
-        __syncthreads();
+        WSYNC();
         hist[4 * lane] = ex; hist[4 * lane + 1] = ex + c0; hist[4 * lane + 2] = ex + c0 + c1; hist[4 * lane + 3] = ex + c0 + c1 + c2;
-        __syncthreads();
+        WSYNC();
         for (u32 base = 0; base < n; base += 64) {
             u32 i = base + lane;
             bool valid = i < n;
@@ -552,17 +559,17 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
             for (int bit = 0; bit < 8; bit++) { u64 bm = __ballot((d >> bit) & 1); m &= ((d >> bit) & 1) ? bm : ~bm; }
             u32 pos = 0;
             if (valid) pos = hist[d] + (u32)__popcll(m & lanemask_lt());
-            __syncthreads();
+            WSYNC();
             if (valid) {
                 dst[pos] = key;
                 if ((m >> lane) >> 1 == 0) hist[d] += (u32)__popcll(m);   // highest lane of the digit group advances the cursor
             }
-            __syncthreads();
+            WSYNC();
         }
         u64 *t = src; src = dst; dst = t;
     }
     if (src != a) { for (u32 i = lane; i < n; i += 64) a[i] = src[i]; }
-    __syncthreads();
+    WSYNC();
 }
 
 // Wave-parallel, bit-exact std::sort(anchors, by getAnchorX descending) -- the tie-sensitive sort of
@@ -578,7 +585,7 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
     XDesc comp;
     if (n <= SORT_SMALL) {
         if (lane == 0) ref_sort(a, (long)n, comp, ls->st);
-        __syncthreads();
+        WSYNC();
         return;
     }
     // wave-uniform stack: kept in LDS (every lane writes the same value), not in per-lane private memory
@@ -590,7 +597,7 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
     u32 ntasks = 0;
     while (sp > 0) {
         --sp;
-        __syncthreads();
+        WSYNC();
         u32 first = (u32)stk_first[sp], last = (u32)stk_last[sp];
         int depth = stk_depth[sp];
         while (true) {
@@ -599,7 +606,7 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
                 ntasks++;
                 break;
             }
-            if (depth == 0) { if (lane == 0) rs_heap_sort(a, (long)first, (long)last, comp); __syncthreads(); break; }
+            if (depth == 0) { if (lane == 0) rs_heap_sort(a, (long)first, (long)last, comp); WSYNC(); break; }
             --depth;
             if (lane == 0) {   // __move_median_to_first(first, first+1, mid, last-1)
                 u32 A = first + 1, B = first + (last - first) / 2, C = last - 1;
@@ -609,7 +616,7 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
                 else pick = comp(va, vc) ? A : (comp(vb, vc) ? C : B);
                 u64 t = a[first]; a[first] = a[pick]; a[pick] = t;
             }
-            __syncthreads();
+            WSYNC();
             u32 xp = (u32)anchor_x(a[first]);
             u32 lo = first + 1, nL = 0, nR = 0;
             for (u32 base = lo; base < last; base += 64) {
@@ -623,7 +630,7 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
                 if (fR) Rbuf[nR + __popcll(mR & lanemask_lt())] = i;
                 nL += (u32)__popcll(mL); nR += (u32)__popcll(mR);
             }
-            __syncthreads();
+            WSYNC();
             u32 lim = nL < nR ? nL : nR, cnt = 0;
             for (u32 k = lane; k < lim; k += 64) cnt += Lbuf[k] < Rbuf[nR - 1 - k] ? 1u : 0u;
             u32 K = wave_sum(cnt);
@@ -631,18 +638,18 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
             u32 cut = last;
             if (K < nL) cut = Lbuf[K];
             if (K >= 1) { u32 r = Rbuf[nR - K]; cut = r < cut ? r : cut; }
-            __syncthreads();
+            WSYNC();
             if (lane == 0) { stk_first[sp] = (int)cut; stk_last[sp] = (int)last; stk_depth[sp] = depth; }
             ++sp;
             last = cut;
         }
     }
-    __syncthreads();
+    WSYNC();
     for (u32 t = lane; t < ntasks; t += 64) {
         u64 v = tasks[t];
         rs_finish_range<16>(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)(v >> 56), comp);   // ranges of <= 32 elements
     }
-    __syncthreads();
+    WSYNC();
 }
 
 // ---- blocked chaining DP (getBestChains, cluster_util.cpp:53-111) ------------------------------------------
@@ -756,16 +763,16 @@ __device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int
     DpStage G;
     dp_stage_carve(G, stage_lds, stage_bytes);
     dp_window_bounds(xs, m, jlo, lane, 64);
-    __syncthreads();
+    WSYNC();
     for (u32 t0 = 0; t0 < m; t0 += DP_TILE) {
         u32 tn = m - t0 < DP_TILE ? m - t0 : DP_TILE;
         if ((u32)lane < tn) { T.tx[lane] = xs[t0 + lane]; T.ty[lane] = ys[t0 + lane]; T.tjlo[lane] = jlo[t0 + lane]; }
         dp_stage_load(G, jlo[t0], t0, xs, ys, r, lane, 64);
-        __syncthreads();
+        WSYNC();
         for (u32 k = 0; k < tn; k++) dp_phase_a(T, G, k, t0, xs, ys, r, score_type, lane);
-        __syncthreads();
+        WSYNC();
         dp_phase_b_flush(T, tn, t0, r, score_type, lane);
-        __syncthreads();
+        WSYNC();
     }
 }
 
@@ -794,9 +801,9 @@ __device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {
 __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int *s_flag, LeaderScratch *ls) {
     int lane = lane_id();
     for (u32 i = lane; i < n; i += 64) cnt[i] = 0;
-    __syncthreads();
+    WSYNC();
     for (u32 i = lane; i < n; i += 64) cnt[r.root[i]] = 1;
-    __syncthreads();
+    WSYNC();
     u32 c = 0;
     for (u32 i = lane; i < n; i += 64) c += (u32)cnt[i];
     u32 root_num = wave_sum(c);
@@ -804,37 +811,152 @@ __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain
         for (int it = 0; it < 50; it++) {
             Tb0Scan sc = tb0_scan_wave(r, n);
             if (lane == 0) *s_flag = tb0_step(r, sc, sink, chain, chain_sc, 1, 45, 0.0f) ? 1 : 0;
-            __syncthreads();
+            WSYNC();
             int cont = *s_flag;
-            __syncthreads();
+            WSYNC();
             if (!cont) break;
         }
     } else {
         if (lane == 0) traceback1(r, n, sink, chain, chain_sc, 1, 45, 50, 0.0f, *ls);
+        WSYNC();
+    }
+}
+
+// wave-parallel twin of prefilter_chains2 (pmpfinder.cpp:2366-2446).  Cuts are visited in their (tie-sensitive) sorted
+// order; for one cut the blocks are independent, so lanes take one block each.  The pieces are re-sorted by their unique
+// end position afterwards, so the order in which lanes append them does not matter.  The j-loop's early stop
+// ("xy_strs[j] < length(hits)" in the loop condition) is the first block whose cursor reached the end of hits at the
+// start of the pass.  `sep` is the leader's Vec (its .n is broadcast through s_n); every lane returns the new count.
+__device__ u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &sep, u32 nb, u64 *cuts, u64 *xy_strs, Vec<UP> &tmp, LeaderScratch &ls) {
+    int lane = lane_id();
+    const u64 mask = 1ULL << 62;
+    UP *sp = sep.p;
+    for (u32 i = lane; i < nb; i += 64) { cuts[2 * i] = sp[i].first; cuts[2 * i + 1] = (sp[i].second - 1) | mask; xy_strs[i] = sp[i].first; }
+    WSYNC();
+    if (lane == 0) { const u64 *h = hits; ref_sort(cuts, (long)(2 * nb), [h, mask](const u64 &a, const u64 &b) { return cord_y(h[a & ~mask]) < cord_y(h[b & ~mask]); }, ls.st); }
+    WSYNC();
+    UP *tp = tmp.p;
+    u32 ntmp = 0, tcap = tmp.cap;
+    for (u32 i = 0; i < 2 * nb; i++) {
+        u64 cut = cuts[i];
+        u64 cuty = cord_y(hits[cut & ~mask]);
+        bool is_end = (cut & mask) != 0;
+        u32 jstar = nb;   // first block whose cursor already sits at the end of hits: the reference's j-loop stops there
+        for (u32 jb = 0; jb < nb; jb += 64) {
+            u32 j = jb + lane;
+            u64 mm = __ballot(j < nb && xy_strs[j] >= nhits);
+            if (mm) { jstar = jb + (u32)__builtin_ctzll(mm); break; }
+        }
+        for (u32 jb = 0; jb < jstar; jb += 64) {
+            u32 j = jb + lane;
+            bool emit = false;
+            UP piece; piece.first = 0; piece.second = 0;
+            if (j < jstar) {
+                u64 lower = xy_strs[j];
+                if (!(cuty < cord_y(hits[lower]))) {
+                    u64 kend = sp[j].second;
+                    for (u64 k = lower; k < kend; k++) {
+                        u64 ky = cord_y(hits[k]);
+                        u64 upper; bool c;
+                        if (is_end) { if (ky == cuty) { upper = k + 1; c = true; } else if (ky > cuty) { upper = k; c = true; } else c = false; }
+                        else { if (ky >= cuty) { upper = k; c = true; } else c = false; }
+                        if (c) {
+                            if (lower != upper) { emit = true; piece.first = lower; piece.second = upper; xy_strs[j] = upper; }
+                            break;
+                        }
+                    }
+                }
+            }
+            u64 em = __ballot(emit);
+            if (emit) { u32 pos = ntmp + (u32)__popcll(em & lanemask_lt()); if (pos < tcap) tp[pos] = piece; }
+            ntmp += (u32)__popcll(em);
+        }
+        WSYNC();
+    }
+    if (ntmp > tcap) { if (lane == 0) *tmp.ovf = 1; ntmp = tcap; }
+    for (u32 i = lane; i < ntmp; i += 64) sp[i] = tp[i];
+    WSYNC();
+    if (lane == 0) ref_sort(sp, (long)ntmp, [](const UP &a, const UP &b) { return a.second < b.second; }, ls.st);
+    WSYNC();
+    for (u32 i = lane; i < ntmp; i += 64) hits[sp[i].second - 1] |= F_END;
+    WSYNC();
+    return ntmp;
+}
+// wave-parallel twin of best_chains2 with getApxChainScore2 (cluster_util.cpp:469-526,586-631): serial over blocks, lanes
+// over the <= 20 predecessors; among equal totals the LAST predecessor wins (ascending scan with >=).
+__device__ void best_chains2_wave(const u64 *hits, const UP *sep, const i32 *sep_score, u32 nb, Rec r) {
+    int lane = lane_id();
+    for (u32 i = 0; i < nb; i++) {
+        int j_str = (int)i - 20 < 0 ? 0 : (int)i - 20;
+        int j = j_str + lane;
+        i64 best = -1;
+        i32 si = sep_score[i];
+        if (j < (int)i) {
+            int sc = block_score2(hits[sep[j].first], hits[sep[i].second - 1]);
+            if (sc > 0) best = ((i64)(sc + r.score[j] + si) << 32) | (i64)(u32)j;   // larger j wins ties
+        }
+        best = wave_max_i64(best);
+        if (lane == 0) {
+            int tot = best >= 0 ? (int)(best >> 32) : -1;
+            i32 li = (i32)(sep[i].second - sep[i].first);
+            if (tot > 0) {
+                int mj = (int)(u32)(best & 0xffffffff);
+                r.p2[i] = mj; r.score[i] = tot; r.len[i] = li + r.len[mj]; r.score2[i] = tot;
+                r.root[i] = r.root[mj]; r.leaf[i] = 1; r.leaf[mj] = 0;
+            } else {
+                r.p2[i] = -1; r.score[i] = si; r.len[i] = li; r.score2[i] = si; r.root[i] = (i32)i; r.leaf[i] = 1;
+            }
+        }
+        WSYNC();
+    }
+}
+
+// Block-wide form of the blocked DP for the multi-wave kernel: phase A spread over the NW waves, phase B + flush on
+// wave 0.  Every thread of the workgroup calls it (it contains workgroup barriers).
+template <int NW>
+__device__ void best_chains_block(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type, i32 *jlo, DpTile &T) {
+    int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    DpStage G;
+    dp_stage_carve(G, nullptr, 0);
+    dp_window_bounds(xs, m, jlo, tid, NW * 64);
+    __syncthreads();
+    for (u32 t0 = 0; t0 < m; t0 += DP_TILE) {
+        u32 tn = m - t0 < DP_TILE ? m - t0 : DP_TILE;
+        if (tid < (int)tn) { T.tx[tid] = xs[t0 + tid]; T.ty[tid] = ys[t0 + tid]; T.tjlo[tid] = jlo[t0 + tid]; }
+        G.st0 = (int)t0;   // no LDS stage here: every predecessor is read through xs / ys / r (LDS when the arena holds them)
+        __syncthreads();
+        for (u32 k = wave; k < tn; k += NW) dp_phase_a(T, G, k, t0, xs, ys, r, score_type, lane);
+        __syncthreads();
+        if (wave == 0) dp_phase_b_flush(T, tn, t0, r, score_type, lane);
         __syncthreads();
     }
 }
 
-// One wave per read: runs the read's jobs in order (round 0: the whole read; remap round: its gaps),
-// appending cords to the read's cord list exactly like consecutive apxMap_ calls do.
-__global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
-    extern __shared__ u32 dyn_lds[];   // binning halves
+// One workgroup per read: runs the read's jobs in order (round 0: the whole read; remap round: its gaps), appending
+// cords to the read's cord list exactly like consecutive apxMap_ calls do.
+//   NW == 1 : one wave does everything (the bulk of the reads).
+//   NW == 16: heavy reads.  Wave 0 runs every serial / wave-parallel phase with a large LDS arena; the other waves only
+//             join for the chaining DP (best_chains_block) and otherwise wait at the two workgroup barriers per job.
+struct DpShare { const u32 *xs, *ys; Rec rec; i32 *jlo; u32 m; int score_type; int abort; };
+template <int NW>
+__device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
     __shared__ u32 hist[256];
     __shared__ u32 s_m;
     __shared__ int s_ovf, s_flag;
     __shared__ u64 *s_H;
-    __shared__ u32 s_nH;
-    __shared__ LeaderScratch s_ls;   // introsort stack + tree table: one per wave, in LDS
+    __shared__ u32 s_nH, s_nhits;
+    __shared__ LeaderScratch s_ls;   // introsort stack + tree table: one per workgroup, in LDS
     __shared__ DpTile s_tile;        // tile state of the blocked chaining DP
-    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
-    u32 grp = A.grp_order[A.grp_lo + blockIdx.x];
+    __shared__ DpShare s_dp;         // NW > 1: what the helper waves need for the DP
     int lane = lane_id();
+    int wave = (int)(threadIdx.x >> 6);
+    const bool lead = NW == 1 || wave == 0;
     u32 jb = A.grp_beg[grp], je = A.grp_beg[grp + 1];
     if (jb >= je) return;
     u32 r = A.J.read[jb];
     u64 L = A.read_len[r];
-    if (lane == 0) s_ovf = 0;
-    __syncthreads();
+    if (threadIdx.x == 0) s_ovf = 0;
+    if (NW == 1) WSYNC(); else __syncthreads();
     Vec<u64> cords;
     cords.init(A.cords + A.cords_off[r], A.cords_cap[r], &s_ovf);
     cords.n = A.ncords[r];
@@ -843,159 +965,150 @@ __global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
     tk_ = clock64();
 #endif
     (void)tk_;
-    unsigned long long *prof = lane == 0 ? A.prof : nullptr;
+    unsigned long long *prof = (lead && lane == 0) ? A.prof : nullptr;
     (void)prof;
     for (u32 j = jb; j < je; j++) {
-        u64 *ag = A.anchors + A.anc_off[j];
-        u32 n = A.n_anchors[j];
-        u32 cap = A.job_cap[j] + 2;
-        LNR_TICK(prof, 0, tk_);
-        if (A.phase != 2) n = binning_wave(ag, n, dyn_lds, A.nbins);   // uses the dynamic LDS as its histogram
-        else n = A.job_nbin[j];
-        LNR_TICK(prof, 1, tk_);
-        // two-level arena: dynamic LDS first (re-used once binning is done), the job's global scratch behind it
-        Arena slow; slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
-        Arena ar; ar.init((void *)dyn_lds, A.arena_lds); ar.next = &slow;
-        u64 *a = ag;
-        u64 *s_alt = nullptr;
-        if (n > 1) {
-            u64 *alt = slow.get<u64>(cap);
-            s_alt = alt;
-            a = ar.get<u64>((u64)n + 2);          // sorted anchors move next to the lanes (LDS when they fit)
-            if (A.phase != 2) {
+        // ---------------- pre: binning, sorts, filter (leader wave)
+        u64 *a = nullptr;
+        u32 m = 0;
+        JobScratch S;
+        int mode = (int)A.J.mode[j];
+        Arena slow, ar;
+        bool ok = true;
+        if (lead) {
+            u64 *ag = A.anchors + A.anc_off[j];
+            u32 n = A.n_anchors[j];
+            u32 cap = A.job_cap[j] + 2;
+            LNR_TICK(prof, 0, tk_);
+            n = binning_wave(ag, n, dyn_lds, A.nbins);   // uses the dynamic LDS as its histogram
+            LNR_TICK(prof, 1, tk_);
+            // two-level arena: dynamic LDS first (re-used once binning is done), the job's global scratch behind it
+            slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
+            ar.init((void *)dyn_lds, A.arena_lds); ar.next = &slow;
+            a = ag;
+            u64 *s_alt = nullptr;
+            if (n > 1) {
+                u64 *alt = slow.get<u64>(cap);
+                s_alt = alt;
+                a = ar.get<u64>((u64)n + 2);          // sorted anchors move next to the lanes (LDS when they fit)
                 if (lane == 0) ag[0] = 0;   // filterAnchorsList pmpfinder.cpp:2031
-                __syncthreads();
+                WSYNC();
                 radix_sort_wave(ag, alt, n, hist);
                 for (u32 i = lane; i < n; i += 64) a[i] = ag[i];
-                __syncthreads();
+                WSYNC();
             }
-        }
-        LNR_TICK(prof, 2, tk_);
-        u32 m;
-        if (A.phase != 2) {
+            LNR_TICK(prof, 2, tk_);
             if (lane == 0) s_m = n > 1 ? filter_anchor_list(a, n) : n;   // filterAnchors1 (pmpfinder.cpp:2073-2091)
-            __syncthreads();
+            WSYNC();
             m = s_m;
-        } else m = A.job_m[j];
-        if (m > 1) {
-            // scratch of the sort: position lists in the (dead) radix buffer, task list behind it
-            u32 *Lbuf = (u32 *)s_alt, *Rbuf = Lbuf + (m + 2);
-            u64 *tasks = slow.get<u64>((u64)m + 2);
-            if (A.phase != 2) introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, &s_ls);
+            if (m > 1) {
+                // scratch of the sort: position lists in the (dead) radix buffer, task list behind it
+                u32 *Lbuf = (u32 *)s_alt, *Rbuf = Lbuf + (m + 2);
+                u64 *tasks = slow.get<u64>((u64)m + 2);
+                introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, &s_ls);
+            }
+            ok = job_carve(ar, m, S, &s_ovf) && !slow.ovf;
+            if (ok) {
+                job_fill_xy(a, m, S, (u32)lane, 64);
+                WSYNC();
+            } else if (lane == 0) s_ovf = 1;
+            LNR_TICK(prof, 3, tk_);
         }
-        JobScratch S;
-        bool ok = job_carve(ar, m, S, &s_ovf);
-        if (!ok || slow.ovf) { if (lane == 0) s_ovf = 1; __syncthreads(); break; }
-        int mode = (int)A.J.mode[j];
-        if (A.phase != 2) {
-            job_fill_xy(a, m, S, (u32)lane, 64);
+        // ---------------- chaining DP
+        if (NW == 1) {
+            if (!ok) break;
+            if (m >= 2) {
+                u32 used = (u32)((ar.off + 15) & ~15ULL);   // stage region: what is left of the dynamic LDS behind the arena
+                u32 *stage = (u32 *)((char *)dyn_lds + used);
+                u32 stage_bytes = A.lds_bytes > used ? A.lds_bytes - used : 0;
+                best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, S.cnt, s_tile, stage, stage_bytes);
+            }
+        } else {
+            if (threadIdx.x == 0) {
+                s_dp.xs = S.xs; s_dp.ys = S.ys; s_dp.rec = S.rec; s_dp.jlo = S.cnt; s_dp.m = ok ? m : 0;
+                s_dp.score_type = job_parm(mode).score_type; s_dp.abort = ok ? 0 : 1;
+            }
             __syncthreads();
-        }
-        LNR_TICK(prof, 3, tk_);
-        if (A.phase == 1) {   // heavy path: state saved, the DP runs in k_dp_big with 16 waves
-            if (lane == 0) { A.job_nbin[j] = n; A.job_m[j] = m; }
-            continue;
-        }
-        if (m >= 2 && A.phase == 0) {
-            // stage region of the blocked DP: what is left of the dynamic LDS behind the arena's fast half
-            u32 used = (u32)((ar.off + 15) & ~15ULL);
-            u32 *stage = (u32 *)((char *)dyn_lds + used);
-            u32 stage_bytes = A.lds_bytes > used ? A.lds_bytes - used : 0;
-            best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, S.cnt, s_tile, stage, stage_bytes);
+            DpShare d = s_dp;
+            if (d.abort) break;                        // uniform: every wave leaves together
+            if (d.m >= 2) best_chains_block<NW>(d.xs, d.ys, d.m, d.rec, d.score_type, d.jlo, s_tile);   // ends with a workgroup barrier
         }
         LNR_TICK(prof, 4, tk_);
-        // traceback of the anchor chains -> hits (the leader owns S.hits / S.hscore from here on)
-        AnchorSink sink; sink.anchors = a; sink.hits = &S.hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
-        if (lane == 0) { S.hits.n = 0; S.hscore.n = 0; S.hits.push(F_END); S.hscore.push(0); }
-        if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, &s_flag, &s_ls);
-        LNR_TICK(prof, 5, tk_);
-        JobCtx c;
-        c.traceback_done = 1;
-        c.L = L; c.read_str = A.J.str[j]; c.read_end = A.J.end[j]; c.mode = mode;
-        u32 nf = A.nf[r];
-        c.f1[0].p = A.f1 + A.f1_off[r]; c.f1[0].n = nf;
-        c.f1[1].p = A.f1 + A.f1_off[r] + nf; c.f1[1].n = nf;
-        c.g = A.g; c.bins = nullptr; c.nbins = 0; c.pair_evals = nullptr; c.prof = prof;
-        if (lane == 0) {   // hit blocks + block chaining (serial)
-            u64 *H = nullptr; u32 nH = 0;
-            if (job_phase3a(a, m, S, c, nullptr, H, nH, s_ls)) s_ovf = 1;
-            s_H = H; s_nH = nH;
-        }
-        __syncthreads();
-        if (s_ovf) break;
-        {
-            u64 *H = s_H; u32 nH = s_nH;
-            if (nH >= 2) {
-                filter_hits_flags(H, nH, c.f1, c.g, S.cnt, (u32)lane, 64);    // window distance of one hit per lane
-                __syncthreads();
-                if (lane == 0) s_nH = filter_hits_apply(H, nH, S.cnt);
-                __syncthreads();
-                nH = s_nH;
-                LNR_TICK(prof, 8, tk_);
-                path_dst_2(H, nH, c.f1, c.g, cords, c.read_str, c.read_end, L);   // SIMT-uniform: candidates evaluated by lanes 0..2
-                LNR_TICK(prof, 9, tk_);
+        // ---------------- post: traceback, blocks, windows (leader wave)
+        if (lead) {
+            AnchorSink sink; sink.anchors = a; sink.hits = &S.hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
+            if (lane == 0) { S.hits.n = 0; S.hscore.n = 0; S.hits.push(F_END); S.hscore.push(0); }
+            if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, &s_flag, &s_ls);
+            LNR_TICK(prof, 5, tk_);
+            JobCtx c;
+            c.traceback_done = 1;
+            c.L = L; c.read_str = A.J.str[j]; c.read_end = A.J.end[j]; c.mode = mode;
+            u32 nf = A.nf[r];
+            c.f1[0].p = A.f1 + A.f1_off[r]; c.f1[0].n = nf;
+            c.f1[1].p = A.f1 + A.f1_off[r] + nf; c.f1[1].n = nf;
+            c.g = A.g; c.bins = nullptr; c.nbins = 0; c.pair_evals = nullptr; c.prof = prof;
+            // hit blocks: gather (leader) -> prefilter (lanes over blocks) -> scores -> block DP (lanes over predecessors)
+            // -> traceback + rewrite (leader)
+            if (lane == 0) { job_blocks_gather(S, c); s_nH = S.sep.n; s_nhits = S.hits.n; }
+            WSYNC();
+            u32 nb = s_nH;
+            S.hits.n = s_nhits;   // the leader filled hits during the traceback: every lane now agrees on the count
+            nb = prefilter_chains2_wave(S.hits.p, S.hits.n, S.sep, nb, S.cuts, S.xy_strs, S.tmp, s_ls);
+            S.sep.n = nb;
+            LNR_TICK(prof, 6, tk_);
+            job_blocks_scores(S, (u32)lane, 64);
+            WSYNC();
+            BlockScratch bsx = job_block_scratch(S, s_ls);
+            if (nb >= 2) {
+                if (lane == 0) chain_blocks_prepare(S.hits.p, S.sep.p, S.sep_score, nb, 1, bsx);
+                WSYNC();
+                best_chains2_wave(S.hits.p, bsx.sep_tmp, bsx.score_tmp, nb, bsx.rec);
             }
-        }
-        __syncthreads();
+            if (lane == 0) {
+                BlockSink bs = job_block_sink(S);
+                if (nb >= 2) chain_blocks_trace(bs, nb, bsx);
+                u64 *H = nullptr; u32 nH = 0;
+                if (job_blocks_finish(a, S, bs, nullptr, H, nH)) s_ovf = 1;
+                s_H = H; s_nH = nH;
+            }
+            WSYNC();
+            LNR_TICK(prof, 7, tk_);
+            if (!s_ovf) {
+                u64 *H = s_H; u32 nH = s_nH;
+                if (nH >= 2) {
+                    filter_hits_flags(H, nH, c.f1, c.g, S.cnt, (u32)lane, 64);    // window distance of one hit per lane
+                    WSYNC();
+                    if (lane == 0) s_nH = filter_hits_apply(H, nH, S.cnt);
+                    WSYNC();
+                    nH = s_nH;
+                    LNR_TICK(prof, 8, tk_);
+                    path_dst_2(H, nH, c.f1, c.g, cords, c.read_str, c.read_end, L);   // SIMT-uniform: candidates evaluated by lanes 0..2
+                    LNR_TICK(prof, 9, tk_);
+                }
+            }
+            WSYNC();
 #ifdef LNR_PROF
-        tk_ = clock64();
+            tk_ = clock64();
 #endif
-        if (s_ovf) break;
+        }
+        if (NW == 1) { if (s_ovf) break; }
+        else {
+            __syncthreads();              // post done: the helpers may see s_ovf and the leader may reuse the LDS
+            if (s_ovf) break;             // uniform
+        }
     }
-    if (lane == 0) { A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
+    if (lead && lane == 0) { A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
 }
 
-// Heavy path, middle kernel: the blocked chaining DP of one large job with 16 waves (phase A spread over the
-// waves, phase B + flush on wave 0).  Pointers are recovered by replaying the job's (global-only) arena allocations.
-template <int NT>
-__global__ void __launch_bounds__(NT) k_dp_big(JobArgs A, const u32 *jobs, u32 njobs, u32 stage_bytes) {
-    extern __shared__ u32 dp_dyn_lds[];
-    __shared__ DpTile T;
-    if (blockIdx.x >= njobs) return;
-    u32 j = jobs[blockIdx.x];
-    u32 n = A.job_nbin[j], m = A.job_m[j];
-    if (m < 2) return;
-    u32 cap = A.job_cap[j] + 2;
-    Arena slow; slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
-    if (n > 1) { (void)slow.get<u64>(cap); (void)slow.get<u64>((u64)n + 2); }
-    if (m > 1) (void)slow.get<u64>((u64)m + 2);
-    JobScratch S;
-    int dummy = 0;
-    if (!job_carve(slow, m, S, &dummy)) return;
-    Rec r = S.rec;
-    const u32 *xs = S.xs, *ys = S.ys;
-    i32 *jlo = S.cnt;   // dead until the traceback re-initialises it
-    int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NW = NT / 64;
-    int score_type = job_parm((int)A.J.mode[j]).score_type;
-#ifdef LNR_PROF
-    unsigned long long t_begin = clock64(), wsum = 0;
-#endif
-    DpStage G;
-    dp_stage_carve(G, dp_dyn_lds, stage_bytes);
-    dp_window_bounds(xs, m, jlo, tid, NT);
-    __syncthreads();
-    for (u32 t0 = 0; t0 < m; t0 += DP_TILE) {
-        u32 tn = m - t0 < DP_TILE ? m - t0 : DP_TILE;
-        if (tid < (int)tn) { T.tx[tid] = xs[t0 + tid]; T.ty[tid] = ys[t0 + tid]; T.tjlo[tid] = jlo[t0 + tid]; }
-        dp_stage_load(G, jlo[t0], t0, xs, ys, r, tid, NT);
-        __syncthreads();
-        for (u32 k = wave; k < tn; k += NW) dp_phase_a(T, G, k, t0, xs, ys, r, score_type, lane);
-        __syncthreads();
-        if (wave == 0) dp_phase_b_flush(T, tn, t0, r, score_type, lane);
-#ifdef LNR_PROF
-        if (tid == 0) for (u32 k = 0; k < tn; k++) wsum += (unsigned long long)((int)(t0 + k) - T.tjlo[k]);
-#endif
-        __syncthreads();
-    }
-#ifdef LNR_PROF
-    if (tid == 0 && A.prof) {
-        unsigned long long dt = clock64() - t_begin;
-        unsigned long long old = atomicMax(&A.prof[12], dt);
-        if (dt > old) { A.prof[13] = m; A.prof[14] = wsum; A.prof[15] = n; }   // (racy, diagnostic only)
-        atomicAdd(&A.prof[11], wsum);
-    }
-#endif
+__global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    job_group_run<1>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
+__global__ void __launch_bounds__(1024) k_job_heavy(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    job_group_run<16>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
 }
 
 // =================================================================== tails ====
