@@ -63,6 +63,9 @@ struct lnr_ctx {
     size_t job_lds_bytes = 8 * 1024;    // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
     size_t job_stage_bytes = 0;         // LDS stage of the blocked DP's predecessor window in the fused k_job (LNR_JOB_STAGE_KB; measured slower, off)
     u32 heavy_lds_kb = 48;              // LDS arena of k_job_heavy (LNR_HEAVY_LDS_KB)
+    u32 mid_cap = 0xffffffffu, mid_lds_kb = 24;   // optional middle size class, 4 waves per read (LNR_MID_CAP, LNR_MID_LDS_KB); measured slower, off
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_join3 = nullptr;
     u32 heavy_cap = 8192;               // jobs with at least this many bucket entries take the heavy path (LNR_HEAVY_CAP overrides)
     hipStream_t stream2 = nullptr;      // heavy path runs here, concurrently with the fused k_job
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -308,18 +311,15 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             size_t lds = std::max<size_t>(lds_min, arena + ctx->job_stage_bytes);
             A.lds_bytes = (u32)lds;
             A.arena_lds = (u32)arena;
-            // heavy groups = prefix of the (weight-descending) slice
+            // three size classes along the (weight-descending) slice: heavy = 16 waves per read, mid = 4 waves, rest = 1 wave
+            auto wsum_of = [&](u32 g) { u64 w = 0; for (u32 q = ord_job_beg[g]; q < ord_job_beg[g + 1]; q++) w += cap[job_list[q]]; return w; };
             u32 gh = g0;
-            while (gh < g1) {
-                u64 wsum = 0;
-                for (u32 q = ord_job_beg[gh]; q < ord_job_beg[gh + 1]; q++) wsum += cap[job_list[q]];
-                if (wsum < ctx->heavy_cap) break;
-                gh++;
-            }
+            while (gh < g1 && wsum_of(gh) >= ctx->heavy_cap) gh++;
+            u32 gm = gh;
+            while (gm < g1 && wsum_of(gm) >= ctx->mid_cap) gm++;
             ctx->t_job.start(ctx->stream);
+            if (gh > g0 || gm > gh) HIPCK(hipEventRecord(ctx->ev_fork, ctx->stream));
             if (gh > g0) {
-                // heavy reads on stream2: one 16-wave workgroup per read with a large LDS arena
-                HIPCK(hipEventRecord(ctx->ev_fork, ctx->stream));
                 HIPCK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
                 JobArgs H = A;
                 size_t hl = std::max<size_t>(lds_min, (size_t)ctx->heavy_lds_kb * 1024);
@@ -328,12 +328,23 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
                 KCHECK();
                 HIPCK(hipEventRecord(ctx->ev_join, ctx->stream2));
             }
-            if (g1 > gh) {
-                A.grp_lo = gh; A.grp_hi = g1;
-                hipLaunchKernelGGL(k_job, dim3(g1 - gh), dim3(64), lds, ctx->stream, A);
+            if (gm > gh) {
+                HIPCK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
+                JobArgs M = A;
+                size_t ml = std::max<size_t>(lds_min, (size_t)ctx->mid_lds_kb * 1024);
+                M.grp_lo = gh; M.grp_hi = gm; M.lds_bytes = (u32)ml; M.arena_lds = (u32)ml;
+                hipLaunchKernelGGL(k_job_mid, dim3(gm - gh), dim3(256), ml, ctx->stream3, M);
+                KCHECK();
+                HIPCK(hipEventRecord(ctx->ev_join3, ctx->stream3));
+            }
+            u32 gh_all = gm;
+            if (g1 > gh_all) {
+                A.grp_lo = gh_all; A.grp_hi = g1;
+                hipLaunchKernelGGL(k_job, dim3(g1 - gh_all), dim3(64), lds, ctx->stream, A);
                 KCHECK();
             }
             if (gh > g0) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            if (gm > gh) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
             ctx->t_job.stop(ctx->stream);
         }
         HIPCK(hipStreamSynchronize(ctx->stream));
@@ -358,8 +369,8 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
         if (L >= (1ULL << 20)) { ctx->err = "read longer than 2^20-1 bases (cord y field, cords.cpp:15)"; return LNR_ERR_LIMIT; }
         B.len[i] = (u32)L;
         B.lpad[i] = (u32)align_up(L + SEQ_PAD, 16);
-        B.rp_off[i] = rp; rp += 2ULL * B.lpad[i];
-        B.pk_off[i] = po; po += packed_words(L);
+        B.rp_off[i] = rp; rp += B.lpad[i];
+        B.pk_off[i] = po; po += 2 * packed_words(L);   // forward + reverse-complement strand
         B.nf[i] = L > 200 ? read_feature_count(L) : 0;
         B.f1_off[i] = fo; fo += 2ULL * B.nf[i];
         B.cords_cap[i] = L > 200 ? (u32)(16 * (L / 64) + 256) : 0;
@@ -398,7 +409,8 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     hipLaunchKernelGGL(k_prep, dim3(n), dim3(256), 0, ctx->stream, d_reads, d_off, ctx->rp_off.as<u64>(), ctx->lpad.as<u32>(), ctx->pk_off.as<u64>(), n, ctx->reads_p.as<u8>(),
                        ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
     KCHECK();
-    hipLaunchKernelGGL(k_f1, dim3(n), dim3(256), 0, ctx->stream, ctx->reads_p.as<u8>(), ctx->rp_off.as<u64>(), ctx->lpad.as<u32>(), ctx->nf.as<u32>(), ctx->f1_off.as<u64>(), n, ctx->f1.as<F96>());
+    hipLaunchKernelGGL(k_f1, dim3(n), dim3(256), 0, ctx->stream, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->pk_off.as<u64>(), ctx->rlen.as<u32>(), ctx->nf.as<u32>(), ctx->f1_off.as<u64>(), n,
+                       ctx->f1.as<F96>());
     KCHECK();
     ctx->t_prep.stop(ctx->stream);
     ctx->stats.reads = n;
@@ -643,6 +655,9 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_JOB_STAGE_KB")) { long kb = atol(e); if (kb >= 0 && kb <= 60) ctx->job_stage_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_HEAVY_CAP")) { long v = atol(e); if (v >= 64) ctx->heavy_cap = (u32)v; }
     if (const char *e = getenv("LNR_HEAVY_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->heavy_lds_kb = (u32)v; }
+    if (const char *e = getenv("LNR_MID_CAP")) { long v = atol(e); if (v >= 64) ctx->mid_cap = (u32)v; }
+    if (const char *e = getenv("LNR_MID_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->mid_lds_kb = (u32)v; }
+    if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     ctx->t_prep.init(); ctx->t_sc.init(); ctx->t_sg.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();
@@ -664,6 +679,8 @@ void lnr_destroy(lnr_ctx *ctx) {
     ctx->t_prep.destroy(); ctx->t_sc.destroy(); ctx->t_sg.destroy(); ctx->t_job.destroy(); ctx->t_tail.destroy(); ctx->t_total.destroy();
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -282,6 +282,26 @@ LNR_HD inline void add2mer(i32 &w0, i32 &w1, i32 &w2, u32 a, u32 b) {
     u32 w = c / 5;
     if (w == 0) w0 += add; else if (w == 1) w1 += add; else w2 += add;
 }
+// 2-mer counts of the 16 two-mers that START in bases [c0, c0+16) of a 2-bit packed sequence (pk LSB-first, nm = N
+// bitmap).  A feature entry m is the sum of cells m, m+1, m+2 (48 two-mers, pmpfinder.cpp:556-588).
+LNR_HD inline void cell_2mers_packed(const u64 *pk, const u32 *nm, u64 c0, i32 &w0, i32 &w1, i32 &w2) {
+    u64 w = c0 >> 5;
+    u32 sh = (u32)(c0 & 31);
+    u64 lo = pk[w], hi = pk[w + 1];
+    u64 span = sh ? (lo >> (2 * sh)) | (hi << (64 - 2 * sh)) : lo;          // base (c0+q) at bits 2q; 17 bases needed
+    u64 nb = ((((u64)nm[w + 1] << 32) | nm[w]) >> sh) & 0x1ffffULL;         // N flags of those 17 bases
+    w0 = 0; w1 = 0; w2 = 0;
+    for (int q = 0; q < 16; q++) {
+        if ((nb >> q) & 3) continue;                                         // either base is N: not counted
+        u32 nib = (u32)(span >> (2 * q)) & 15;                               // b_q + 4*b_{q+1}
+        u32 c = ((nib & 3) << 2) | (nib >> 2);                               // 4*b_q + b_{q+1}
+        if (c == 15) continue;                                               // TT is not counted (pmpfinder.cpp:547)
+        i32 add = 1 << (6 * (c % 5));
+        u32 wi = c / 5;
+        if (wi == 0) w0 += add; else if (wi == 1) w1 += add; else w2 += add;
+    }
+}
+
 LNR_HD inline u32 read_feature_count(u64 L) {   // length of createFeatures2_48's result (pmpfinder.cpp:556-588)
     if (L < 50) return 0;
     return (u32)(1 + (L - 50) / 16);

@@ -291,9 +291,9 @@ __global__ void __launch_bounds__(256) k_f2(const u8 *g, const u64 *seq_off, con
 }
 
 // ================================================================ read prep ====
-// Padded forward copy + reverse complement (_compltRvseStr, base.cpp:335-344) of every read, the 2-bit packed
-// forward strand (+ N bitmap) the seed kernel hashes from, and the N-skip hashInit would take at the read start.
-// One block per read.
+// Per read: padded forward byte copy (seed fallback path, hashInit), both strands 2-bit packed (+ N bitmaps; the
+// reverse complement is _compltRvseStr, base.cpp:335-344) and the N-skip hashInit would take at the read start.
+// Packed layout per read: [forward words | reverse-complement words], packed_words(L) each.  One block per read.
 __global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, const u64 *rp_off, const u32 *lpad, const u64 *pk_off, u32 n, u8 *dst, u64 *pk, u32 *nm,
                                              i32 *read_ks) {
     u32 r = blockIdx.x;
@@ -301,27 +301,27 @@ __global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, con
     u64 o = off[r];
     u32 L = (u32)(off[r + 1] - o);
     u32 P = lpad[r];
-    u8 *fwd = dst + rp_off[r], *rev = fwd + P;
+    u8 *fwd = dst + rp_off[r];
     for (u32 i = threadIdx.x; i < P; i += blockDim.x) {
-        u8 a = 0, b = 0;
-        if (i < L) {
-            a = src[o + i]; if (a > 4) a = 4;
-            u8 c = src[o + L - 1 - i]; if (c > 4) c = 4;
-            b = c == 4 ? 4 : 3 - c;
-        }
+        u8 a = 0;
+        if (i < L) { a = src[o + i]; if (a > 4) a = 4; }
         fwd[i] = a;
-        rev[i] = b;
     }
     u32 nw = (u32)packed_words(L);
     u64 *pw = pk + pk_off[r];
     u32 *nw_ = nm + pk_off[r];
-    for (u32 w = threadIdx.x; w < nw; w += blockDim.x) {
+    for (u32 w = threadIdx.x; w < 2 * nw; w += blockDim.x) {
+        bool rev = w >= nw;
+        u32 base = (rev ? w - nw : w) * 32;
         u64 bits = 0; u32 nb = 0;
-        u32 base = w * 32;
         for (u32 q = 0; q < 32; q++) {
             u32 i = base + q;
             u8 a = 0;
-            if (i < L) { a = src[o + i]; if (a > 4) a = 4; }
+            if (i < L) {
+                a = src[o + (rev ? L - 1 - i : i)];
+                if (a > 4) a = 4;
+                if (rev && a < 4) a = 3 - a;
+            }
             if (a == 4) nb |= 1u << q; else bits |= (u64)a << (2 * q);
         }
         pw[w] = bits; nw_[w] = nb;
@@ -329,22 +329,30 @@ __global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, con
     __syncthreads();
     if (threadIdx.x == 0) read_ks[r] = shape_init_skip(fwd);
 }
-// read window features of both strands (createFeatures2_48 serial form, pmpfinder.cpp:556-588, in closed form)
-__global__ void __launch_bounds__(256) k_f1(const u8 *reads_p, const u64 *rp_off, const u32 *lpad, const u32 *nf, const u64 *f1_off, u32 n, F96 *f1) {
+// read window features of both strands (createFeatures2_48 serial form, pmpfinder.cpp:556-588) from the packed strands:
+// 16-base cells are counted once into LDS, an entry is the sum of three consecutive cells.
+#define F1_TILE 1024
+__global__ void __launch_bounds__(256) k_f1(const u64 *pk, const u32 *nm, const u64 *pk_off, const u32 *rlen, const u32 *nf, const u64 *f1_off, u32 n, F96 *f1) {
+    __shared__ i32 c0[F1_TILE + 2], c1[F1_TILE + 2], c2[F1_TILE + 2];
     u32 r = blockIdx.x;
     if (r >= n) return;
     u32 cnt = nf[r];
-    const u8 *fwd = reads_p + rp_off[r];
+    if (!cnt) return;
+    u32 nw = (u32)packed_words(rlen[r]);
     F96 *out = f1 + f1_off[r];
-    for (u32 e = threadIdx.x; e < 2 * cnt; e += blockDim.x) {
-        u32 strand = e >= cnt;
-        u32 m = strand ? e - cnt : e;
-        const u8 *s = fwd + (strand ? lpad[r] : 0) + 16 * m;
-        i32 w0 = 0, w1 = 0, w2 = 0;
-        u32 prev = s[0];
-        for (int j = 1; j <= 48; j++) { u32 cur = s[j]; add2mer(w0, w1, w2, prev, cur); prev = cur; }
-        F96 o; o.v0 = w0; o.v1 = w1; o.v2 = w2; o.pad = 0;
-        out[e] = o;
+    for (u32 strand = 0; strand < 2; strand++) {
+        const u64 *p = pk + pk_off[r] + (strand ? nw : 0);
+        const u32 *q = nm + pk_off[r] + (strand ? nw : 0);
+        for (u32 m0 = 0; m0 < cnt; m0 += F1_TILE) {
+            u32 me = cnt - m0 < F1_TILE ? cnt - m0 : F1_TILE;
+            for (u32 c = threadIdx.x; c < me + 2; c += blockDim.x) cell_2mers_packed(p, q, 16ULL * (m0 + c), c0[c], c1[c], c2[c]);
+            __syncthreads();
+            for (u32 e = threadIdx.x; e < me; e += blockDim.x) {
+                F96 o; o.v0 = c0[e] + c0[e + 1] + c0[e + 2]; o.v1 = c1[e] + c1[e + 1] + c1[e + 2]; o.v2 = c2[e] + c2[e + 1] + c2[e + 2]; o.pad = 0;
+                out[strand * cnt + m0 + e] = o;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1109,6 +1117,11 @@ __global__ void __launch_bounds__(1024) k_job_heavy(JobArgs A) {
     extern __shared__ u32 dyn_lds[];
     if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
     job_group_run<16>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
+__global__ void __launch_bounds__(256) k_job_mid(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    job_group_run<4>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
 }
 
 // =================================================================== tails ====

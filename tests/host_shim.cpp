@@ -278,6 +278,23 @@ u64 hs_packed_vs_bytes(const u8 *read, u64 L, u64 read_str, u64 read_end, int al
     return bad;
 }
 
+// read features computed from the packed strand via per-cell counts, written as 3 ints per entry
+u64 hs_read_features_packed(const u8 *read, u64 L, int strand, i32 *out, u64 cap) {
+    std::vector<u8> s(L + PAD, 0);
+    static const u8 cpl[5] = {3, 2, 1, 0, 4};
+    if (strand) for (u64 k = 0; k < L; k++) s[k] = cpl[read[L - 1 - k]];
+    else memcpy(s.data(), read, L);
+    u64 nw = packed_words(L) + 2;
+    std::vector<u64> pk(nw, 0);
+    std::vector<u32> nm(nw, 0);
+    for (u64 i = 0; i < L; i++) { u8 b = s[i]; if (b > 3) nm[i >> 5] |= 1u << (i & 31); else pk[i >> 5] |= (u64)b << (2 * (i & 31)); }
+    u32 nf = read_feature_count(L);
+    std::vector<i32> c0(nf + 2), c1(nf + 2), c2(nf + 2);
+    for (u32 c = 0; c < nf + 2; c++) cell_2mers_packed(pk.data(), nm.data(), 16ULL * c, c0[c], c1[c], c2[c]);
+    for (u32 m = 0; m < nf && m < cap; m++) { out[3 * m] = c0[m] + c0[m + 1] + c0[m + 2]; out[3 * m + 1] = c1[m] + c1[m + 1] + c1[m + 2]; out[3 * m + 2] = c2[m] + c2[m + 1] + c2[m + 2]; }
+    return nf;
+}
+
 // fuzz hook for ref_sort: sorts keys (compare on the high 32 bits only, descending when desc != 0)
 void hs_ref_sort_hi32(u64 *a, u64 n, int desc) {
     SortStack st;

@@ -86,3 +86,26 @@ def test_packed_minimizer_equals_byte_form(case_inputs):
                 tot += ns.value
                 fbs += fb.value
     assert tot > 50_000 and fbs < tot * 0.05
+
+
+def test_packed_cell_features_equal_byte_features(case_inputs):
+    """Window features from the 2-bit packed strands (per-cell counts summed three at a time) == byte-wise features."""
+    shimlib.build()
+    lib = C.CDLL(shimlib.SO)
+    lib.hs_read_features_packed.restype = C.c_uint64
+    lib.hs_read_features_packed.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, C.c_int, C.POINTER(C.c_int32), C.c_uint64]
+    lib.hs_read_features.restype = C.c_uint64
+    lib.hs_read_features.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, C.c_int, C.POINTER(C.c_int32), C.c_uint64]
+    for name in ("ont", "edge"):
+        refs, reads, off = case_inputs(name)
+        for i in range(0, off.size - 1, 3):
+            rd = np.ascontiguousarray(reads[int(off[i]):int(off[i + 1])])
+            if rd.size <= 200:
+                continue
+            cap = rd.size // 16 + 8
+            for strand in (0, 1):
+                a = np.zeros((cap, 3), np.int32)
+                b = np.zeros((cap, 3), np.int32)
+                na = lib.hs_read_features(rd.ctypes.data_as(C.POINTER(C.c_uint8)), rd.size, strand, a.ctypes.data_as(C.POINTER(C.c_int32)), cap)
+                nb = lib.hs_read_features_packed(rd.ctypes.data_as(C.POINTER(C.c_uint8)), rd.size, strand, b.ctypes.data_as(C.POINTER(C.c_int32)), cap)
+                assert na == nb and np.array_equal(a[:na], b[:nb]), f"{name} read {i} strand {strand}"
