@@ -257,11 +257,26 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
     u64 budget = ctx->opts.scratch_budget ? ctx->opts.scratch_budget : (24ULL << 30);
     u32 ngrp = (u32)hj.grp_beg.size() - 1;
     std::vector<u32> order(ngrp);
-    for (u32 g = 0; g < ngrp; g++) order[g] = g;
-    if (with_job_kernel) {
+    {
+        // counting sort by weight class, heaviest first: classes are 1/8-octave steps of the group's bucket-entry sum, so
+        // the order is "descending up to 9 %" -- all the scheduler needs -- in O(n)
         std::vector<u64> w(ngrp, 0);
         for (u32 g = 0; g < ngrp; g++) for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) w[g] += cap[j];
-        std::stable_sort(order.begin(), order.end(), [&w](u32 a, u32 b) { return w[a] > w[b]; });
+        auto cls = [](u64 v) -> u32 {
+            if (v < 8) return (u32)v;
+            int lg = 63 - __builtin_clzll(v);
+            return (u32)(8 * (lg - 2) + ((v >> (lg - 3)) & 7));
+        };
+        const u32 NCLS = 8 * 64;
+        std::vector<u32> cnt(NCLS + 1, 0);
+        std::vector<u32> gc(ngrp);
+        for (u32 g = 0; g < ngrp; g++) { gc[g] = NCLS - 1 - std::min<u32>(cls(w[g]), NCLS - 1); cnt[gc[g] + 1]++; }
+        for (u32 c = 0; c < NCLS; c++) cnt[c + 1] += cnt[c];
+        for (u32 g = 0; g < ngrp; g++) order[cnt[gc[g]]++] = g;
+        // the heavy prefix is small: put it in exact descending order (the size-class cut below walks it)
+        u32 nh = 0;
+        while (nh < ngrp && w[order[nh]] >= std::min<u64>(ctx->heavy_cap, ctx->mid_cap) / 2) nh++;
+        std::stable_sort(order.begin(), order.begin() + nh, [&w](u32 a, u32 b) { return w[a] > w[b]; });
     }
     std::vector<u32> job_list;
     job_list.reserve(nj);
