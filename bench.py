@@ -34,6 +34,21 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def recorded_traffic(args, launches_per_step):
+    """HBM-side bytes per k_seed_fused launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_seed_fused.json,
+    made by tools/pmc_summary.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  Counters cannot
+    be read from inside the process, so the figure is only reported when the workload is the one the passes were taken on."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_seed_fused.json")
+    if not os.path.exists(p):
+        return None
+    rec = json.load(open(p))
+    key = {"reads": args.reads, "read_len": args.read_len, "err": args.err, "layout_threads": args.layout_threads,
+           "small": bool(args.small), "seed_only": bool(args.seed_only)}
+    if rec.get("workload") != key or abs(rec.get("launches_per_step", 0) - launches_per_step) > 1e-9:
+        return None
+    return {"bytes_per_launch": rec["traffic_bytes_per_launch"], "source": rec["source"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,9 +144,13 @@ def main():
 
     st = flt.stats()
     K = max(args.steps, 1)
-    seed_ms = (acc["seed_count_ms"] + acc["seed_gather_ms"]) / K      # per launch pair (one pass over the batch)
-    seed_bytes = acc["seed_bytes"] / K
+    # k_seed_fused: one launch per round (round 0 = whole reads, round 1 = the re-mapped gaps); timed by the library with
+    # HIP events recorded on the stream the kernel is launched on (lnr_api.hip run_jobs, Timer t_sc)
+    launches = max(int(acc["seed_count_launches"]), 1)
+    seed_ms = acc["seed_count_ms"] / launches
+    seed_bytes = acc["seed_bytes"] / launches
     achieved = seed_bytes / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
+    traffic = recorded_traffic(args, launches / K)
 
     out = {
         "metric": "reads/sec (whole node) + HBM GB/s on seed lookup, 10 kb reads vs GRCh38",
@@ -157,19 +176,21 @@ def main():
             "index_bytes": bcast["bytes"] if bcast else None,
             "per_read": {"samples": st["samples"] / args.reads, "lookups": st["lookups"] / args.reads, "bucket_entries": st["bucket_entries"] / args.reads,
                          "anchors": st["anchors"] / args.reads, "cords": st["cords"] / args.reads, "remap_reads": st["remap_reads"]},
-            "stage_ms_per_step": {"prep": acc["prep_ms"] / K, "seed_count": acc["seed_count_ms"] / K, "seed_gather": acc["seed_gather_ms"] / K,
+            "stage_ms_per_step": {"prep": acc["prep_ms"] / K, "seed": acc["seed_count_ms"] / K,
                                   "job": acc["job_ms"] / K, "tail": acc["tail_ms"] / K, "total_device": acc["total_ms"] / K},
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "seed lookup = k_seed_count + k_seed_gather (one launch each per batch)",
+            "kernel": "k_seed_fused (minimizers of the 2-bit packed read -> bucket bitmap -> dir -> hs -> Y filter -> anchors), "
+                      f"{launches / K:g} launches per step, averages per launch",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": seed_bytes,
             "launch_ms": seed_ms,
-            "traffic": None,
+            "traffic": traffic["bytes_per_launch"] if traffic else None,
+            "traffic_source": traffic["source"] if traffic else None,
         },
     }
 
