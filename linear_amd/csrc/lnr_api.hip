@@ -77,7 +77,7 @@ struct lnr_ctx {
     DevBuf tail_scr, tail_off, tail_cap, gaps, gaps_off, gaps_cap, ngaps, remap;
     // ---- jobs
     DevBuf j_read, j_str, j_end, j_mode, j_cap, j_look, j_anc_off, j_scr_off, j_nanc, grp_beg, grp_order, job_list;
-    DevBuf anchors, job_scr, prof, seed_ctl;   // seed_ctl: allocator cursor + overflow flag
+    DevBuf anchors, job_scr, prof, tl, seed_ctl; u32 tl_round = 0, tl_n[4] = {0, 0, 0, 0}; u32 tl_nh[4] = {0, 0, 0, 0};   // seed_ctl: allocator cursor + overflow flag
     u64 anc_slots_per_job = 1536;       // running estimate of anchor slots per job (grows on overflow)
     // ---- results
     DevBuf r_off, r_str, r_end;
@@ -318,8 +318,14 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             A.nbins = ctx->nbins; A.grp_lo = g0; A.grp_hi = g1;
             A.prof = nullptr;
 #ifdef LNR_PROF
-            if (!ctx->prof.p) { if (!ctx->prof.ensure(32 * 8)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->prof.p, 0, 32 * 8, ctx->stream); }
+            if (!ctx->prof.p) { if (!ctx->prof.ensure(128 * 8)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->prof.p, 0, 128 * 8, ctx->stream); }
             A.prof = ctx->prof.as<unsigned long long>();
+            // timeline: up to 4 launches (rounds) of up to 2^20 positions
+            if (!ctx->tl.p) { if (!ctx->tl.ensure(4ULL * (1u << 20) * 32)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->tl.p, 0, 4ULL * (1u << 20) * 32, ctx->stream); }
+            A.tl = nullptr;
+            if (ctx->tl_round < 4 && g1 <= (1u << 20)) { A.tl = ctx->tl.as<unsigned long long>() + (size_t)ctx->tl_round * (1u << 20) * 4; ctx->tl_n[ctx->tl_round] = g1; }
+#else
+            A.tl = nullptr;
 #endif
             size_t lds_min = (((size_t)((ctx->nbins + 1) / 2) * 4) + 15) & ~(size_t)15;
             size_t arena = (ctx->job_lds_bytes + 15) & ~(size_t)15;
@@ -332,6 +338,10 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             while (gh < g1 && wsum_of(gh) >= ctx->heavy_cap) gh++;
             u32 gm = gh;
             while (gm < g1 && wsum_of(gm) >= ctx->mid_cap) gm++;
+#ifdef LNR_PROF
+            if (ctx->tl_round < 4) ctx->tl_nh[ctx->tl_round] = gh;
+            ctx->tl_round++;
+#endif
             ctx->t_job.start(ctx->stream);
             if (gh > g0 || gm > gh) HIPCK(hipEventRecord(ctx->ev_fork, ctx->stream));
             if (gh > g0) {
@@ -932,10 +942,19 @@ lnr_status lnr_seed_lookup_batch(lnr_ctx *ctx, const uint8_t *reads, const uint6
 
 #ifdef LNR_PROF
 // diagnostic build only: cumulative per-phase cycle sums of k_job's lane 0 (16 counters)
+// diagnostic build: timeline of launch `round` (4 x u64 per launch position); returns positions, *n_heavy = size of the heavy prefix
+long long lnr_prof_timeline(lnr_ctx *ctx, unsigned round, unsigned long long *out, unsigned long long cap_positions, unsigned *n_heavy) {
+    if (!ctx || round >= 4 || !ctx->tl.p) return -1;
+    unsigned long long n = ctx->tl_n[round] < cap_positions ? ctx->tl_n[round] : cap_positions;
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    if (hipMemcpy(out, ctx->tl.as<unsigned long long>() + (size_t)round * (1u << 20) * 4, n * 32, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (n_heavy) *n_heavy = ctx->tl_nh[round];
+    return (long long)n;
+}
 lnr_status lnr_prof_read(lnr_ctx *ctx, unsigned long long *out16) {
     if (!ctx || !out16 || !ctx->prof.p) return LNR_ERR_ARG;
     HIPCK(hipStreamSynchronize(ctx->stream));
-    HIPCK(hipMemcpy(out16, ctx->prof.p, 32 * 8, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(out16, ctx->prof.p, 128 * 8, hipMemcpyDeviceToHost));
     return LNR_OK;
 }
 #endif

@@ -502,6 +502,7 @@ struct JobArgs {
     u32 lds_bytes;          // dynamic LDS per block: binning histogram first, then the fast half of the job arena
     u32 arena_lds;          // bytes of that LDS the job arena may use
     unsigned long long *prof;   // diagnostic build (-DLNR_PROF) only: per-phase cycle sums of lane 0
+    unsigned long long *tl;     // diagnostic build only: per launch position {start, end (100 MHz ticks), hw id, anchors in the DP}
 };
 
 // wave-parallel twin of binning_filter_serial: LDS histogram of anchor x-field / 30000 (saturating u16
@@ -660,21 +661,24 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
     WSYNC();
 }
 
-// ---- blocked chaining DP (getBestChains, cluster_util.cpp:53-111) ------------------------------------------
-// The recurrence is serial in i only through predecessors a short distance back, so anchors are processed in tiles
-// of 64:
-//   phase A (no dependencies): for every anchor of the tile, the best (total, smallest j) over its predecessors that
-//            lie BEFORE the tile -- their chain scores are final;
-//   phase B (one wave, LDS only): the anchors of the tile in order, lanes over the in-tile predecessors, merged with
-//            the phase-A candidate under the same key (max total, ties -> smallest j);
-//   flush : the tile's score/len/root/p2/leaf go to the job's arrays once.
-// Window bounds j_lo(i) depend on x only (dp_window_bounds).
+// ---- tiled chaining DP (getBestChains, cluster_util.cpp:53-111) ---------------------------------------------
+// Anchors are processed in tiles of 64 with ONE ANCHOR PER LANE; predecessors are the uniform operand:
+//   before-tile : the predecessors [j_lo(t0), t0) -- their chain scores are final -- are loaded 64 at a time, one per lane
+//                 (coalesced), and broadcast one by one out of registers (v_readlane -> SGPR operands); every lane scores
+//                 the broadcast predecessor against its own anchor.  No memory access and no cross-lane reduction inside
+//                 the 64 steps of a chunk, so the loop runs at VALU rate.  A multi-wave workgroup deals the chunks out
+//                 over its waves and merges the per-wave candidates through LDS;
+//   in-tile     : step l broadcasts anchor t0+l, whose score is final once steps < l are done, to the lanes k > l;
+//   finish      : len / root follow the chosen predecessor: a gather for a before-tile predecessor, pointer jumping over
+//                 lane registers for in-tile chains; one coalesced store of the tile's score / len / root / p2 / leaf.
+// The reference scans j downwards and keeps the later (smaller) j on equal totals (`>= best`): the candidate key is
+// (total << 32 | 0x7fffffff - j), maximised.  Window bounds j_lo(i) depend on x only (dp_window_bounds) and are
+// non-decreasing, so j_lo(t0) bounds the whole tile.
 #define DP_TILE 64
+template <int NW>
 struct DpTile {
-    u32 tx[DP_TILE], ty[DP_TILE];
-    i32 ts[DP_TILE], tlen[DP_TILE], troot[DP_TILE], tjlo[DP_TILE], tp2[DP_TILE], tleaf[DP_TILE];
-    long long tkey[DP_TILE];
-    i32 talen[DP_TILE], taroot[DP_TILE];   // len / root of the phase-A candidate (prefetched)
+    long long wkey[NW > 1 ? NW : 1][DP_TILE];   // per-wave before-tile candidates (multi-wave workgroups only)
+    i32 tleaf[DP_TILE];
 };
 // j_lo(i) = min(first j with xs[j] - xs[i] < 300, max(0, i - 20)); xs is non-increasing -> binary search
 __device__ __forceinline__ void dp_window_bounds(const u32 *xs, u32 m, i32 *jlo, int tid, int nthreads) {
@@ -687,101 +691,88 @@ __device__ __forceinline__ void dp_window_bounds(const u32 *xs, u32 m, i32 *jlo,
     }
 }
 __device__ __forceinline__ i64 dp_key(int total, int j) { return ((i64)total << 32) | (i64)(u32)(0x7fffffff - j); }
-// Staged predecessor range of a tile.  j_lo is non-decreasing in i, so the union of the tile's windows is the
-// contiguous range [tjlo[0], t0); its x / y / score / len / root are copied to LDS once per tile (coalesced) and
-// phase A reads only LDS.  Entries below st0 (window longer than the stage) are read from the global arrays.
-struct DpStage { u32 *x, *y; i32 *sc, *len, *root; u32 cap; int st0; };
-__device__ __forceinline__ void dp_stage_carve(DpStage &G, u32 *lds, u32 bytes) {
-    G.cap = bytes / 20;
-    G.x = lds; G.y = lds + G.cap; G.sc = (i32 *)(lds + 2 * (size_t)G.cap); G.len = (i32 *)(lds + 3 * (size_t)G.cap); G.root = (i32 *)(lds + 4 * (size_t)G.cap);
-    G.st0 = 0;
+template <int ST>
+__device__ __forceinline__ void dp_eval(i64 &best, u32 px, u32 py, i32 ps, int jj, u32 xi, u32 yi, bool act) {
+    int sc = ST ? chain_score0(px, py, xi, yi) : chain_score(px, py, xi, yi);
+    if (act && sc > 0) { i64 key = dp_key(sc + ps, jj); best = key > best ? key : best; }
 }
-__device__ __forceinline__ void dp_stage_load(DpStage &G, int rlo, u32 t0, const u32 *xs, const u32 *ys, const Rec &r, int tid, int nthreads) {
-    int st0 = (int)t0 - (int)G.cap;
-    if (st0 < rlo) st0 = rlo;
-    G.st0 = st0;
-    for (int jj = st0 + tid; jj < (int)t0; jj += nthreads) {
-        int o = jj - st0;
-        G.x[o] = xs[jj]; G.y[o] = ys[jj]; G.sc[o] = r.score[jj]; G.len[o] = r.len[jj]; G.root[o] = r.root[jj];
-    }
-}
-// phase A for tile anchor k by one wave
-__device__ __forceinline__ void dp_phase_a(DpTile &T, const DpStage &G, u32 k, u32 t0, const u32 *xs, const u32 *ys, const Rec &r, int score_type, int lane) {
-    u32 xi = T.tx[k], yi = T.ty[k];
-    int jl = T.tjlo[k];
-    i64 best = -1;
-    int jstage = jl > G.st0 ? jl : G.st0;
-    for (int jj = (int)t0 - 1 - lane; jj >= jstage; jj -= 64) {
-        int o = jj - G.st0;
-        int sc = score_type ? chain_score0(G.x[o], G.y[o], xi, yi) : chain_score(G.x[o], G.y[o], xi, yi);
-        if (sc > 0) { i64 key = dp_key(sc + G.sc[o], jj); best = key > best ? key : best; }
-    }
-    for (int jj = G.st0 - 1 - lane; jj >= jl; jj -= 64) {   // rare: part of the window below the stage
-        int sc = score_type ? chain_score0(xs[jj], ys[jj], xi, yi) : chain_score(xs[jj], ys[jj], xi, yi);
-        if (sc > 0) { i64 key = dp_key(sc + r.score[jj], jj); best = key > best ? key : best; }
-    }
-    best = wave_max_i64(best);
-    if (lane == 0) {
-        T.tkey[k] = best;
-        if (best >= 0) {
-            int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff);
-            if (mj >= G.st0) { T.talen[k] = G.len[mj - G.st0]; T.taroot[k] = G.root[mj - G.st0]; }
-            else { T.talen[k] = r.len[mj]; T.taroot[k] = r.root[mj]; }
-        }
-    }
-}
-// phase B + flush by one wave; before-tile leaf clears are plain global stores nobody reads during the DP
-__device__ __forceinline__ void dp_phase_b_flush(DpTile &T, u32 tn, u32 t0, Rec &r, int score_type, int lane) {
-    if ((u32)lane < tn) T.tleaf[lane] = 1;
-    for (u32 k = 0; k < tn; k++) {
-        u32 xi = T.tx[k], yi = T.ty[k];
-        int jl = T.tjlo[k];
-        i64 best = -1;
-        if ((u32)lane < k && (int)(t0 + lane) >= jl) {
-            int sc = score_type ? chain_score0(T.tx[lane], T.ty[lane], xi, yi) : chain_score(T.tx[lane], T.ty[lane], xi, yi);
-            if (sc > 0) best = dp_key(sc + T.ts[lane], (int)(t0 + lane));
-        }
-        best = wave_max_i64(best);
-        if (lane == 0) {
-            i64 ka = T.tkey[k];
-            if (ka > best) {   // the before-tile candidate wins (keys are distinct: they encode j)
-                int mj = 0x7fffffff - (int)(u32)(ka & 0xffffffff);
-                T.ts[k] = (int)(ka >> 32); T.tlen[k] = T.talen[k] + 1; T.troot[k] = T.taroot[k]; T.tp2[k] = mj;
-                r.leaf[mj] = 0;
-            } else if (best >= 0) {
-                int mj = 0x7fffffff - (int)(u32)(best & 0xffffffff);
-                int l = mj - (int)t0;
-                T.ts[k] = (int)(best >> 32); T.tlen[k] = T.tlen[l] + 1; T.troot[k] = T.troot[l]; T.tp2[k] = mj;
-                T.tleaf[l] = 0;
-            } else {
-                T.ts[k] = 0; T.tlen[k] = 1; T.troot[k] = (i32)(t0 + k); T.tp2[k] = -1;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();   // LDS is in-order per wave: later lanes' reads see the leader's writes
-    }
-    if ((u32)lane < tn) {
-        u32 i = t0 + lane;
-        i32 v = T.ts[lane];
-        r.score[i] = v; r.score2[i] = v; r.len[i] = T.tlen[lane]; r.root[i] = T.troot[lane]; r.p2[i] = T.tp2[lane]; r.leaf[i] = T.tleaf[lane];
-    }
-}
-// one-wave driver (fused k_job)
-__device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type, i32 *jlo, DpTile &T, u32 *stage_lds, u32 stage_bytes) {
+// before-tile candidates of this wave's share of the chunks; jl = the lane's j_lo (INT_MAX for an idle lane)
+template <int ST>
+__device__ __forceinline__ i64 dp_before_tile(const u32 *xs, const u32 *ys, const i32 *score, int t0, int lo, u32 xi, u32 yi, int jl, int wave, int nw) {
     int lane = lane_id();
-    DpStage G;
-    dp_stage_carve(G, stage_lds, stage_bytes);
+    i64 best = -1;
+    for (int top = t0 - 64 * wave; top > lo; top -= 64 * nw) {   // chunk = predecessors top-1, top-2, ... (at most 64, not below lo)
+        int jl_ = top - 1 - lane;
+        u32 px = 0, py = 0; i32 ps = 0;
+        if (jl_ >= lo) { px = xs[jl_]; py = ys[jl_]; ps = score[jl_]; }
+        int cnt = top - lo < 64 ? top - lo : 64;
+        for (int s_ = 0; s_ < cnt; s_++) {
+            u32 qx = (u32)__builtin_amdgcn_readlane((int)px, s_), qy = (u32)__builtin_amdgcn_readlane((int)py, s_);
+            i32 qs = __builtin_amdgcn_readlane(ps, s_);
+            int jj = top - 1 - s_;
+            dp_eval<ST>(best, qx, qy, qs, jj, xi, yi, jj >= jl);
+        }
+    }
+    return best;
+}
+// in-tile steps, finish and store by ONE wave; `best` = merged before-tile candidate of the lane's anchor
+template <int ST>
+__device__ __forceinline__ void dp_in_tile_finish(i32 *tleaf, int t0, int tn, u32 xi, u32 yi, int jl, i64 best, Rec &r) {
+    int lane = lane_id();
+    for (int l = 0; l + 1 < tn; l++) {
+        i32 mysc = best >= 0 ? (i32)(best >> 32) : 0;    // final for lane l at step l
+        u32 qx = (u32)__builtin_amdgcn_readlane((int)xi, l), qy = (u32)__builtin_amdgcn_readlane((int)yi, l);
+        i32 qs = __builtin_amdgcn_readlane(mysc, l);
+        int jj = t0 + l;
+        dp_eval<ST>(best, qx, qy, qs, jj, xi, yi, lane > l && jj >= jl);
+    }
+    bool live = lane < tn;
+    bool has = live && best >= 0;
+    int mj = has ? 0x7fffffff - (int)(u32)(best & 0xffffffff) : -1;
+    i32 sc = has ? (i32)(best >> 32) : 0;
+    int par = (has && mj >= t0) ? mj - t0 : -1;
+    i32 len = 1, root = t0 + lane;
+    if (has && mj < t0) { len = r.len[mj] + 1; root = r.root[mj]; r.leaf[mj] = 0; }
+    tleaf[lane] = 1;
+    __builtin_amdgcn_wave_barrier();
+    if (par >= 0) tleaf[par] = 0;
+    // chains inside the tile: pointer jumping.  acc = anchors from this one up to (not including) par.
+    i32 acc = 1;
+    bool unres = par >= 0;
+    while (__ballot(unres)) {
+        int src = par < 0 ? lane : par;
+        int p_par = __shfl(par, src); i32 p_len = __shfl(len, src), p_root = __shfl(root, src), p_acc = __shfl(acc, src);
+        int p_unres = __shfl((int)unres, src);
+        if (unres) {
+            if (!p_unres) { len = acc + p_len; root = p_root; unres = false; }
+            else { acc += p_acc; par = p_par; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+        u32 i = (u32)(t0 + lane);
+        r.score[i] = sc; r.score2[i] = sc; r.len[i] = len; r.root[i] = root; r.p2[i] = mj; r.leaf[i] = tleaf[lane];
+    }
+}
+template <int ST>
+__device__ void best_chains_wave_t(const u32 *xs, const u32 *ys, u32 m, Rec r, i32 *jlo, i32 *tleaf) {
+    int lane = lane_id();
     dp_window_bounds(xs, m, jlo, lane, 64);
     WSYNC();
     for (u32 t0 = 0; t0 < m; t0 += DP_TILE) {
-        u32 tn = m - t0 < DP_TILE ? m - t0 : DP_TILE;
-        if ((u32)lane < tn) { T.tx[lane] = xs[t0 + lane]; T.ty[lane] = ys[t0 + lane]; T.tjlo[lane] = jlo[t0 + lane]; }
-        dp_stage_load(G, jlo[t0], t0, xs, ys, r, lane, 64);
-        WSYNC();
-        for (u32 k = 0; k < tn; k++) dp_phase_a(T, G, k, t0, xs, ys, r, score_type, lane);
-        WSYNC();
-        dp_phase_b_flush(T, tn, t0, r, score_type, lane);
+        int tn = (int)(m - t0 < DP_TILE ? m - t0 : DP_TILE);
+        u32 xi = 0, yi = 0; int jl = 0x7fffffff;
+        if (lane < tn) { xi = xs[t0 + lane]; yi = ys[t0 + lane]; jl = jlo[t0 + lane]; }
+        int lo = __builtin_amdgcn_readfirstlane(jl);
+        i64 best = dp_before_tile<ST>(xs, ys, r.score, (int)t0, lo, xi, yi, jl, 0, 1);
+        dp_in_tile_finish<ST>(tleaf, (int)t0, tn, xi, yi, jl, best, r);
         WSYNC();
     }
+}
+// one-wave driver (k_job)
+__device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type, i32 *jlo, i32 *tleaf) {
+    if (score_type) best_chains_wave_t<1>(xs, ys, m, r, jlo, tleaf);
+    else best_chains_wave_t<0>(xs, ys, m, r, jlo, tleaf);
 }
 
 // wave-parallel twin of tb0_scan_serial: first index of the maximal score (> -1), the running maximum seen before
@@ -919,25 +910,33 @@ __device__ void best_chains2_wave(const u64 *hits, const UP *sep, const i32 *sep
     }
 }
 
-// Block-wide form of the blocked DP for the multi-wave kernel: phase A spread over the NW waves, phase B + flush on
-// wave 0.  Every thread of the workgroup calls it (it contains workgroup barriers).
-template <int NW>
-__device__ void best_chains_block(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type, i32 *jlo, DpTile &T) {
+// Workgroup form of the tiled DP for the multi-wave kernels: the before-tile chunks are dealt out over the NW waves,
+// wave 0 merges the candidates and runs the in-tile steps.  Every thread of the workgroup calls it (workgroup barriers).
+template <int NW, int ST>
+__device__ void best_chains_block_t(const u32 *xs, const u32 *ys, u32 m, Rec r, i32 *jlo, DpTile<NW> &T) {
     int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    DpStage G;
-    dp_stage_carve(G, nullptr, 0);
     dp_window_bounds(xs, m, jlo, tid, NW * 64);
     __syncthreads();
     for (u32 t0 = 0; t0 < m; t0 += DP_TILE) {
-        u32 tn = m - t0 < DP_TILE ? m - t0 : DP_TILE;
-        if (tid < (int)tn) { T.tx[tid] = xs[t0 + tid]; T.ty[tid] = ys[t0 + tid]; T.tjlo[tid] = jlo[t0 + tid]; }
-        G.st0 = (int)t0;   // no LDS stage here: every predecessor is read through xs / ys / r (LDS when the arena holds them)
+        int tn = (int)(m - t0 < DP_TILE ? m - t0 : DP_TILE);
+        u32 xi = 0, yi = 0; int jl = 0x7fffffff;
+        if (lane < tn) { xi = xs[t0 + lane]; yi = ys[t0 + lane]; jl = jlo[t0 + lane]; }
+        int lo = __builtin_amdgcn_readfirstlane(jl);
+        T.wkey[wave][lane] = dp_before_tile<ST>(xs, ys, r.score, (int)t0, lo, xi, yi, jl, wave, NW);
         __syncthreads();
-        for (u32 k = wave; k < tn; k += NW) dp_phase_a(T, G, k, t0, xs, ys, r, score_type, lane);
-        __syncthreads();
-        if (wave == 0) dp_phase_b_flush(T, tn, t0, r, score_type, lane);
+        if (wave == 0) {
+            i64 best = -1;
+#pragma unroll
+            for (int w = 0; w < NW; w++) { i64 v = T.wkey[w][lane]; best = v > best ? v : best; }
+            dp_in_tile_finish<ST>(T.tleaf, (int)t0, tn, xi, yi, jl, best, r);
+        }
         __syncthreads();
     }
+}
+template <int NW>
+__device__ void best_chains_block(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type, i32 *jlo, DpTile<NW> &T) {
+    if (score_type) best_chains_block_t<NW, 1>(xs, ys, m, r, jlo, T);
+    else best_chains_block_t<NW, 0>(xs, ys, m, r, jlo, T);
 }
 
 // One workgroup per read: runs the read's jobs in order (round 0: the whole read; remap round: its gaps), appending
@@ -954,7 +953,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
     __shared__ u64 *s_H;
     __shared__ u32 s_nH, s_nhits;
     __shared__ LeaderScratch s_ls;   // introsort stack + tree table: one per workgroup, in LDS
-    __shared__ DpTile s_tile;        // tile state of the blocked chaining DP
+    __shared__ DpTile<NW> s_tile;    // tiled chaining DP: leaf flags (+ the per-wave candidates of a multi-wave workgroup)
     __shared__ DpShare s_dp;         // NW > 1: what the helper waves need for the DP
     int lane = lane_id();
     int wave = (int)(threadIdx.x >> 6);
@@ -971,9 +970,12 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
     unsigned long long tk_ = 0;
 #ifdef LNR_PROF
     tk_ = clock64();
+    unsigned long long *tl = (lead && lane == 0 && A.tl) ? A.tl + 4 * (size_t)(A.grp_lo + blockIdx.x) : nullptr;
+    if (tl) { tl[0] = wall_clock64(); tl[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); tl[3] = 0; }
 #endif
     (void)tk_;
-    unsigned long long *prof = (lead && lane == 0) ? A.prof : nullptr;
+    // diagnostic build: 4 stamp classes of 32 slots = (multi-wave kernel) x 2 + (re-map round)
+    unsigned long long *prof = (lead && lane == 0 && A.prof) ? A.prof + 32 * ((NW > 1 ? 2 : 0) + (A.J.mode[jb] ? 1 : 0)) : nullptr;
     (void)prof;
     for (u32 j = jb; j < je; j++) {
         // ---------------- pre: binning, sorts, filter (leader wave)
@@ -1022,14 +1024,20 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             } else if (lane == 0) s_ovf = 1;
             LNR_TICK(prof, 3, tk_);
         }
+#ifdef LNR_PROF
+        if (prof) {   // job count, anchors entering the DP, predecessor pairs
+            unsigned long long pairs = 0;
+            if (ok && m >= 2) { u32 p300 = 0; for (u32 i = 0; i < m; i++) { while (p300 < i && S.xs[p300] - S.xs[i] >= 300) p300++; u32 js = i > 20 ? i - 20 : 0; pairs += i - (p300 < js ? p300 : js); } }
+            if (tl) tl[3] += ((unsigned long long)m << 32) | (pairs > 0xffffffffULL ? 0xffffffffULL : pairs);
+            atomicAdd(&prof[10], 1ULL); atomicAdd(&prof[11], (unsigned long long)m); atomicAdd(&prof[12], pairs); atomicAdd(&prof[13], (unsigned long long)A.n_anchors[j]);
+            tk_ = clock64();
+        }
+#endif
         // ---------------- chaining DP
         if (NW == 1) {
             if (!ok) break;
             if (m >= 2) {
-                u32 used = (u32)((ar.off + 15) & ~15ULL);   // stage region: what is left of the dynamic LDS behind the arena
-                u32 *stage = (u32 *)((char *)dyn_lds + used);
-                u32 stage_bytes = A.lds_bytes > used ? A.lds_bytes - used : 0;
-                best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, S.cnt, s_tile, stage, stage_bytes);
+                best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, S.cnt, s_tile.tleaf);
             }
         } else {
             if (threadIdx.x == 0) {
@@ -1106,6 +1114,9 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
         }
     }
     if (lead && lane == 0) { A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
+#ifdef LNR_PROF
+    if (tl) tl[1] = wall_clock64();
+#endif
 }
 
 __global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {

@@ -18,14 +18,48 @@ f.build_index([ref], 1)
 d_ref = torch.from_numpy(ref).cuda()
 d_reads, d_off = sample_reads_cuda(d_ref, n, 10000, 0.10, 777, non_n_start=10_510_000)
 f.filter_batch_dev(d_reads.data_ptr(), d_off.data_ptr(), n)
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 128)()
 f.lib.lnr_prof_read.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert f.lib.lnr_prof_read(f.h, out) == 0
-names = ["carve+setup", "binning", "radix sort", "phase1: filter list + introsort + xs/ys", "chain DP (wave)", "traceback", "gather_blocks + prefilter_chains2",
+names = ["carve+setup", "binning", "radix sort", "phase1: filter list + introsort + xs/ys", "chain DP", "traceback", "gather_blocks + prefilter_chains2",
          "chain_blocks + filter_blocks_hits", "filter_hits (window dist)", "path_dst_2 (extension)"]
-tot = sum(out[:10])
 print("stats", f.stats())
-for i, nm in enumerate(names):
-    print(f"{nm:45s} {out[i] / 1e6:12.1f} Mcycles  {100.0 * out[i] / max(tot, 1):5.1f} %   max single job-phase {out[16 + i] / 1e6:9.2f} Mcycles")
-print("cycles per job (lane 0 sum):", tot / max(f.stats()['jobs'], 1))
-print(f"k_dp_big: slowest block {out[12] / 1e6:.1f} Mcycles, its m = {out[13]}, its sum of windows = {out[14]} (avg window {out[14] / max(out[13], 1):.0f}), n after binning = {out[15]}; sum of windows over all heavy jobs = {out[11]}")
+for cls, cname in enumerate(["k_job round 0", "k_job round 1 (re-map)", "k_job_heavy round 0", "k_job_heavy round 1"]):
+    o = out[32 * cls: 32 * cls + 32]
+    tot = sum(o[:10]); jobs = max(o[10], 1)
+    print(f"== {cname}: {o[10]} jobs, anchors in {o[13] / jobs:.0f}/job, anchors in DP {o[11] / jobs:.0f}/job, pairs {o[12] / jobs:.0f}/job (window {o[12] / max(o[11], 1):.1f}); lane-0 cycles/job {tot / jobs:.0f}")
+    for i, nm in enumerate(names):
+        print(f"   {nm:42s} {o[i] / 1e6:10.1f} Mcyc {100.0 * o[i] / max(tot, 1):5.1f} %  per job {o[i] / jobs:9.0f}  max {o[16 + i] / 1e6:8.2f} Mcyc")
+
+# ---- per-workgroup timeline (100 MHz ticks): who runs when, and what the tail consists of
+f.lib.lnr_prof_timeline.restype = C.c_longlong
+f.lib.lnr_prof_timeline.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_ulonglong), C.c_ulonglong, C.POINTER(C.c_uint)]
+for rnd in range(2):
+    cap = 1 << 20
+    buf = np.zeros(cap * 4, dtype=np.uint64)
+    nh = C.c_uint(0)
+    k = f.lib.lnr_prof_timeline(f.h, rnd, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), cap, C.byref(nh))
+    if k <= 0:
+        continue
+    t = buf[: 4 * k].reshape(k, 4)
+    np.save(os.path.join(ROOT, "gpurun_out", f"timeline_r{rnd}.npy"), t)
+    ok = t[:, 1] > 0
+    t0 = t[ok, 0].min()
+    st = (t[:, 0].astype(np.int64) - int(t0)) / 100.0      # us
+    en = (t[:, 1].astype(np.int64) - int(t0)) / 100.0
+    m = (t[:, 3] >> np.uint64(32)).astype(np.int64); pairs = (t[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
+    H = nh.value
+    print(f"== round {rnd}: {k} workgroups, heavy prefix {H}; span {en[ok].max() / 1000:.1f} ms")
+    for name, sl in (("heavy", slice(0, H)), ("normal", slice(H, k))):
+        s_, e_, m_, p_ = st[sl], en[sl], m[sl], pairs[sl]
+        if len(s_) == 0:
+            continue
+        d = e_ - s_
+        print(f"  {name}: first start {s_.min() / 1000:.2f} ms, last start {s_.max() / 1000:.2f} ms, last end {e_.max() / 1000:.2f} ms; sum of durations {d.sum() / 1000:.0f} ms; "
+              f"mean {d.mean():.0f} us, p50 {np.percentile(d, 50):.0f}, p99 {np.percentile(d, 99):.0f}, max {d.max():.0f} us")
+        top = np.argsort(-e_)[:8]
+        for i in top:
+            print(f"     pos {i + (H if name == 'normal' else 0):6d}: start {s_[i] / 1000:7.2f} ms  dur {d[i] / 1000:7.2f} ms  end {e_[i] / 1000:7.2f} ms  anchors-in-DP {m_[i]:6d} pairs {p_[i]:10d}")
+        grid = np.linspace(0, e_.max(), 21)[1:]
+        res = [(int(((s_ <= g) & (e_ > g)).sum())) for g in grid]
+        print(f"     resident workgroups at 5% steps of its span: {res}")
