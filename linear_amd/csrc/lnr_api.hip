@@ -66,7 +66,7 @@ struct lnr_ctx {
     u32 mid_cap = 0xffffffffu, mid_lds_kb = 24;   // optional middle size class, 4 waves per read (LNR_MID_CAP, LNR_MID_LDS_KB); measured slower, off
     hipStream_t stream3 = nullptr;
     hipEvent_t ev_join3 = nullptr;
-    u32 heavy_cap = 8192;               // jobs with at least this many bucket entries take the heavy path (LNR_HEAVY_CAP overrides)
+    u32 heavy_cap = 8192;               // reads with at least this many anchors (after the Y filter) take the 16-wave path (LNR_HEAVY_CAP overrides)
     hipStream_t stream2 = nullptr;      // heavy path runs here, concurrently with the fused k_job
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm;   // bm: bucket-non-empty bitmap (derived from dir)
@@ -252,16 +252,16 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
     }
     if (!with_job_kernel) return LNR_OK;
 
-    // launch order: heaviest group first (sum of bucket entries is the work proxy), so the long tail of
+    // launch order: heaviest group first (anchors that passed the Y filter are the work proxy), so the long tail of
     // repeat-rich reads starts at once instead of at the end of the grid
     u64 budget = ctx->opts.scratch_budget ? ctx->opts.scratch_budget : (24ULL << 30);
     u32 ngrp = (u32)hj.grp_beg.size() - 1;
     std::vector<u32> order(ngrp);
     {
-        // counting sort by weight class, heaviest first: classes are 1/8-octave steps of the group's bucket-entry sum, so
+        // counting sort by weight class, heaviest first: classes are 1/8-octave steps of the group's anchor count, so
         // the order is "descending up to 9 %" -- all the scheduler needs -- in O(n)
         std::vector<u64> w(ngrp, 0);
-        for (u32 g = 0; g < ngrp; g++) for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) w[g] += cap[j];
+        for (u32 g = 0; g < ngrp; g++) for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) w[g] += nanc_all[j];
         auto cls = [](u64 v) -> u32 {
             if (v < 8) return (u32)v;
             int lg = 63 - __builtin_clzll(v);
@@ -333,7 +333,7 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             A.lds_bytes = (u32)lds;
             A.arena_lds = (u32)arena;
             // three size classes along the (weight-descending) slice: heavy = 16 waves per read, mid = 4 waves, rest = 1 wave
-            auto wsum_of = [&](u32 g) { u64 w = 0; for (u32 q = ord_job_beg[g]; q < ord_job_beg[g + 1]; q++) w += cap[job_list[q]]; return w; };
+            auto wsum_of = [&](u32 g) { u64 w = 0; for (u32 q = ord_job_beg[g]; q < ord_job_beg[g + 1]; q++) w += nanc_all[job_list[q]]; return w; };
             u32 gh = g0;
             while (gh < g1 && wsum_of(gh) >= ctx->heavy_cap) gh++;
             u32 gm = gh;
@@ -342,34 +342,35 @@ lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool
             if (ctx->tl_round < 4) ctx->tl_nh[ctx->tl_round] = gh;
             ctx->tl_round++;
 #endif
+            // The multi-wave kernels go first and on the main stream: a 16-wave workgroup only finds a CU with 16 free wave
+            // slots while the single-wave kernel has not flooded the chip yet (it refills every slot a finished wave frees,
+            // so a late heavy launch starts only when the bulk kernel drains -- measured: 47 ms late).  The bulk kernel
+            // follows on the second stream behind an event recorded before the heavy launch.
             ctx->t_job.start(ctx->stream);
-            if (gh > g0 || gm > gh) HIPCK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            bool side = (gh > g0 || gm > gh) && g1 > gm;
+            if (side) HIPCK(hipEventRecord(ctx->ev_fork, ctx->stream));
             if (gh > g0) {
-                HIPCK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
                 JobArgs H = A;
                 size_t hl = std::max<size_t>(lds_min, (size_t)ctx->heavy_lds_kb * 1024);
                 H.grp_lo = g0; H.grp_hi = gh; H.lds_bytes = (u32)hl; H.arena_lds = (u32)hl;
-                hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, ctx->stream2, H);
+                hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, ctx->stream, H);
                 KCHECK();
-                HIPCK(hipEventRecord(ctx->ev_join, ctx->stream2));
             }
             if (gm > gh) {
-                HIPCK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
                 JobArgs M = A;
                 size_t ml = std::max<size_t>(lds_min, (size_t)ctx->mid_lds_kb * 1024);
                 M.grp_lo = gh; M.grp_hi = gm; M.lds_bytes = (u32)ml; M.arena_lds = (u32)ml;
-                hipLaunchKernelGGL(k_job_mid, dim3(gm - gh), dim3(256), ml, ctx->stream3, M);
-                KCHECK();
-                HIPCK(hipEventRecord(ctx->ev_join3, ctx->stream3));
-            }
-            u32 gh_all = gm;
-            if (g1 > gh_all) {
-                A.grp_lo = gh_all; A.grp_hi = g1;
-                hipLaunchKernelGGL(k_job, dim3(g1 - gh_all), dim3(64), lds, ctx->stream, A);
+                hipLaunchKernelGGL(k_job_mid, dim3(gm - gh), dim3(256), ml, ctx->stream, M);
                 KCHECK();
             }
-            if (gh > g0) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            if (gm > gh) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
+            if (g1 > gm) {
+                hipStream_t bulk = side ? ctx->stream2 : ctx->stream;
+                if (side) HIPCK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                A.grp_lo = gm; A.grp_hi = g1;
+                hipLaunchKernelGGL(k_job, dim3(g1 - gm), dim3(64), lds, bulk, A);
+                KCHECK();
+                if (side) { HIPCK(hipEventRecord(ctx->ev_join, ctx->stream2)); HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); }
+            }
             ctx->t_job.stop(ctx->stream);
         }
         HIPCK(hipStreamSynchronize(ctx->stream));

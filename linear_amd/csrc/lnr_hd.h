@@ -434,6 +434,53 @@ LNR_HD inline int chain_score(u32 x1, u32 y1, u32 x2, u32 y2) {   // getApxChain
     return 100 - score_dy - score_derr;
 }
 
+// Branch-free twins for the lane-parallel DP (every lane scores a different anchor, so a branch would almost never be
+// skipped by the whole wave).  Same values as chain_score / chain_score0 for every input with x < 2^30, y < 2^20
+// (tests/test_stage_logic_host.py fuzzes the pair).  derr = floor(100 * da / M) comes from a float estimate that is
+// within +-1 of the quotient (da < M < 2^30, quotient < 100) and one exact integer correction step.
+LNR_HD inline int chain_score0_bl(u32 x1, u32 y1, u32 x2, u32 y2) {
+    i32 dy = (i32)y1 - (i32)y2;
+    i32 dx = (i32)x1 - (i32)x2;
+    i32 t = dx - dy;
+    i32 da = t < 0 ? -t : t;
+    i32 adx = dx < 0 ? -dx : dx;
+    i32 M = dy > adx ? dy : adx;
+    M = M < 50 ? 50 : M;
+    i32 res = 100 - dy - (da < 30 ? 0 : da);
+    res = da >= M ? -1000 : res;
+    res = dy < 5 ? -10000 : res;
+    return res;
+}
+LNR_HD inline int chain_score_bl(u32 x1, u32 y1, u32 x2, u32 y2) {
+    i32 dy = (i32)y1 - (i32)y2;
+    i32 dx = (i32)x1 - (i32)x2;
+    i32 t = dx - dy;
+    u32 da = (u32)(t < 0 ? -t : t);
+    u32 adx = (u32)(dx < 0 ? -dx : dx);
+    u32 udy = (u32)(dy < 0 ? 0 : dy);
+    u32 M = udy > adx ? udy : adx;
+    M = M < 50 ? 50 : M;
+    u32 dq = udy / 15;
+    u32 dqc = dq < 9999 ? dq : 9999;
+    u32 s_hi = dqc * dqc / 200 + 20;
+    u32 score_dy = dq < 150 ? dq / 5 : (dq < 10000 ? s_hi : 10000);
+    u32 dac = da < M ? da : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float inv = __builtin_amdgcn_rcpf((float)M);
+#else
+    float inv = 1.0f / (float)M;
+#endif
+    u32 q = (u32)((float)dac * 100.0f * inv);
+    i32 r = (i32)(100u * dac - q * M);        // exact modulo 2^32; the true remainder lies in [-M, 2M)
+    q = r < 0 ? q - 1 : ((u32)r >= M ? q + 1 : q);
+    u32 score_derr = q < 5 ? 4 * q : (q < 10 ? 6 * q - 10 : q * q - 5 * q);
+    score_derr = da < 10 ? 0 : score_derr;
+    i32 res = 100 - (i32)score_dy - (i32)score_derr;
+    res = da >= M ? -1000 : res;
+    res = dy < 10 ? -10000 : res;
+    return res;
+}
+
 struct Rec { i32 *score, *score2, *len, *p2, *root, *leaf; };   // ChainsRecord as SoA
 
 // Small arrays that only the leader lane touches (introsort stack, tree table of traceBackChains1).  In the

@@ -693,7 +693,7 @@ __device__ __forceinline__ void dp_window_bounds(const u32 *xs, u32 m, i32 *jlo,
 __device__ __forceinline__ i64 dp_key(int total, int j) { return ((i64)total << 32) | (i64)(u32)(0x7fffffff - j); }
 template <int ST>
 __device__ __forceinline__ void dp_eval(i64 &best, u32 px, u32 py, i32 ps, int jj, u32 xi, u32 yi, bool act) {
-    int sc = ST ? chain_score0(px, py, xi, yi) : chain_score(px, py, xi, yi);
+    int sc = ST ? chain_score0_bl(px, py, xi, yi) : chain_score_bl(px, py, xi, yi);
     if (act && sc > 0) { i64 key = dp_key(sc + ps, jj); best = key > best ? key : best; }
 }
 // before-tile candidates of this wave's share of the chunks; jl = the lane's j_lo (INT_MAX for an idle lane)
@@ -706,6 +706,7 @@ __device__ __forceinline__ i64 dp_before_tile(const u32 *xs, const u32 *ys, cons
         u32 px = 0, py = 0; i32 ps = 0;
         if (jl_ >= lo) { px = xs[jl_]; py = ys[jl_]; ps = score[jl_]; }
         int cnt = top - lo < 64 ? top - lo : 64;
+#pragma unroll 4
         for (int s_ = 0; s_ < cnt; s_++) {
             u32 qx = (u32)__builtin_amdgcn_readlane((int)px, s_), qy = (u32)__builtin_amdgcn_readlane((int)py, s_);
             i32 qs = __builtin_amdgcn_readlane(ps, s_);

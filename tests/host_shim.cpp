@@ -305,4 +305,28 @@ void hs_std_sort_hi32(u64 *a, u64 n, int desc) {
     if (desc) std::sort(a, a + n, [](const u64 &x, const u64 &y) { return (x >> 32) > (y >> 32); });
     else std::sort(a, a + n, [](const u64 &x, const u64 &y) { return (x >> 32) < (y >> 32); });
 }
+// fuzz hook: branch-free chain scores (what the lane-parallel DP evaluates) against the literal ones; returns mismatches
+u64 hs_chain_score_fuzz(u64 seed, u64 n) {
+    u64 bad = 0, st = seed * 0x9E3779B97F4A7C15ULL + 1;
+    auto rnd = [&st]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    for (u64 it = 0; it < n; it++) {
+        u64 a = rnd(), b = rnd(), c = rnd();
+        u32 x2 = (u32)(a & 0x3fffffff), y2 = (u32)((a >> 32) & 0xfffff);
+        u32 x1, y1;
+        switch (c & 7) {
+        case 0: x1 = (u32)(b & 0x3fffffff); y1 = (u32)((b >> 32) & 0xfffff); break;                    // anything
+        case 1: x1 = x2 + (u32)(b % 400); y1 = y2 + (u32)((b >> 32) % 400); break;                       // the usual window
+        case 2: x1 = x2 + (u32)(b % 5000); y1 = y2 + (u32)((b >> 32) % 5000); break;
+        case 3: x1 = x2 + (u32)(b % 400) - 40; y1 = y2 + (u32)((b >> 32) % 64) - 8; break;               // around the cut-offs
+        case 4: x1 = x2 + (u32)(b & 0x3fffff); y1 = y2 + (u32)((b >> 32) & 0xfffff); break;              // long gaps
+        case 5: { u32 d = (u32)(b % 200000); x1 = x2 + d; y1 = y2 + d + (u32)((b >> 40) % 41) - 20; break; }   // near-diagonal, long
+        case 6: { u32 d = (u32)(b % 3000); x1 = x2 + d; y1 = y2 + d * (u32)((b >> 40) % 7) / 3; break; }
+        default: x1 = x2 + (u32)(b % 60); y1 = y2 + (u32)((b >> 32) % 60); break;
+        }
+        x1 &= 0x3fffffff; y1 &= 0xfffff;
+        if (chain_score(x1, y1, x2, y2) != chain_score_bl(x1, y1, x2, y2)) bad++;
+        if (chain_score0(x1, y1, x2, y2) != chain_score0_bl(x1, y1, x2, y2)) bad++;
+    }
+    return bad;
+}
 }

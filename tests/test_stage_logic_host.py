@@ -36,6 +36,17 @@ def test_ref_sort_equals_libstdcxx_sort_with_ties():
             assert np.array_equal(b, c), f"n={n} keys={keys} desc={desc}"
 
 
+def test_branch_free_chain_scores_equal_the_literal_ones():
+    """The lane-parallel DP scores pairs with chain_score_bl / chain_score0_bl (float quotient estimate + exact
+    correction); they must agree with the literal getApxChainScore restatements on every input."""
+    shimlib.build()
+    lib = C.CDLL(shimlib.SO)
+    lib.hs_chain_score_fuzz.restype = C.c_uint64
+    lib.hs_chain_score_fuzz.argtypes = [C.c_uint64, C.c_uint64]
+    for seed in range(4):
+        assert lib.hs_chain_score_fuzz(seed, 5_000_000) == 0
+
+
 @pytest.mark.parametrize("name,T", PARAMS)
 def test_stage_logic_matches_golden(case_inputs, name, T):
     refs, reads, off = case_inputs(name)
