@@ -60,13 +60,13 @@ struct lnr_ctx {
     lnr_index_info info{};
     std::vector<u64> seq_len, seq_off, f2_off;
     u32 nbins = 0;
-    size_t job_lds_bytes = 8 * 1024;    // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
+    size_t job_lds_bytes = 5 * 1024;    // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
     size_t job_stage_bytes = 0;         // LDS stage of the blocked DP's predecessor window in the fused k_job (LNR_JOB_STAGE_KB; measured slower, off)
     u32 heavy_lds_kb = 48;              // LDS arena of k_job_heavy (LNR_HEAVY_LDS_KB)
-    u32 mid_cap = 0xffffffffu, mid_lds_kb = 24;   // optional middle size class, 4 waves per read (LNR_MID_CAP, LNR_MID_LDS_KB); measured slower, off
+    u32 mid_cap = 6144, mid_lds_kb = 24;   // reads with at least this many anchors run on 4 waves (k_job_mid: the DP is dealt over the waves); LNR_MID_CAP, LNR_MID_LDS_KB
     hipStream_t stream3 = nullptr;
     hipEvent_t ev_join3 = nullptr;
-    u32 heavy_cap = 8192;               // reads with at least this many anchors (after the Y filter) take the 16-wave path (LNR_HEAVY_CAP overrides)
+    u32 heavy_cap = 0xffffffffu;               // reads with at least this many anchors (after the Y filter) take the 16-wave path (LNR_HEAVY_CAP overrides)
     hipStream_t stream2 = nullptr;      // heavy path runs here, concurrently with the fused k_job
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm;   // bm: bucket-non-empty bitmap (derived from dir)

@@ -1130,7 +1130,7 @@ __global__ void __launch_bounds__(1024) k_job_heavy(JobArgs A) {
     if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
     job_group_run<16>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
 }
-__global__ void __launch_bounds__(256) k_job_mid(JobArgs A) {
+__global__ void __launch_bounds__(256, 4) k_job_mid(JobArgs A) {
     extern __shared__ u32 dyn_lds[];
     if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
     job_group_run<4>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
