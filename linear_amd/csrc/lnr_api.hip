@@ -72,7 +72,7 @@ struct lnr_ctx {
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm;   // bm: bucket-non-empty bitmap (derived from dir)
     // ---- batch inputs / per-read arrays
     DevBuf in_reads, in_off;                       // staging for the host-buffer entry points
-    DevBuf reads_p, rp_off, lpad, rlen, rks, nf, f1_off, f1, pk, nm, pk_off;
+    DevBuf rlen, rks, nf, f1_off, f1, pk, nm, pk_off;
     DevBuf cords, out_str, out_end, cords_off, cords_cap, ncords, nout, read_err;
     DevBuf tail_scr, tail_off, tail_cap, gaps, gaps_off, gaps_cap, ngaps, remap;
     // ---- jobs
@@ -171,8 +171,8 @@ struct HostJobs {
 struct BatchHost {
     u32 n = 0;
     std::vector<u64> off;
-    std::vector<u32> len, lpad, nf, cords_cap, gaps_cap;
-    std::vector<u64> rp_off, f1_off, cords_off, gaps_off, pk_off;
+    std::vector<u32> len, nf, cords_cap, gaps_cap;
+    std::vector<u64> f1_off, cords_off, gaps_off, pk_off;
 };
 
 JobArrays job_arrays(lnr_ctx *ctx) {
@@ -182,7 +182,7 @@ JobArrays job_arrays(lnr_ctx *ctx) {
 }
 ReadArrays read_arrays(lnr_ctx *ctx) {
     ReadArrays R;
-    R.bases = ctx->reads_p.as<u8>(); R.rp_off = ctx->rp_off.as<u64>(); R.lpad = ctx->lpad.as<u32>(); R.len = ctx->rlen.as<u32>(); R.ks = ctx->rks.as<i32>();
+    R.len = ctx->rlen.as<u32>(); R.ks = ctx->rks.as<i32>();
     R.pk = ctx->pk.as<u64>(); R.nm = ctx->nm.as<u32>(); R.pk_off = ctx->pk_off.as<u64>();
     return R;
 }
@@ -386,16 +386,14 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     B.off.resize((size_t)n + 1);
     HIPCK(hipMemcpyAsync(B.off.data(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCK(hipStreamSynchronize(ctx->stream));
-    B.len.resize(n); B.lpad.resize(n); B.nf.resize(n); B.cords_cap.resize(n); B.gaps_cap.resize(n);
-    B.rp_off.resize(n); B.f1_off.resize(n); B.cords_off.resize(n); B.gaps_off.resize(n); B.pk_off.resize(n);
-    u64 rp = 0, fo = 0, co = 0, go = 0, po = 0;
+    B.len.resize(n); B.nf.resize(n); B.cords_cap.resize(n); B.gaps_cap.resize(n);
+    B.f1_off.resize(n); B.cords_off.resize(n); B.gaps_off.resize(n); B.pk_off.resize(n);
+    u64 fo = 0, co = 0, go = 0, po = 0;
     for (u32 i = 0; i < n; i++) {
         if (B.off[i + 1] < B.off[i]) { ctx->err = "read offsets not monotone"; return LNR_ERR_ARG; }
         u64 L = B.off[i + 1] - B.off[i];
         if (L >= (1ULL << 20)) { ctx->err = "read longer than 2^20-1 bases (cord y field, cords.cpp:15)"; return LNR_ERR_LIMIT; }
         B.len[i] = (u32)L;
-        B.lpad[i] = (u32)align_up(L + SEQ_PAD, 16);
-        B.rp_off[i] = rp; rp += B.lpad[i];
         B.pk_off[i] = po; po += 2 * packed_words(L);   // forward + reverse-complement strand
         B.nf[i] = L > 200 ? read_feature_count(L) : 0;
         B.f1_off[i] = fo; fo += 2ULL * B.nf[i];
@@ -406,8 +404,6 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     }
     lnr_status s;
     if ((s = upload(ctx, ctx->rlen, B.len)) != LNR_OK) return s;
-    if ((s = upload(ctx, ctx->lpad, B.lpad)) != LNR_OK) return s;
-    if ((s = upload(ctx, ctx->rp_off, B.rp_off)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->pk_off, B.pk_off)) != LNR_OK) return s;
     ENSURE(ctx->pk, std::max<u64>(po * 8, 16));
     ENSURE(ctx->nm, std::max<u64>(po * 4, 16));
@@ -417,7 +413,6 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     if ((s = upload(ctx, ctx->cords_off, B.cords_off)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->gaps_cap, B.gaps_cap)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->gaps_off, B.gaps_off)) != LNR_OK) return s;
-    ENSURE(ctx->reads_p, std::max<u64>(rp, 16));
     ENSURE(ctx->rks, (size_t)n * 4);
     ENSURE(ctx->f1, std::max<u64>(fo * sizeof(F96), 16));
     ENSURE(ctx->cords, std::max<u64>(co * 8, 16));
@@ -432,8 +427,7 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     HIPCK(hipMemsetAsync(ctx->ncords.p, 0, (size_t)n * 4, ctx->stream));
     HIPCK(hipMemsetAsync(ctx->read_err.p, 0, (size_t)n * 4, ctx->stream));
     ctx->t_prep.start(ctx->stream);
-    hipLaunchKernelGGL(k_prep, dim3(n), dim3(256), 0, ctx->stream, d_reads, d_off, ctx->rp_off.as<u64>(), ctx->lpad.as<u32>(), ctx->pk_off.as<u64>(), n, ctx->reads_p.as<u8>(),
-                       ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
+    hipLaunchKernelGGL(k_prep, dim3(n), dim3(256), 0, ctx->stream, d_reads, d_off, ctx->pk_off.as<u64>(), n, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
     KCHECK();
     hipLaunchKernelGGL(k_f1, dim3(n), dim3(256), 0, ctx->stream, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->pk_off.as<u64>(), ctx->rlen.as<u32>(), ctx->nf.as<u32>(), ctx->f1_off.as<u64>(), n,
                        ctx->f1.as<F96>());
@@ -695,8 +689,8 @@ void lnr_destroy(lnr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->g, &ctx->dir, &ctx->hs, &ctx->f2, &ctx->d_seq_off, &ctx->d_f2_off, &ctx->bm, &ctx->pk, &ctx->nm, &ctx->pk_off, &ctx->in_reads, &ctx->in_off, &ctx->reads_p, &ctx->rp_off,
-                      &ctx->lpad, &ctx->rlen, &ctx->rks, &ctx->nf, &ctx->f1_off, &ctx->f1, &ctx->cords, &ctx->out_str, &ctx->out_end, &ctx->cords_off,
+    DevBuf *bufs[] = {&ctx->g, &ctx->dir, &ctx->hs, &ctx->f2, &ctx->d_seq_off, &ctx->d_f2_off, &ctx->bm, &ctx->pk, &ctx->nm, &ctx->pk_off, &ctx->in_reads, &ctx->in_off,
+                      &ctx->rlen, &ctx->rks, &ctx->nf, &ctx->f1_off, &ctx->f1, &ctx->cords, &ctx->out_str, &ctx->out_end, &ctx->cords_off,
                       &ctx->cords_cap, &ctx->ncords, &ctx->nout, &ctx->read_err, &ctx->tail_scr, &ctx->tail_off, &ctx->tail_cap, &ctx->gaps, &ctx->gaps_off,
                       &ctx->gaps_cap, &ctx->ngaps, &ctx->remap, &ctx->j_read, &ctx->j_str, &ctx->j_end, &ctx->j_mode, &ctx->j_cap,
                       &ctx->j_look, &ctx->j_anc_off, &ctx->j_scr_off, &ctx->j_nanc, &ctx->grp_beg, &ctx->anchors, &ctx->job_scr, &ctx->r_off,

@@ -119,9 +119,36 @@ LNR_HD inline u64 tail_scratch_bytes(u64 cap) { return cap * 240 + 8192; }
 //   h_k   = sum VW[p]*4^(20-p) mod 2^42 (N=4 carries), crh_k = sum ((3-VW[p])&3) << 2p
 //   VW[p] = s[k+p], except while fewer than 21 bases have been rolled in (n=k-k0+1<21):
 //           the first 21-n slots still hold the tail of the hashInit window.
+LNR_HD inline int lnr_popc64(u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(v);
+#else
+    return __builtin_popcountll(v);
+#endif
+}
+// A read as the kernels hold it: 2 bits per base + an N bitmap (k_prep).  Indexing returns the Dna5 ordinal; positions at
+// or past the end read as 0 ('A'), the value the reference finds in the zeroed slack behind a sequence (pinned UB).
+struct PackedSeq {
+    const u64 *pk; const u32 *nm; u64 L;
+    LNR_HD u8 operator[](u64 i) const {
+        u64 j = i < L ? i : L;                       // slack words behind the read are zero (k_prep), index L is always inside
+        u32 n = nm[j >> 5]; u64 w = pk[j >> 5];      // two independent loads, no branch
+        u32 v = (u32)(w >> (2 * (j & 31))) & 3;
+        return (u8)(((n >> (j & 31)) & 1) ? 4 : v);
+    }
+    // sum of the ordinals of the 20 bases starting at p (p + 20 <= L + 44: inside the slack)
+    LNR_HD int sum20(u64 p) const {
+        u64 w = p >> 5; u32 sh = (u32)(p & 31);
+        u64 lo = pk[w], hi = pk[w + 1];
+        u64 bits = sh ? (lo >> (2 * sh)) | (hi << (64 - 2 * sh)) : lo;
+        bits &= (1ULL << 40) - 1;
+        u64 nb = ((((u64)nm[w + 1] << 32) | nm[w]) >> sh) & ((1ULL << 20) - 1);
+        return lnr_popc64(bits & 0x5555555555555555ULL) + 2 * lnr_popc64(bits & 0xAAAAAAAAAAAAAAAAULL) + 4 * lnr_popc64(nb);
+    }
+};
 struct SeedOut { u32 X; u32 Y; u32 strand; };
 
-LNR_HD inline int shape_init_skip(const u8 *s) {   // N-skip of hashInit (shape_extend.cpp:95-105)
+template <class Seq> LNR_HD inline int shape_init_skip(const Seq &s) {   // N-skip of hashInit (shape_extend.cpp:95-105)
     u64 k = 0, count = 0;
     while (count < 21) {
         if (s[k + count] == 4) { k += count + 1; count = 0; }
@@ -129,12 +156,15 @@ LNR_HD inline int shape_init_skip(const u8 *s) {   // N-skip of hashInit (shape_
     }
     return (int)k;
 }
-LNR_HD inline int shape_const(const u8 *s, u64 init_at, int ks, u64 k0) {
+template <class Seq> LNR_HD inline int shape_const(const Seq &s, u64 init_at, int ks, u64 k0) {
     int a = 0, b = 0;
     for (int i = 0; i < 20; i++) { a += s[init_at + ks + i]; b += s[k0 + i]; }
     return -63 + 2 * a - 2 * b;
 }
-LNR_HD inline SeedOut seed_sample(const u8 *s, u64 k, u64 k0, u64 init_at, int ks, int C) {
+LNR_HD inline int shape_const(const PackedSeq &s, u64 init_at, int ks, u64 k0) {   // same value from the packed words
+    return -63 + 2 * s.sum20(init_at + (u64)ks) - 2 * s.sum20(k0);
+}
+template <class Seq> LNR_HD inline SeedOut seed_sample(const Seq &s, u64 k, u64 k0, u64 init_at, int ks, int C) {
     u64 h = 0, crh = 0;
     int W = 0;
     u64 n = k - k0 + 1;
@@ -159,7 +189,7 @@ LNR_HD inline SeedOut seed_sample(const u8 *s, u64 k, u64 k0, u64 init_at, int k
         for (i64 i = d; i < d + 4; i++) { u64 val = s[k + i]; Y = val > 3 ? (Y << 2) : (Y << 2) + val; }
     } else {
         i64 d = 18 - (i64)(t >> 1);
-        for (i64 i = d; i > d - 4; i--) { i64 val = 3 - (i64)s[(i64)k + i]; Y = val < 0 ? (Y << 2) : (Y << 2) + (u64)val; }
+        for (i64 i = d; i > d - 4; i--) { i64 val = 3 - (i64)s[(u64)((i64)k + i)]; Y = val < 0 ? (Y << 2) : (Y << 2) + (u64)val; }
     }
     SeedOut o; o.X = (u32)X; o.Y = (u32)Y; o.strand = x > 0 ? 0 : 1;
     return o;
@@ -182,13 +212,6 @@ LNR_HD inline u64 lnr_brev64(u64 v) {
     v = ((v >> 8) & 0x00FF00FF00FF00FFULL) | ((v & 0x00FF00FF00FF00FFULL) << 8);
     v = ((v >> 16) & 0x0000FFFF0000FFFFULL) | ((v & 0x0000FFFF0000FFFFULL) << 16);
     return (v >> 32) | (v << 32);
-#endif
-}
-LNR_HD inline int lnr_popc64(u64 v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __popcll(v);
-#else
-    return __builtin_popcountll(v);
 #endif
 }
 LNR_HD inline bool seed_sample_packed(const u64 *pk, const u32 *nm, u64 k, u64 k0, int C, SeedOut &o) {

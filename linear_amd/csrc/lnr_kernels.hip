@@ -7,7 +7,7 @@
 //   index build  [a3-a5]: k_ix_chunk_const, k_ix_sample, k_ix_start_blk, k_max_top, k_ix_rec,
 //                         k_ix_omit, k_scan_*, k_ix_scatter, k_ix_sort_small, k_ix_sort_big
 //   features     [a6]   : k_f2 (genome), k_f1 (reads, both strands)
-//   read prep    [a1,a2]: k_prep (padded copy + reverse complement + 2-bit packing + hashInit N-skip)
+//   read prep    [a1,a2]: k_prep (2-bit packing of both strands + N bitmaps + hashInit N-skip)
 //   seed lookup  [a3,a4,a7]: k_seed_fused (+ k_ix_bitmap at index time)
 //   per-read job [a8-a16]: k_job (1 wave per read) / k_job_heavy (16 waves per heavy read): binning, radix sort, filter,
 //                         introsort, blocked chaining DP, traceback, blocks, windows
@@ -291,43 +291,109 @@ __global__ void __launch_bounds__(256) k_f2(const u8 *g, const u64 *seq_off, con
 }
 
 // ================================================================ read prep ====
-// Per read: padded forward byte copy (seed fallback path, hashInit), both strands 2-bit packed (+ N bitmaps; the
-// reverse complement is _compltRvseStr, base.cpp:335-344) and the N-skip hashInit would take at the read start.
-// Packed layout per read: [forward words | reverse-complement words], packed_words(L) each.  One block per read.
-__global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, const u64 *rp_off, const u32 *lpad, const u64 *pk_off, u32 n, u8 *dst, u64 *pk, u32 *nm,
-                                             i32 *read_ks) {
+// Per read: both strands 2-bit packed + N bitmaps (the reverse complement is _compltRvseStr, base.cpp:335-344) and the
+// N-skip hashInit would take at the read start.  Packed layout per read: [forward words | reverse-complement words],
+// packed_words(L) each (slack words zero).  One workgroup per read.  A lane takes 4 bases with one (unaligned) dword
+// load and folds them to 8 code bits + 4 N bits with SWAR arithmetic; a wave step covers 256 bases = 8 packed words,
+// transposed through 96 bytes of LDS so that the global stores are whole words.
+__device__ __forceinline__ u32 prep_load4(const u8 *rd, u32 L, u32 i, bool rev, u32 &valid) {
+    // strand positions i .. i+3 as bytes 0..3 (0 behind the end).  One dword load whatever the position: near the end the
+    // load window is clamped into the read and the result shifted, so there is no byte loop and no branch to wait in.
+    // (L >= 4; shorter reads take the serial path of k_prep.)  No branch at all: a lane behind the end loads the first
+    // dword of the read and masks it away, so the loads of several steps can be in flight together.
+    bool in = i < L;
+    u32 ii = in ? i : 0;
+    u32 want = rev ? L - 4 - ii : ii;               // forward address of the window (may run off the read)
+    u32 f = rev ? ((i32)want < 0 ? 0u : want) : (want > L - 4 ? L - 4 : want);
+    u32 d = rev ? f - want : want - f;              // bytes the window was moved by (<= 3)
+    u32 x;
+    __builtin_memcpy(&x, rd + f, 4);
+    x = rev ? __builtin_bswap32(x) : x;
+    x >>= 8 * d;
+    u32 nv = L - ii < 4 ? L - ii : 4;
+    valid = 0x01010101u & (nv == 4 ? 0xFFFFFFFFu : (1u << (8 * nv)) - 1u);
+    valid = in ? valid : 0;
+    x &= valid * 255u;
+    return x;
+}
+__global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, const u64 *pk_off, u32 n, u64 *pk, u32 *nm, i32 *read_ks) {
+    const int U = 4;                                 // loads in flight per wave
+    __shared__ u64 s_c[4][U][8];  // per wave and step in flight: 64 code bytes = 8 packed words
+    __shared__ u32 s_n[4][U][8];  // per wave and step in flight: 32 N bytes   = 8 bitmap words
     u32 r = blockIdx.x;
     if (r >= n) return;
     u64 o = off[r];
     u32 L = (u32)(off[r + 1] - o);
-    u32 P = lpad[r];
-    u8 *fwd = dst + rp_off[r];
-    for (u32 i = threadIdx.x; i < P; i += blockDim.x) {
-        u8 a = 0;
-        if (i < L) { a = src[o + i]; if (a > 4) a = 4; }
-        fwd[i] = a;
-    }
     u32 nw = (u32)packed_words(L);
+    const u8 *rd = src + o;
     u64 *pw = pk + pk_off[r];
     u32 *nw_ = nm + pk_off[r];
-    for (u32 w = threadIdx.x; w < 2 * nw; w += blockDim.x) {
-        bool rev = w >= nw;
-        u32 base = (rev ? w - nw : w) * 32;
-        u64 bits = 0; u32 nb = 0;
-        for (u32 q = 0; q < 32; q++) {
-            u32 i = base + q;
-            u8 a = 0;
-            if (i < L) {
-                a = src[o + (rev ? L - 1 - i : i)];
-                if (a > 4) a = 4;
-                if (rev && a < 4) a = 3 - a;
-            }
-            if (a == 4) nb |= 1u << q; else bits |= (u64)a << (2 * q);
+    int lane = lane_id();
+    u32 wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    if (L < 4) {                                     // degenerate read: one thread, literal form
+        if (threadIdx.x == 0) {
+            for (u32 w = 0; w < 2 * nw; w++) { pw[w] = 0; nw_[w] = 0; }
+            for (u32 sd = 0; sd < 2; sd++)
+                for (u32 i = 0; i < L; i++) {
+                    u32 a = rd[sd ? L - 1 - i : i];
+                    a = a > 4 ? 4 : a;
+                    if (a == 4) nw_[sd * nw] |= 1u << i; else pw[sd * nw] |= (u64)(sd ? 3 - a : a) << (2 * i);
+                }
+            PackedSeq fwd; fwd.pk = pw; fwd.nm = nw_; fwd.L = L;
+            read_ks[r] = shape_init_skip(fwd);
         }
-        pw[w] = bits; nw_[w] = nb;
+        return;
+    }
+    u32 nstep = (nw + 7) >> 3;                       // steps per strand (8 words each)
+    for (u32 st0 = wave * U; st0 < 2 * nstep; st0 += nwaves * U) {
+        u32 xv[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            u32 st = st0 + u;
+            bool rev = st >= nstep;
+            u32 i = 256 * (rev ? st - nstep : st) + 4 * (u32)lane;   // first of this lane's 4 strand positions
+            i = st < 2 * nstep ? i : L;                               // a step past the end loads nothing useful (masked)
+            xv[u] = prep_load4(rd, L, i, rev, vv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            bool rev = st0 + u >= nstep;
+            u32 x = xv[u];
+            u32 y = x & 0xFCFCFCFCu;                                           // ordinal > 3 -> N (values above 4 are clamped to N)
+            u32 n01 = ((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) >> 7) & 0x01010101u;
+            u32 t = x & 0x03030303u;
+            if (rev) t ^= 0x03030303u & (vv[u] * 3u);                          // complement, not behind the end
+            t &= ~(n01 * 255u);
+            u32 c8 = (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
+            u32 n4 = (n01 | (n01 >> 7) | (n01 >> 14) | (n01 >> 21)) & 0xFu;
+            u32 n8 = n4 | ((u32)__shfl_down((int)n4, 1) << 4);
+            ((u8 *)s_c[wave][u])[lane] = (u8)c8;
+            if (!(lane & 1)) ((u8 *)s_n[wave][u])[lane >> 1] = (u8)n8;
+        }
+        // LDS is in order within a wave: only the compiler must not move the reads above the writes, and the previous
+        // iteration's reads must have returned before these writes (they have: their values were stored already)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            u32 st = st0 + u;
+            if (st >= 2 * nstep) break;
+            bool rev = st >= nstep;
+            u32 wi = 8 * (rev ? st - nstep : st) + (u32)lane;
+            if (lane < 8 && wi < nw) {
+                u32 base = rev ? nw : 0;
+                pw[base + wi] = s_c[wave][u][lane];
+                nw_[base + wi] = s_n[wave][u][lane];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    if (threadIdx.x == 0) read_ks[r] = shape_init_skip(fwd);
+    if (threadIdx.x == 0) {
+        PackedSeq fwd; fwd.pk = pw; fwd.nm = nw_; fwd.L = L;
+        read_ks[r] = (nw_[0] & 0x1FFFFFu) ? shape_init_skip(fwd) : 0;   // no N among the first 21 bases: nothing to skip
+    }
 }
 // read window features of both strands (createFeatures2_48 serial form, pmpfinder.cpp:556-588) from the packed strands:
 // 16-base cells are counted once into LDS, an entry is the sum of three consecutive cells.
@@ -361,7 +427,7 @@ struct JobArrays {
     const u32 *read, *str, *end, *mode;   // per job
 };
 struct ReadArrays {
-    const u8 *bases; const u64 *rp_off; const u32 *lpad; const u32 *len; const i32 *ks;
+    const u32 *len; const i32 *ks;
     const u64 *pk; const u32 *nm; const u64 *pk_off;   // 2-bit packed forward strand + N bitmap
 };
 struct SeedOutArrays {
@@ -399,10 +465,10 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
     if (j >= njobs) return;
     int lane = lane_id();
     u32 r = J.read[j];
-    const u8 *s = R.bases + R.rp_off[r];
     const u64 *pk = R.pk + R.pk_off[r];
     const u32 *nm = R.nm + R.pk_off[r];
     u64 L = R.len[r];
+    PackedSeq s; s.pk = pk; s.nm = nm; s.L = L;   // byte view for the rare samples the packed path declines (N nearby, hashInit state)
     u64 rs = J.str[j], re = J.end[j];
     u32 alpha = (u32)job_parm((int)J.mode[j]).alpha;
     int ks = R.ks[r];

@@ -263,15 +263,23 @@ u64 hs_packed_vs_bytes(const u8 *read, u64 L, u64 read_str, u64 read_end, int al
         if (b > 3) nm[i >> 5] |= 1u << (i & 31);
         else pk[i >> 5] |= (u64)b << (2 * (i & 31));
     }
-    int ks = shape_init_skip(s.data());
+    const u8 *sb = s.data();
+    int ks = shape_init_skip(sb);
     u64 k0 = read_str + 21;
-    int C = shape_const(s.data(), 0, ks, k0);
+    int C = shape_const(sb, 0, ks, k0);
     u32 ns = seed_num_samples(read_str, read_end, (u32)alpha);
     u64 bad = 0, fb = 0;
+    // the kernels' view of the read (PackedSeq): element access, hashInit skip, shape constant, byte-path samples
+    PackedSeq ps; ps.pk = pk.data(); ps.nm = nm.data(); ps.L = L;
+    for (u64 i = 0; i < L + 40; i++) if (ps[i] != s[i]) bad++;
+    if (shape_init_skip(ps) != ks) bad++;
+    if (shape_const(ps, 0, ks, k0) != C) bad++;
+    for (u64 kk = 0; kk + 64 < L; kk += 97) if (shape_const(ps, 0, ks, kk) != shape_const(sb, 0, ks, kk)) bad++;
     for (u32 q = 0; q < ns; q++) {
         u64 k = k0 + alpha - 1 + (u64)alpha * q;
-        SeedOut a = seed_sample(s.data(), k, k0, 0, ks, C), b;
-        if (!seed_sample_packed(pk.data(), nm.data(), k, k0, C, b)) { fb++; continue; }
+        SeedOut a = seed_sample(sb, k, k0, 0, ks, C), b;
+        if (q < 4 || q % 13 == 0) { SeedOut c = seed_sample(ps, k, k0, 0, ks, C); if (a.X != c.X || a.Y != c.Y || a.strand != c.strand) bad++; }
+        if (!seed_sample_packed(pk.data(), nm.data(), k, k0, C, b)) { fb++; SeedOut c = seed_sample(ps, k, k0, 0, ks, C); if (a.X != c.X || a.Y != c.Y || a.strand != c.strand) bad++; continue; }
         if (a.X != b.X || a.Y != b.Y || a.strand != b.strand) bad++;
     }
     *n_fallback = fb; *n_samples = ns;
