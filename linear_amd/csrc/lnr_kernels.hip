@@ -37,6 +37,14 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+    for (int o = 32; o > 0; o >>= 1) { u32 t = (u32)__shfl_xor((int)v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+    for (int o = 32; o > 0; o >>= 1) { u32 t = (u32)__shfl_xor((int)v, o); v = t > v ? t : v; }
+    return v;
+}
 __device__ __forceinline__ i64 wave_max_i64(i64 v) {
     for (int o = 32; o > 0; o >>= 1) { i64 t = __shfl_xor((long long)v, o); v = t > v ? t : v; }
     return v;
@@ -727,6 +735,63 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
     WSYNC();
 }
 
+// wave-parallel twin of filter_anchor_list (filterAnchorsList, pmpfinder.cpp:2025-2071).  The serial loop compares anchor i
+// with ak2 = a[(block_str + i - 1) >> 1]: inside a block that only depends on where the block started, so 64 anchors are
+// tested at once and the first one that breaks the block is found with a ballot.  Block statistics (count, min / max y of
+// the continuing anchors) are kept per lane and reduced when a block closes; accepted blocks are copied forward in place
+// (ii <= block_str, chunks read before they are written).  Every lane returns the new count.
+__device__ u32 filter_anchor_list_wave(u64 *a, u32 n) {
+    int lane = lane_id();
+    if (n <= 1) return n;
+    u32 ii = 0, bs = 1, i0 = 2;
+    u32 cnt = 1;
+    u32 y1 = (u32)cord_y(a[1]);
+    u32 bmn = y1, bmx = y1;                  // block min / max so far (uniform part: the block's first anchor)
+    u32 pmn = 0xffffffffu, pmx = 0;          // per-lane part over the continuing anchors
+    while (i0 < n) {
+        u32 i = i0 + (u32)lane;
+        bool valid = i < n;
+        bool cont = false;
+        u32 yi = 0;
+        if (valid) {
+            u64 ai = a[i], ak = a[(bs + i - 1) >> 1];
+            yi = (u32)cord_y(ai);
+            u32 yk = (u32)cord_y(ak);
+            u64 dy2 = (u64)(yi > yk ? yi - yk : yk - yi);
+            cont = cord_x40(ai - ak) < (dy2 >> 2);
+        }
+        u64 brk = __ballot(valid && !cont);
+        u32 avail = n - i0 < 64 ? n - i0 : 64;
+        u32 take = brk ? (u32)__builtin_ctzll(brk) : avail;      // continuing anchors at the head of this chunk
+        if ((u32)lane < take) { pmn = yi < pmn ? yi : pmn; pmx = yi > pmx ? yi : pmx; }
+        cnt += take;
+        bool closes = brk != 0;
+        bool at_end = !closes && i0 + take == n;                  // the last anchor continued: the loop's "i == n - 1" close
+        if (closes || at_end) {
+            u32 mn = wave_min_u32(pmn), mx = wave_max_u32(pmx);
+            mn = mn < bmn ? mn : bmn; mx = mx > bmx ? mx : bmx;
+            u32 thd = (mx - mn) >> 10; thd = thd < 2 ? 2 : thd;
+            u32 iend = closes ? i0 + take : n - 1;                // the block is emitted as [bs, iend)
+            if (cnt > thd) {
+                for (u32 j0 = bs; j0 < iend; j0 += 64) {
+                    u32 j = j0 + (u32)lane;
+                    u64 v = j < iend ? a[j] : 0;
+                    WSYNC();
+                    if (j < iend) a[ii + (j - bs)] = v;
+                }
+                ii += iend - bs;
+                WSYNC();
+            }
+            if (!closes) break;
+            bs = iend;
+            u32 yb = (u32)cord_y(a[bs]);
+            bmn = yb; bmx = yb; pmn = 0xffffffffu; pmx = 0; cnt = 1;
+            i0 = bs + 1;
+        } else i0 += 64;
+    }
+    return ii;
+}
+
 // ---- tiled chaining DP (getBestChains, cluster_util.cpp:53-111) ---------------------------------------------
 // Anchors are processed in tiles of 64 with ONE ANCHOR PER LANE; predecessors are the uniform operand:
 //   before-tile : the predecessors [j_lo(t0), t0) -- their chain scores are final -- are loaded 64 at a time, one per lane
@@ -1075,9 +1140,8 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
                 WSYNC();
             }
             LNR_TICK(prof, 2, tk_);
-            if (lane == 0) s_m = n > 1 ? filter_anchor_list(a, n) : n;   // filterAnchors1 (pmpfinder.cpp:2073-2091)
+            m = n > 1 ? filter_anchor_list_wave(a, n) : n;   // filterAnchors1 (pmpfinder.cpp:2073-2091)
             WSYNC();
-            m = s_m;
             if (m > 1) {
                 // scratch of the sort: position lists in the (dead) radix buffer, task list behind it
                 u32 *Lbuf = (u32 *)s_alt, *Rbuf = Lbuf + (m + 2);
