@@ -604,9 +604,10 @@ LNR_HD inline void traceback0(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_s
         if (!tb0_step(r, sc, sink, chain, chain_sc, min_len, abort_score, stop_ratio)) break;
     }
 }
-// traceBackChains1 cluster_util.cpp:213-304 (at most 50 trees reach this function)
-template <class Sink>
-LNR_HD inline void traceback1(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, int min_len, int abort_score, int bestn, float stop_ratio, LeaderScratch &ls) {
+// traceBackChains1 cluster_util.cpp:213-304 (at most 50 trees reach this function), in two halves:
+//   table: per tree (in order of its first leaf) the best leaf -- highest score, earliest on ties;
+//   emit : trees by score (std::sort order), chains walked from the leaf.
+LNR_HD inline int traceback1_table(const Rec &r, u32 n, LeaderScratch &ls) {
     i32 *l_root = ls.l_root, *l_score = ls.l_score, *l_len = ls.l_len, *l_leaf = ls.l_leaf;
     int nl = 0;
     for (u32 j = 0; j < n; j++) {
@@ -621,6 +622,11 @@ LNR_HD inline void traceback1(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_s
             if (f_new && nl < 64) { l_root[nl] = r.root[j]; l_score[nl] = r.score[j]; l_len[nl] = r.len[j]; l_leaf[nl] = (i32)j; nl++; }
         }
     }
+    return nl;
+}
+template <class Sink>
+LNR_HD inline void traceback1_emit(Rec r, int nl, Sink &sink, i32 *chain, i32 *chain_sc, int min_len, int abort_score, int bestn, float stop_ratio, LeaderScratch &ls) {
+    i32 *l_score = ls.l_score, *l_len = ls.l_len, *l_leaf = ls.l_leaf;
     u64 *ranks = ls.ranks;   // (tree index, score) pairs; std::sort by score desc with ties (cluster_util.cpp:269)
     for (int i = 0; i < nl; i++) ranks[i] = ((u64)(u32)l_score[i] << 32) | (u32)i;
     ref_sort(ranks, (long)nl, [](const u64 &a, const u64 &b) { return (i32)(a >> 32) > (i32)(b >> 32); }, ls.st);
@@ -638,6 +644,11 @@ LNR_HD inline void traceback1(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_s
             }
         }
     }
+}
+template <class Sink>
+LNR_HD inline void traceback1(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, int min_len, int abort_score, int bestn, float stop_ratio, LeaderScratch &ls) {
+    int nl = traceback1_table(r, n, ls);
+    traceback1_emit(r, nl, sink, chain, chain_sc, min_len, abort_score, bestn, stop_ratio, ls);
 }
 // traceBackChains cluster_util.cpp:306-335; cnt = n zeroed ints of scratch
 template <class Sink>

@@ -927,6 +927,45 @@ __device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {
     s.max_len = r.len[s.max_str];
     return s;
 }
+// wave-parallel twin of traceback1_table: lanes over the anchors, the (<= 50) trees in LDS.  Trees are numbered by their
+// first leaf: per chunk of 64 anchors the not-yet-listed roots are appended lowest lane first.  The best leaf of a tree is
+// the maximum of (score, earliest j) -- an LDS atomic max on a 64-bit key.
+__device__ int traceback1_table_wave(const Rec &r, u32 n, LeaderScratch *ls) {
+    int lane = lane_id();
+    int nl = 0;
+    unsigned long long *key = (unsigned long long *)ls->ranks;
+    if (lane < 64) key[lane] = 0;
+    WSYNC();
+    for (u32 base = 0; base < n; base += 64) {
+        u32 j = base + (u32)lane;
+        bool lf = j < n && r.leaf[j] != 0;
+        i32 root = lf ? r.root[j] : -1;
+        int k = -1;
+        if (lf) for (int q = 0; q < nl; q++) if (ls->l_root[q] == root) { k = q; break; }
+        u64 pend = __ballot(lf && k < 0);
+        while (pend) {
+            int src = (int)__builtin_ctzll(pend);
+            i32 rt = __shfl(root, src);
+            if (nl < 64) { if (lane == 0) ls->l_root[nl] = rt; }
+            if (lf && k < 0 && root == rt) k = nl < 64 ? nl : -2;      // -2: table full, the leaf is ignored like the serial form does
+            if (nl < 64) nl++;
+            WSYNC();
+            pend = __ballot(lf && k == -1);
+        }
+        if (lf && k >= 0) {
+            unsigned long long kv = ((unsigned long long)(u32)(r.score[j] + 0x40000000) << 32) | (unsigned long long)(0xffffffffu - j);
+            atomicMax(&key[k], kv);
+        }
+    }
+    WSYNC();
+    if (lane < nl) {
+        unsigned long long kv = key[lane];
+        u32 j = 0xffffffffu - (u32)(kv & 0xffffffffu);
+        ls->l_score[lane] = (i32)(u32)(kv >> 32) - 0x40000000; ls->l_len[lane] = r.len[j]; ls->l_leaf[lane] = (i32)j;
+    }
+    WSYNC();
+    return nl;
+}
 // traceBackChains (cluster_util.cpp:306-335) for the anchor DP, lanes cooperating on the scans; lane 0 walks chains
 // and emits hits.  s_flag = one LDS word.
 __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int *s_flag, LeaderScratch *ls) {
@@ -948,7 +987,8 @@ __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain
             if (!cont) break;
         }
     } else {
-        if (lane == 0) traceback1(r, n, sink, chain, chain_sc, 1, 45, 50, 0.0f, *ls);
+        int nl = traceback1_table_wave(r, n, ls);
+        if (lane == 0) traceback1_emit(r, nl, sink, chain, chain_sc, 1, 45, 50, 0.0f, *ls);
         WSYNC();
     }
 }
