@@ -64,28 +64,39 @@ struct lnr_ctx {
     size_t job_stage_bytes = 0;         // LDS stage of the blocked DP's predecessor window in the fused k_job (LNR_JOB_STAGE_KB; measured slower, off)
     u32 heavy_lds_kb = 48;              // LDS arena of k_job_heavy (LNR_HEAVY_LDS_KB)
     u32 mid_cap = 6144, mid_lds_kb = 24;   // reads with at least this many anchors run on 4 waves (k_job_mid: the DP is dealt over the waves); LNR_MID_CAP, LNR_MID_LDS_KB
-    hipStream_t stream3 = nullptr;
-    hipEvent_t ev_join3 = nullptr;
-    u32 heavy_cap = 0xffffffffu;               // reads with at least this many anchors (after the Y filter) take the 16-wave path (LNR_HEAVY_CAP overrides)
-    hipStream_t stream2 = nullptr;      // heavy path runs here, concurrently with the fused k_job
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    u32 heavy_cap = 0xffffffffu;        // reads with at least this many anchors (after the Y filter) take the 16-wave path (LNR_HEAVY_CAP overrides)
+    u32 split_cap = 0xffffffffu;               // reads with at least this many anchors form the "heavy lane": their re-map round starts
+                                        // while the bulk of the batch is still in round 0 (LNR_SPLIT_CAP; 0xffffffff = one lane)
+    // Two lanes of streams: lane 0 = heavy reads, lane 1 = the bulk.  s_multi carries the multi-wave kernels (and the
+    // lane's seed / tail launches), s_bulk the single-wave kernel of the same launch.
+    hipStream_t s_multi[2] = {nullptr, nullptr}, s_bulk[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_start = nullptr, ev_lane[2] = {nullptr, nullptr};
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm;   // bm: bucket-non-empty bitmap (derived from dir)
     // ---- batch inputs / per-read arrays
     DevBuf in_reads, in_off;                       // staging for the host-buffer entry points
     DevBuf rlen, rks, nf, f1_off, f1, pk, nm, pk_off;
     DevBuf cords, out_str, out_end, cords_off, cords_cap, ncords, nout, read_err;
-    DevBuf tail_scr, tail_off, tail_cap, gaps, gaps_off, gaps_cap, ngaps, remap;
-    // ---- jobs
-    DevBuf j_read, j_str, j_end, j_mode, j_cap, j_look, j_anc_off, j_scr_off, j_nanc, grp_beg, grp_order, job_list;
-    DevBuf anchors, job_scr, prof, tl, seed_ctl; u32 tl_round = 0, tl_n[4] = {0, 0, 0, 0}; u32 tl_nh[4] = {0, 0, 0, 0};   // seed_ctl: allocator cursor + overflow flag
-    u64 anc_slots_per_job = 1536;       // running estimate of anchor slots per job (grows on overflow)
+    DevBuf gaps, gaps_off, gaps_cap, ngaps, remap;
+    // ---- jobs: a JobSet is one seeded job list (device arrays + host mirrors); a Launch is the per-launch state of the
+    // job kernels (order, scratch); a TailBuf the per-launch state of a tail kernel.  Two of each: one per lane.
+    struct JobSet {
+        DevBuf j_read, j_str, j_end, j_mode, j_cap, j_look, j_anc_off, j_nanc, grp_beg, anchors, seed_ctl;
+        std::vector<u32> cap, look, nanc;
+        std::vector<u64> anc_off;
+        u64 anc_slots_per_job = 1536;   // running estimate of anchor slots per job (grows on overflow)
+        Timer t_seed;
+    } js[2];
+    // (host vectors that feed asynchronous uploads live here, not on the stack: the launch functions return before the copy ran)
+    struct Launch { DevBuf grp_order, j_scr_off, job_scr; std::vector<u32> h_order; std::vector<u64> h_scr_off; } ln[2];
+    struct TailBuf { DevBuf off, cap, scr, list; std::vector<u64> h_off; std::vector<u32> h_cap, h_list; } tb[3];
+    DevBuf prof, tl; u32 tl_round = 0, tl_n[4] = {0, 0, 0, 0}; u32 tl_nh[4] = {0, 0, 0, 0};
     // ---- results
     DevBuf r_off, r_str, r_end;
     std::vector<u64> h_cord_off, h_cords_str, h_cords_end, h_anchor_off, h_anchors;
     u32 last_n = 0;
     u64 last_ncords = 0;
     lnr_stats stats{};
-    Timer t_prep, t_sc, t_sg, t_job, t_tail, t_total;
+    Timer t_prep, t_job, t_tail, t_total;
 };
 
 namespace {
@@ -175,9 +186,13 @@ struct BatchHost {
     std::vector<u64> f1_off, cords_off, gaps_off, pk_off;
 };
 
-JobArrays job_arrays(lnr_ctx *ctx) {
+typedef lnr_ctx::JobSet JobSet;
+typedef lnr_ctx::Launch Launch;
+typedef lnr_ctx::TailBuf TailBuf;
+
+JobArrays job_arrays(JobSet &S) {
     JobArrays J;
-    J.read = ctx->j_read.as<u32>(); J.str = ctx->j_str.as<u32>(); J.end = ctx->j_end.as<u32>(); J.mode = ctx->j_mode.as<u32>();
+    J.read = S.j_read.as<u32>(); J.str = S.j_str.as<u32>(); J.end = S.j_end.as<u32>(); J.mode = S.j_mode.as<u32>();
     return J;
 }
 ReadArrays read_arrays(lnr_ctx *ctx) {
@@ -186,196 +201,192 @@ ReadArrays read_arrays(lnr_ctx *ctx) {
     R.pk = ctx->pk.as<u64>(); R.nm = ctx->nm.as<u32>(); R.pk_off = ctx->pk_off.as<u64>();
     return R;
 }
+template <class T>
+lnr_status upload_on(lnr_ctx *ctx, DevBuf &b, const std::vector<T> &v, hipStream_t st) {
+    ENSURE(b, std::max<size_t>(v.size() * sizeof(T), 16));
+    if (!v.empty()) HIPCK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return LNR_OK;
+}
 
-// Seed lookup (both passes) for the jobs in `hj`, optionally followed by the per-read job kernel.
-// Groups are processed in slices whose anchor + scratch footprint fits the scratch budget.
-lnr_status run_jobs(lnr_ctx *ctx, const HostJobs &hj, bool with_job_kernel, bool keep_anchor_layout) {
+// Seed lookup (k_seed_fused) of the job list `hj` into the job set S, on stream st.  Returns with the stream idle and the
+// per-job counts (bucket entries, lookups, anchors, anchor offsets) mirrored on the host.
+lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st) {
     u32 nj = hj.size();
+    S.cap.assign(nj, 0); S.look.assign(nj, 0); S.nanc.assign(nj, 0); S.anc_off.assign(nj, 0);
     if (nj == 0) return LNR_OK;
     lnr_status s;
-    if ((s = upload(ctx, ctx->j_read, hj.read)) != LNR_OK) return s;
-    if ((s = upload(ctx, ctx->j_str, hj.str)) != LNR_OK) return s;
-    if ((s = upload(ctx, ctx->j_end, hj.end)) != LNR_OK) return s;
-    if ((s = upload(ctx, ctx->j_mode, hj.mode)) != LNR_OK) return s;
-    if ((s = upload(ctx, ctx->grp_beg, hj.grp_beg)) != LNR_OK) return s;
-    ENSURE(ctx->j_cap, (size_t)nj * 4);
-    ENSURE(ctx->j_look, (size_t)nj * 4);
-    ENSURE(ctx->j_nanc, (size_t)nj * 4);
-    ENSURE(ctx->j_anc_off, (size_t)nj * 8);
-    ENSURE(ctx->j_scr_off, (size_t)nj * 8);
-    ENSURE(ctx->seed_ctl, 64);
-    JobArrays J = job_arrays(ctx);
+    if ((s = upload_on(ctx, S.j_read, hj.read, st)) != LNR_OK) return s;
+    if ((s = upload_on(ctx, S.j_str, hj.str, st)) != LNR_OK) return s;
+    if ((s = upload_on(ctx, S.j_end, hj.end, st)) != LNR_OK) return s;
+    if ((s = upload_on(ctx, S.j_mode, hj.mode, st)) != LNR_OK) return s;
+    if ((s = upload_on(ctx, S.grp_beg, hj.grp_beg, st)) != LNR_OK) return s;
+    ENSURE(S.j_cap, (size_t)nj * 4);
+    ENSURE(S.j_look, (size_t)nj * 4);
+    ENSURE(S.j_nanc, (size_t)nj * 4);
+    ENSURE(S.j_anc_off, (size_t)nj * 8);
+    ENSURE(S.seed_ctl, 64);
+    if (!S.t_seed.a) S.t_seed.init();
+    JobArrays J = job_arrays(S);
     ReadArrays R = read_arrays(ctx);
-    std::vector<u32> cap(nj), look(nj), nanc_all(nj);
-    std::vector<u64> anc_off(nj);
-    u64 anc_slots = std::max<u64>(ctx->anc_slots_per_job * nj, 1024);
+    u64 anc_slots = std::max<u64>(S.anc_slots_per_job * nj, 1024);
     for (int attempt = 0; attempt < 2; attempt++) {
-        ENSURE(ctx->anchors, anc_slots * 8);
-        HIPCK(hipMemsetAsync(ctx->seed_ctl.p, 0, 64, ctx->stream));
+        ENSURE(S.anchors, anc_slots * 8);
+        HIPCK(hipMemsetAsync(S.seed_ctl.p, 0, 64, st));
         SeedOutArrays O;
-        O.cursor = ctx->seed_ctl.as<unsigned long long>(); O.overflow = (int *)(ctx->seed_ctl.as<char>() + 16); O.capacity = anc_slots;
-        O.anchors = ctx->anchors.as<u64>(); O.anc_off = ctx->j_anc_off.as<u64>(); O.job_cap = ctx->j_cap.as<u32>(); O.job_look = ctx->j_look.as<u32>();
-        O.n_anchors = ctx->j_nanc.as<u32>();
-        ctx->t_sc.start(ctx->stream);
-        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, ctx->stream, J, R, ctx->dir.as<i32>(), ctx->bm.as<u32>(), ctx->hs.as<u64>(), nj, O);
+        O.cursor = S.seed_ctl.as<unsigned long long>(); O.overflow = (int *)(S.seed_ctl.as<char>() + 16); O.capacity = anc_slots;
+        O.anchors = S.anchors.as<u64>(); O.anc_off = S.j_anc_off.as<u64>(); O.job_cap = S.j_cap.as<u32>(); O.job_look = S.j_look.as<u32>();
+        O.n_anchors = S.j_nanc.as<u32>();
+        S.t_seed.start(st);
+        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->dir.as<i32>(), ctx->bm.as<u32>(), ctx->hs.as<u64>(), nj, O);
         KCHECK();
-        ctx->t_sc.stop(ctx->stream);
+        S.t_seed.stop(st);
         int ovf = 0;
-        HIPCK(hipMemcpyAsync(cap.data(), ctx->j_cap.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCK(hipMemcpyAsync(look.data(), ctx->j_look.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCK(hipMemcpyAsync(nanc_all.data(), ctx->j_nanc.p, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCK(hipMemcpyAsync(anc_off.data(), ctx->j_anc_off.p, (size_t)nj * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCK(hipMemcpyAsync(&ovf, ctx->seed_ctl.as<char>() + 16, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCK(hipStreamSynchronize(ctx->stream));
-        ctx->stats.seed_count_ms += ctx->t_sc.ms();
+        HIPCK(hipMemcpyAsync(S.cap.data(), S.j_cap.p, (size_t)nj * 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(S.look.data(), S.j_look.p, (size_t)nj * 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(S.nanc.data(), S.j_nanc.p, (size_t)nj * 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(S.anc_off.data(), S.j_anc_off.p, (size_t)nj * 8, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(&ovf, S.seed_ctl.as<char>() + 16, 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        ctx->stats.seed_count_ms += S.t_seed.ms();
         ctx->stats.seed_count_launches++;
         if (!ovf) break;
         if (attempt == 1) { ctx->err = "anchor buffer overflow after resize"; return LNR_ERR_INTERNAL; }
         u64 need = 0;
-        for (u32 j = 0; j < nj; j++) need += ((u64)cap[j] + 1) & ~1ULL;   // cap already includes the dummy
+        for (u32 j = 0; j < nj; j++) need += ((u64)S.cap[j] + 1) & ~1ULL;   // cap already includes the dummy
         anc_slots = need + 1024;
-        ctx->anc_slots_per_job = std::max<u64>(ctx->anc_slots_per_job, (need / nj) * 5 / 4 + 64);
+        S.anc_slots_per_job = std::max<u64>(S.anc_slots_per_job, (need / nj) * 5 / 4 + 64);
     }
     ctx->stats.jobs += nj;
     ctx->stats.samples += hj.nsamp;
-    for (u32 j = 0; j < nj; j++) { ctx->stats.lookups += look[j]; ctx->stats.bucket_entries += cap[j] - 1; ctx->stats.anchors += nanc_all[j] - 1; }
-    if (keep_anchor_layout) {
-        // export CSR of the raw anchors to the host arrays
-        ctx->h_anchor_off.assign(nj + 1, 0);
-        for (u32 j = 0; j < nj; j++) ctx->h_anchor_off[j + 1] = ctx->h_anchor_off[j] + nanc_all[j];
-        ctx->h_anchors.resize(ctx->h_anchor_off[nj]);
-        u64 used = 0;
-        for (u32 j = 0; j < nj; j++) used = std::max<u64>(used, anc_off[j] + nanc_all[j]);
-        std::vector<u64> all(used);
-        if (used) HIPCK(hipMemcpy(all.data(), ctx->anchors.p, used * 8, hipMemcpyDeviceToHost));
-        for (u32 j = 0; j < nj; j++) memcpy(ctx->h_anchors.data() + ctx->h_anchor_off[j], all.data() + anc_off[j], (size_t)nanc_all[j] * 8);
-    }
-    if (!with_job_kernel) return LNR_OK;
+    for (u32 j = 0; j < nj; j++) { ctx->stats.lookups += S.look[j]; ctx->stats.bucket_entries += S.cap[j] - 1; ctx->stats.anchors += S.nanc[j] - 1; }
+    return LNR_OK;
+}
 
-    // launch order: heaviest group first (anchors that passed the Y filter are the work proxy), so the long tail of
-    // repeat-rich reads starts at once instead of at the end of the grid
+// copy the raw anchors of a seeded job set to the host arrays (CSR by job)
+lnr_status export_anchors(lnr_ctx *ctx, JobSet &S, u32 nj) {
+    ctx->h_anchor_off.assign((size_t)nj + 1, 0);
+    for (u32 j = 0; j < nj; j++) ctx->h_anchor_off[j + 1] = ctx->h_anchor_off[j] + S.nanc[j];
+    ctx->h_anchors.resize(ctx->h_anchor_off[nj]);
+    u64 used = 0;
+    for (u32 j = 0; j < nj; j++) used = std::max<u64>(used, S.anc_off[j] + S.nanc[j]);
+    std::vector<u64> all(used);
+    if (used) HIPCK(hipMemcpy(all.data(), S.anchors.p, used * 8, hipMemcpyDeviceToHost));
+    for (u32 j = 0; j < nj; j++) memcpy(ctx->h_anchors.data() + ctx->h_anchor_off[j], all.data() + S.anc_off[j], (size_t)S.nanc[j] * 8);
+    return LNR_OK;
+}
+
+// Per-read job kernels for the groups `groups` of the seeded job set S (hj = its host list).  Heaviest group first (anchors
+// that passed the Y filter are the work proxy), so the long tail of repeat-rich reads starts at once.  The multi-wave
+// kernels go to lane's s_multi and are launched first: a multi-wave workgroup only finds a CU with enough free wave slots
+// while the single-wave kernel has not flooded the chip (it refills every slot a finished wave frees -- a late heavy
+// launch was measured to start only when the bulk kernel drained, 47 ms late).  The bulk kernel follows on s_bulk.  On
+// return everything is enqueued and s_multi also waits for s_bulk; nothing is synchronised unless the scratch budget
+// forces several slices.
+lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, const std::vector<u32> &groups, int lane) {
+    u32 ngrp = (u32)groups.size();
+    if (ngrp == 0) return LNR_OK;
+    u32 nj = hj.size();
+    hipStream_t sm = ctx->s_multi[lane], sb = ctx->s_bulk[lane];
     u64 budget = ctx->opts.scratch_budget ? ctx->opts.scratch_budget : (24ULL << 30);
-    u32 ngrp = (u32)hj.grp_beg.size() - 1;
-    std::vector<u32> order(ngrp);
+    const std::vector<u32> &cap = S.cap, &nanc = S.nanc;
+    std::vector<u64> w(ngrp, 0);
+    for (u32 k = 0; k < ngrp; k++) for (u32 j = hj.grp_beg[groups[k]]; j < hj.grp_beg[groups[k] + 1]; j++) w[k] += nanc[j];
+    std::vector<u32> order(ngrp);   // indices into `groups`, heaviest first
     {
-        // counting sort by weight class, heaviest first: classes are 1/8-octave steps of the group's anchor count, so
-        // the order is "descending up to 9 %" -- all the scheduler needs -- in O(n)
-        std::vector<u64> w(ngrp, 0);
-        for (u32 g = 0; g < ngrp; g++) for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) w[g] += nanc_all[j];
+        // counting sort by weight class (1/8-octave steps: "descending up to 9 %" is all the scheduler needs) in O(n),
+        // then the small multi-wave prefix in exact order (the size-class cut below walks it)
         auto cls = [](u64 v) -> u32 {
             if (v < 8) return (u32)v;
             int lg = 63 - __builtin_clzll(v);
             return (u32)(8 * (lg - 2) + ((v >> (lg - 3)) & 7));
         };
         const u32 NCLS = 8 * 64;
-        std::vector<u32> cnt(NCLS + 1, 0);
-        std::vector<u32> gc(ngrp);
-        for (u32 g = 0; g < ngrp; g++) { gc[g] = NCLS - 1 - std::min<u32>(cls(w[g]), NCLS - 1); cnt[gc[g] + 1]++; }
+        std::vector<u32> cnt(NCLS + 1, 0), gc(ngrp);
+        for (u32 k = 0; k < ngrp; k++) { gc[k] = NCLS - 1 - std::min<u32>(cls(w[k]), NCLS - 1); cnt[gc[k] + 1]++; }
         for (u32 c = 0; c < NCLS; c++) cnt[c + 1] += cnt[c];
-        for (u32 g = 0; g < ngrp; g++) order[cnt[gc[g]]++] = g;
-        // the heavy prefix is small: put it in exact descending order (the size-class cut below walks it)
+        for (u32 k = 0; k < ngrp; k++) order[cnt[gc[k]]++] = k;
         u32 nh = 0;
         while (nh < ngrp && w[order[nh]] >= std::min<u64>(ctx->heavy_cap, ctx->mid_cap) / 2) nh++;
         std::stable_sort(order.begin(), order.begin() + nh, [&w](u32 a, u32 b) { return w[a] > w[b]; });
     }
-    std::vector<u32> job_list;
-    job_list.reserve(nj);
-    std::vector<u32> ord_job_beg(ngrp + 1, 0);
-    for (u32 k = 0; k < ngrp; k++) {
-        u32 g = order[k];
-        ord_job_beg[k] = (u32)job_list.size();
-        for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) job_list.push_back(j);
-    }
-    ord_job_beg[ngrp] = (u32)job_list.size();
-    if ((s = upload(ctx, ctx->grp_order, order)) != LNR_OK) return s;
-    if ((s = upload(ctx, ctx->job_list, job_list)) != LNR_OK) return s;
-    // slices of (ordered) groups under the scratch budget
-    std::vector<u64> scr_off(nj);
+    std::vector<u32> &dev_order = Lx.h_order;
+    dev_order.resize(ngrp);
+    for (u32 k = 0; k < ngrp; k++) dev_order[k] = groups[order[k]];
+    lnr_status s;
+    if ((s = upload_on(ctx, Lx.grp_order, dev_order, sm)) != LNR_OK) return s;
+    ENSURE(Lx.j_scr_off, (size_t)nj * 8);
+    std::vector<u64> &scr_off = Lx.h_scr_off;
+    scr_off.assign(nj, 0);
+    auto grp_scr = [&](u32 g) { u64 b = 0; for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) b += align_up(job_scratch_bytes((u64)cap[j] + 2), 256); return b; };
     u32 g0 = 0;
     while (g0 < ngrp) {
         u64 scr = 0;
         u32 g1 = g0;
         while (g1 < ngrp) {
-            u64 s2 = scr;
-            for (u32 q = ord_job_beg[g1]; q < ord_job_beg[g1 + 1]; q++) s2 += align_up(job_scratch_bytes((u64)cap[job_list[q]] + 2), 256);
+            u64 s2 = scr + grp_scr(dev_order[g1]);
             if (g1 > g0 && s2 > budget) break;
             scr = s2; g1++;
         }
         u64 so = 0;
-        u32 j0 = ord_job_beg[g0], j1 = ord_job_beg[g1];   // positions in job_list
-        for (u32 q = j0; q < j1; q++) { u32 j = job_list[q]; scr_off[j] = so; so += align_up(job_scratch_bytes((u64)cap[j] + 2), 256); }
-        ENSURE(ctx->job_scr, std::max<u64>(so, 16));
-        HIPCK(hipMemcpyAsync(ctx->j_scr_off.p, scr_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, ctx->stream));
-        if (with_job_kernel) {
-            JobArgs A;
-            A.grp_order = ctx->grp_order.as<u32>(); A.grp_beg = ctx->grp_beg.as<u32>(); A.J = J;
-            A.anc_off = ctx->j_anc_off.as<u64>(); A.job_cap = ctx->j_cap.as<u32>(); A.n_anchors = ctx->j_nanc.as<u32>(); A.scr_off = ctx->j_scr_off.as<u64>();
-            A.anchors = ctx->anchors.as<u64>(); A.scratch = ctx->job_scr.as<char>();
-            A.read_len = ctx->rlen.as<u32>(); A.f1_off = ctx->f1_off.as<u64>(); A.nf = ctx->nf.as<u32>(); A.f1 = ctx->f1.as<F96>();
-            A.g.base = ctx->f2.as<F96>(); A.g.off = ctx->d_f2_off.as<u64>(); A.g.nseq = ctx->info.nseq;
-            A.cords = ctx->cords.as<u64>(); A.cords_off = ctx->cords_off.as<u64>(); A.cords_cap = ctx->cords_cap.as<u32>(); A.ncords = ctx->ncords.as<u32>();
-            A.read_err = ctx->read_err.as<i32>();
-            A.nbins = ctx->nbins; A.grp_lo = g0; A.grp_hi = g1;
-            A.prof = nullptr;
+        for (u32 k = g0; k < g1; k++)
+            for (u32 j = hj.grp_beg[dev_order[k]]; j < hj.grp_beg[dev_order[k] + 1]; j++) { scr_off[j] = so; so += align_up(job_scratch_bytes((u64)cap[j] + 2), 256); }
+        ENSURE(Lx.job_scr, std::max<u64>(so, 16));
+        HIPCK(hipMemcpyAsync(Lx.j_scr_off.p, scr_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, sm));
+        JobArgs A;
+        A.grp_order = Lx.grp_order.as<u32>(); A.grp_beg = S.grp_beg.as<u32>(); A.J = job_arrays(S);
+        A.anc_off = S.j_anc_off.as<u64>(); A.job_cap = S.j_cap.as<u32>(); A.n_anchors = S.j_nanc.as<u32>(); A.scr_off = Lx.j_scr_off.as<u64>();
+        A.anchors = S.anchors.as<u64>(); A.scratch = Lx.job_scr.as<char>();
+        A.read_len = ctx->rlen.as<u32>(); A.f1_off = ctx->f1_off.as<u64>(); A.nf = ctx->nf.as<u32>(); A.f1 = ctx->f1.as<F96>();
+        A.g.base = ctx->f2.as<F96>(); A.g.off = ctx->d_f2_off.as<u64>(); A.g.nseq = ctx->info.nseq;
+        A.cords = ctx->cords.as<u64>(); A.cords_off = ctx->cords_off.as<u64>(); A.cords_cap = ctx->cords_cap.as<u32>(); A.ncords = ctx->ncords.as<u32>();
+        A.read_err = ctx->read_err.as<i32>();
+        A.nbins = ctx->nbins; A.grp_lo = g0; A.grp_hi = g1;
+        A.prof = nullptr; A.tl = nullptr;
+        size_t lds_min = (((size_t)((ctx->nbins + 1) / 2) * 4) + 15) & ~(size_t)15;
+        size_t arena = (ctx->job_lds_bytes + 15) & ~(size_t)15;
+        size_t lds = std::max<size_t>(lds_min, arena + ctx->job_stage_bytes);
+        A.lds_bytes = (u32)lds;
+        A.arena_lds = (u32)arena;
+        // size classes along the (weight-descending) slice: heavy = 16 waves per read, mid = 4 waves, rest = 1 wave
+        u32 gh = g0;
+        while (gh < g1 && w[order[gh]] >= ctx->heavy_cap) gh++;
+        u32 gm = gh;
+        while (gm < g1 && w[order[gm]] >= ctx->mid_cap) gm++;
 #ifdef LNR_PROF
-            if (!ctx->prof.p) { if (!ctx->prof.ensure(128 * 8)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->prof.p, 0, 128 * 8, ctx->stream); }
-            A.prof = ctx->prof.as<unsigned long long>();
-            // timeline: up to 4 launches (rounds) of up to 2^20 positions
-            if (!ctx->tl.p) { if (!ctx->tl.ensure(4ULL * (1u << 20) * 32)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->tl.p, 0, 4ULL * (1u << 20) * 32, ctx->stream); }
-            A.tl = nullptr;
-            if (ctx->tl_round < 4 && g1 <= (1u << 20)) { A.tl = ctx->tl.as<unsigned long long>() + (size_t)ctx->tl_round * (1u << 20) * 4; ctx->tl_n[ctx->tl_round] = g1; }
-#else
-            A.tl = nullptr;
+        if (!ctx->prof.p) { if (!ctx->prof.ensure(128 * 8)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->prof.p, 0, 128 * 8, sm); }
+        A.prof = ctx->prof.as<unsigned long long>();
+        // timeline: up to 4 launches of up to 2^20 positions
+        if (!ctx->tl.p) { if (!ctx->tl.ensure(4ULL * (1u << 20) * 32)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->tl.p, 0, 4ULL * (1u << 20) * 32, sm); }
+        if (ctx->tl_round < 4 && g1 <= (1u << 20)) { A.tl = ctx->tl.as<unsigned long long>() + (size_t)ctx->tl_round * (1u << 20) * 4; ctx->tl_n[ctx->tl_round] = g1; ctx->tl_nh[ctx->tl_round] = gm; }
+        ctx->tl_round++;
 #endif
-            size_t lds_min = (((size_t)((ctx->nbins + 1) / 2) * 4) + 15) & ~(size_t)15;
-            size_t arena = (ctx->job_lds_bytes + 15) & ~(size_t)15;
-            size_t lds = std::max<size_t>(lds_min, arena + ctx->job_stage_bytes);
-            A.lds_bytes = (u32)lds;
-            A.arena_lds = (u32)arena;
-            // three size classes along the (weight-descending) slice: heavy = 16 waves per read, mid = 4 waves, rest = 1 wave
-            auto wsum_of = [&](u32 g) { u64 w = 0; for (u32 q = ord_job_beg[g]; q < ord_job_beg[g + 1]; q++) w += nanc_all[job_list[q]]; return w; };
-            u32 gh = g0;
-            while (gh < g1 && wsum_of(gh) >= ctx->heavy_cap) gh++;
-            u32 gm = gh;
-            while (gm < g1 && wsum_of(gm) >= ctx->mid_cap) gm++;
-#ifdef LNR_PROF
-            if (ctx->tl_round < 4) ctx->tl_nh[ctx->tl_round] = gh;
-            ctx->tl_round++;
-#endif
-            // The multi-wave kernels go first and on the main stream: a 16-wave workgroup only finds a CU with 16 free wave
-            // slots while the single-wave kernel has not flooded the chip yet (it refills every slot a finished wave frees,
-            // so a late heavy launch starts only when the bulk kernel drains -- measured: 47 ms late).  The bulk kernel
-            // follows on the second stream behind an event recorded before the heavy launch.
-            ctx->t_job.start(ctx->stream);
-            bool side = (gh > g0 || gm > gh) && g1 > gm;
-            if (side) HIPCK(hipEventRecord(ctx->ev_fork, ctx->stream));
-            if (gh > g0) {
-                JobArgs H = A;
-                size_t hl = std::max<size_t>(lds_min, (size_t)ctx->heavy_lds_kb * 1024);
-                H.grp_lo = g0; H.grp_hi = gh; H.lds_bytes = (u32)hl; H.arena_lds = (u32)hl;
-                hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, ctx->stream, H);
-                KCHECK();
-            }
-            if (gm > gh) {
-                JobArgs M = A;
-                size_t ml = std::max<size_t>(lds_min, (size_t)ctx->mid_lds_kb * 1024);
-                M.grp_lo = gh; M.grp_hi = gm; M.lds_bytes = (u32)ml; M.arena_lds = (u32)ml;
-                hipLaunchKernelGGL(k_job_mid, dim3(gm - gh), dim3(256), ml, ctx->stream, M);
-                KCHECK();
-            }
-            if (g1 > gm) {
-                hipStream_t bulk = side ? ctx->stream2 : ctx->stream;
-                if (side) HIPCK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-                A.grp_lo = gm; A.grp_hi = g1;
-                hipLaunchKernelGGL(k_job, dim3(g1 - gm), dim3(64), lds, bulk, A);
-                KCHECK();
-                if (side) { HIPCK(hipEventRecord(ctx->ev_join, ctx->stream2)); HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); }
-            }
-            ctx->t_job.stop(ctx->stream);
+        bool side = gm > g0 && g1 > gm && sb != sm;
+        if (side) HIPCK(hipEventRecord(ctx->ev_fork[lane], sm));    // before the multi-wave launches: the bulk kernel must not wait for them
+        if (gh > g0) {
+            JobArgs H = A;
+            size_t hl = std::max<size_t>(lds_min, (size_t)ctx->heavy_lds_kb * 1024);
+            H.grp_lo = g0; H.grp_hi = gh; H.lds_bytes = (u32)hl; H.arena_lds = (u32)hl;
+            hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, sm, H);
+            KCHECK();
         }
-        HIPCK(hipStreamSynchronize(ctx->stream));
-        if (with_job_kernel) { ctx->stats.job_ms += ctx->t_job.ms(); ctx->stats.job_launches++; }
+        if (gm > gh) {
+            JobArgs M = A;
+            size_t ml = std::max<size_t>(lds_min, (size_t)ctx->mid_lds_kb * 1024);
+            M.grp_lo = gh; M.grp_hi = gm; M.lds_bytes = (u32)ml; M.arena_lds = (u32)ml;
+            hipLaunchKernelGGL(k_job_mid, dim3(gm - gh), dim3(256), ml, sm, M);
+            KCHECK();
+        }
+        if (g1 > gm) {
+            hipStream_t bulk = side ? sb : sm;
+            if (side) HIPCK(hipStreamWaitEvent(sb, ctx->ev_fork[lane], 0));
+            A.grp_lo = gm; A.grp_hi = g1;
+            hipLaunchKernelGGL(k_job, dim3(g1 - gm), dim3(64), lds, bulk, A);
+            KCHECK();
+            if (side) { HIPCK(hipEventRecord(ctx->ev_join[lane], sb)); HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[lane], 0)); }
+        }
+        ctx->stats.job_launches++;
         g0 = g1;
+        if (g0 < ngrp) HIPCK(hipStreamSynchronize(sm));   // next slice reuses the scratch
     }
     return LNR_OK;
 }
@@ -438,31 +449,36 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     return LNR_OK;
 }
 
-lnr_status tail_sizes(lnr_ctx *ctx, const BatchHost &B, std::vector<u32> &ncords) {
+// Scratch layout + launch arguments of a tail kernel over the reads in `list` (null = all reads), on stream st.
+// Returns with the stream idle (it reads the current cord counts back to size the scratch).
+lnr_status tail_prepare(lnr_ctx *ctx, const BatchHost &B, TailBuf &tb, const std::vector<u32> *list, hipStream_t st, TailArgs &T) {
     u32 n = B.n;
-    ncords.resize(n);
-    HIPCK(hipMemcpyAsync(ncords.data(), ctx->ncords.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCK(hipStreamSynchronize(ctx->stream));
-    std::vector<u64> off(n);
-    std::vector<u32> cap(n);
+    std::vector<u32> ncords(n);
+    HIPCK(hipMemcpyAsync(ncords.data(), ctx->ncords.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));   // (counts of reads another lane is still working on are not used)
+    tb.h_off.assign(n, 0); tb.h_cap.assign(n, 0);
     u64 o = 0;
-    for (u32 i = 0; i < n; i++) { cap[i] = ncords[i] + 4; off[i] = o; o += align_up(tail_scratch_bytes(cap[i]), 256); }
+    u32 cnt = list ? (u32)list->size() : n;
+    for (u32 k = 0; k < cnt; k++) {
+        u32 i = list ? (*list)[k] : k;
+        tb.h_cap[i] = ncords[i] + 4; tb.h_off[i] = o; o += align_up(tail_scratch_bytes(tb.h_cap[i]), 256);
+    }
     lnr_status s;
-    if ((s = upload(ctx, ctx->tail_off, off)) != LNR_OK) return s;
-    if ((s = upload(ctx, ctx->tail_cap, cap)) != LNR_OK) return s;
-    ENSURE(ctx->tail_scr, std::max<u64>(o, 16));
-    return LNR_OK;
-}
-
-TailArgs tail_args(lnr_ctx *ctx, u32 n) {
-    TailArgs T;
-    T.read_len = ctx->rlen.as<u32>(); T.n = n;
+    if ((s = upload_on(ctx, tb.off, tb.h_off, st)) != LNR_OK) return s;
+    if ((s = upload_on(ctx, tb.cap, tb.h_cap, st)) != LNR_OK) return s;
+    ENSURE(tb.scr, std::max<u64>(o, 16));
+    T.read_len = ctx->rlen.as<u32>(); T.n = cnt; T.list = nullptr;
+    if (list) {
+        tb.h_list = *list;
+        if ((s = upload_on(ctx, tb.list, tb.h_list, st)) != LNR_OK) return s;
+        T.list = tb.list.as<u32>();
+    }
     T.cords = ctx->cords.as<u64>(); T.cords_off = ctx->cords_off.as<u64>(); T.cords_cap = ctx->cords_cap.as<u32>(); T.ncords = ctx->ncords.as<u32>();
     T.read_err = ctx->read_err.as<i32>();
-    T.scratch = ctx->tail_scr.as<char>(); T.scr_off = ctx->tail_off.as<u64>(); T.scr_cap = ctx->tail_cap.as<u32>();
+    T.scratch = tb.scr.as<char>(); T.scr_off = tb.off.as<u64>(); T.scr_cap = tb.cap.as<u32>();
     T.gaps = ctx->gaps.as<UP>(); T.gaps_off = ctx->gaps_off.as<u64>(); T.gaps_cap = ctx->gaps_cap.as<u32>(); T.ngaps = ctx->ngaps.as<u32>(); T.remap = ctx->remap.as<u32>();
     T.out_str = ctx->out_str.as<u64>(); T.out_end = ctx->out_end.as<u64>(); T.nout = ctx->nout.as<u32>();
-    return T;
+    return LNR_OK;
 }
 
 void reset_stats(lnr_ctx *ctx) { memset(&ctx->stats, 0, sizeof ctx->stats); }
@@ -470,6 +486,45 @@ void finish_stats(lnr_ctx *ctx, const BatchHost &B) {
     u64 rb = 0;
     for (u32 i = 0; i < B.n; i++) if (B.len[i] > 200) rb += (B.len[i] + 3) / 4;
     ctx->stats.seed_bytes = rb + ctx->stats.lookups * 8 + ctx->stats.bucket_entries * 8 + ctx->stats.anchors * 8;
+}
+
+// Tail A + re-map round of the reads in `list` (whose round 0 has completed on the lane's s_multi): clean / gather /
+// gaps decide the remap loop (pmpfinder.cpp:2744-2749); every gap of a poorly covered read is then re-seeded with
+// step 7 / score0 (pmpfinder.cpp:2749-2767).  Uses job set S and launch state Lx; returns with the launches enqueued.
+lnr_status remap_round(lnr_ctx *ctx, const BatchHost &B, const std::vector<u32> &list, int lane, JobSet &S, Launch &Lx, TailBuf &tb, HostJobs &j1) {
+    if (list.empty()) return LNR_OK;
+    hipStream_t st = ctx->s_multi[lane];
+    u32 n = B.n;
+    TailArgs T;
+    lnr_status s;
+    if ((s = tail_prepare(ctx, B, tb, &list, st, T)) != LNR_OK) return s;
+    hipLaunchKernelGGL(k_tail_a, dim3((T.n + 63) / 64), dim3(64), 0, st, T);
+    KCHECK();
+    std::vector<u32> remap(n), ngaps(n);
+    HIPCK(hipMemcpyAsync(remap.data(), ctx->remap.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(ngaps.data(), ctx->ngaps.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    bool any = false;
+    for (u32 i : list) if (remap[i] && ngaps[i]) { any = true; break; }
+    if (!any) return LNR_OK;
+    u64 gtot = B.gaps_off[n - 1] + B.gaps_cap[n - 1];
+    std::vector<UP> gaps(gtot);
+    HIPCK(hipMemcpyAsync(gaps.data(), ctx->gaps.p, gtot * sizeof(UP), hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    for (u32 i : list) {
+        if (!(remap[i] && ngaps[i])) continue;
+        ctx->stats.remap_reads++;
+        j1.grp_beg.push_back(j1.size());
+        for (u32 k = 0; k < ngaps[i]; k++) {
+            UP y = forward_y(gaps[B.gaps_off[i] + k], B.len[i]);
+            j1.add(i, (u32)y.first, (u32)y.second, 1);
+        }
+    }
+    j1.grp_beg.push_back(j1.size());
+    if ((s = seed_jobs(ctx, S, j1, st)) != LNR_OK) return s;
+    std::vector<u32> all((size_t)j1.grp_beg.size() - 1);
+    for (u32 g = 0; g < all.size(); g++) all[g] = g;
+    return launch_jobs(ctx, S, Lx, j1, all, lane);
 }
 
 lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, lnr_cords_dev *out) {
@@ -494,44 +549,42 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         if (B.len[i] > 200) { j0.grp_beg.push_back(j0.size()); j0.add(i, 0, B.len[i], 0); }
     }
     j0.grp_beg.push_back(j0.size());
-    if ((s = run_jobs(ctx, j0, true, false)) != LNR_OK) return s;
-    // tail A: clean / gather / gaps, decides the remap loop (pmpfinder.cpp:2744-2749)
-    std::vector<u32> ncords;
-    if ((s = tail_sizes(ctx, B, ncords)) != LNR_OK) return s;
-    TailArgs T = tail_args(ctx, n);
-    ctx->t_tail.start(ctx->stream);
-    hipLaunchKernelGGL(k_tail_a, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, T);
-    KCHECK();
-    ctx->t_tail.stop(ctx->stream);
-    std::vector<u32> remap(n), ngaps(n);
-    HIPCK(hipMemcpyAsync(remap.data(), ctx->remap.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCK(hipMemcpyAsync(ngaps.data(), ctx->ngaps.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCK(hipStreamSynchronize(ctx->stream));
-    ctx->stats.tail_ms += ctx->t_tail.ms();
-    // remap loop (pmpfinder.cpp:2749-2767): every gap of a poorly covered read is re-seeded with step 7 / score0
-    HostJobs j1;
-    u64 gtot = B.gaps_off[n - 1] + B.gaps_cap[n - 1];
-    std::vector<UP> gaps;
-    bool any = false;
-    for (u32 i = 0; i < n; i++) if (remap[i] && ngaps[i]) { any = true; break; }
-    if (any) {
-        gaps.resize(gtot);
-        HIPCK(hipMemcpy(gaps.data(), ctx->gaps.p, gtot * sizeof(UP), hipMemcpyDeviceToHost));
-        for (u32 i = 0; i < n; i++) {
-            if (!(remap[i] && ngaps[i])) continue;
-            ctx->stats.remap_reads++;
-            j1.grp_beg.push_back(j1.size());
-            for (u32 k = 0; k < ngaps[i]; k++) {
-                UP y = forward_y(gaps[B.gaps_off[i] + k], B.len[i]);
-                j1.add(i, (u32)y.first, (u32)y.second, 1);
-            }
-        }
-        j1.grp_beg.push_back(j1.size());
-        if ((s = run_jobs(ctx, j1, true, false)) != LNR_OK) return s;
+    JobSet &S0 = ctx->js[0], &S1 = ctx->js[1];
+    if ((s = seed_jobs(ctx, S0, j0, ctx->stream)) != LNR_OK) return s;
+    // Two lanes.  Lane 0 = the reads with many anchors (they hold the long chaining jobs of both rounds), lane 1 = the bulk.
+    // The reference maps read by read, so any interleaving of reads is the same computation; here lane 0 goes through
+    // round 0 -> tail A -> re-map round while lane 1 is still in round 0, instead of a batch-wide barrier per round.
+    u32 ngrp0 = (u32)j0.grp_beg.size() - 1;
+    std::vector<u32> grp[2], reads[2];
+    std::vector<char> in_heavy(n, 0);
+    for (u32 g = 0; g < ngrp0; g++) {
+        u64 w = 0;
+        for (u32 j = j0.grp_beg[g]; j < j0.grp_beg[g + 1]; j++) w += S0.nanc[j];
+        int lane = w >= ctx->split_cap ? 0 : 1;
+        grp[lane].push_back(g);
+        if (lane == 0) in_heavy[j0.read[j0.grp_beg[g]]] = 1;
     }
+    for (u32 i = 0; i < n; i++) reads[in_heavy[i] ? 0 : 1].push_back(i);   // reads without a job go with the bulk
+    ctx->t_job.start(ctx->stream);
+    HIPCK(hipEventRecord(ctx->ev_start, ctx->stream));
+    HIPCK(hipStreamWaitEvent(ctx->s_multi[0], ctx->ev_start, 0));
+    HIPCK(hipStreamWaitEvent(ctx->s_bulk[1], ctx->ev_start, 0));
+    if ((s = launch_jobs(ctx, S0, ctx->ln[0], j0, grp[0], 0)) != LNR_OK) return s;
+    if ((s = launch_jobs(ctx, S0, ctx->ln[1], j0, grp[1], 1)) != LNR_OK) return s;
+    // lane 0: tail A + re-map round as soon as its round 0 is done (job set 1: lane 1 still reads job set 0)
+    HostJobs j1h, j1b;
+    if ((s = remap_round(ctx, B, reads[0], 0, S1, ctx->ln[0], ctx->tb[0], j1h)) != LNR_OK) return s;
+    // lane 1: the same once the bulk is through round 0; by then nobody reads job set 0 any more
+    HIPCK(hipStreamSynchronize(ctx->s_multi[1]));
+    if ((s = remap_round(ctx, B, reads[1], 1, S0, ctx->ln[1], ctx->tb[1], j1b)) != LNR_OK) return s;
+    HIPCK(hipEventRecord(ctx->ev_lane[0], ctx->s_multi[0]));
+    HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_lane[0], 0));   // (lane 1's multi stream is the main stream)
+    ctx->t_job.stop(ctx->stream);
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    ctx->stats.job_ms += ctx->t_job.ms();
     // tail B: block chaining on both strands, flags, cords_end (pmpfinder.cpp:2764-2801)
-    if ((s = tail_sizes(ctx, B, ncords)) != LNR_OK) return s;
-    T = tail_args(ctx, n);
+    TailArgs T;
+    if ((s = tail_prepare(ctx, B, ctx->tb[2], nullptr, ctx->stream, T)) != LNR_OK) return s;
     ctx->t_tail.start(ctx->stream);
     hipLaunchKernelGGL(k_tail_b, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, T);
     KCHECK();
@@ -585,8 +638,8 @@ lnr_status seed_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, bo
         if (B.len[i] >= 43) { job_of[i] = j0.size(); j0.grp_beg.push_back(j0.size()); j0.add(i, 0, B.len[i], 0); }
     }
     j0.grp_beg.push_back(j0.size());
-    std::vector<u64> joff, janc;
-    if ((s = run_jobs(ctx, j0, false, to_host)) != LNR_OK) return s;
+    if ((s = seed_jobs(ctx, ctx->js[0], j0, ctx->stream)) != LNR_OK) return s;
+    if (to_host && (s = export_anchors(ctx, ctx->js[0], j0.size())) != LNR_OK) return s;
     ctx->t_total.stop(ctx->stream);
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->stats.prep_ms = ctx->t_prep.ms();
@@ -677,10 +730,20 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_HEAVY_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->heavy_lds_kb = (u32)v; }
     if (const char *e = getenv("LNR_MID_CAP")) { long v = atol(e); if (v >= 64) ctx->mid_cap = (u32)v; }
     if (const char *e = getenv("LNR_MID_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->mid_lds_kb = (u32)v; }
-    if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
-    ctx->t_prep.init(); ctx->t_sc.init(); ctx->t_sg.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();
+    if (const char *e = getenv("LNR_SPLIT_CAP")) { long v = atol(e); if (v >= 1) ctx->split_cap = (u32)std::min<long>(v, 0xffffffffL); }
+    // Three streams in all: the runtime multiplexes streams onto a few hardware queues (4 by default) and two streams on
+    // one queue run their kernels back to back (measured: the bulk kernel waited for the 4-wave kernel).  Lane 1 (bulk)
+    // uses the main stream for its multi-wave kernels, seeds and tails and one side stream for the single-wave kernel;
+    // lane 0 (heavy reads, nearly all multi-wave) runs everything on one stream.
+    bool ok = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->s_multi[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ctx->s_bulk[1], hipStreamNonBlocking) == hipSuccess;
+    ctx->s_bulk[0] = ctx->s_multi[0];
+    ctx->s_multi[1] = ctx->stream;
+    for (int l = 0; l < 2 && ok; l++)
+        ok = hipEventCreateWithFlags(&ctx->ev_fork[l], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_join[l], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_lane[l], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { lnr_destroy(ctx); return LNR_ERR_HIP; }
+    ctx->t_prep.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();
     *out = ctx;
     return LNR_OK;
 }
@@ -689,19 +752,20 @@ void lnr_destroy(lnr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->g, &ctx->dir, &ctx->hs, &ctx->f2, &ctx->d_seq_off, &ctx->d_f2_off, &ctx->bm, &ctx->pk, &ctx->nm, &ctx->pk_off, &ctx->in_reads, &ctx->in_off,
-                      &ctx->rlen, &ctx->rks, &ctx->nf, &ctx->f1_off, &ctx->f1, &ctx->cords, &ctx->out_str, &ctx->out_end, &ctx->cords_off,
-                      &ctx->cords_cap, &ctx->ncords, &ctx->nout, &ctx->read_err, &ctx->tail_scr, &ctx->tail_off, &ctx->tail_cap, &ctx->gaps, &ctx->gaps_off,
-                      &ctx->gaps_cap, &ctx->ngaps, &ctx->remap, &ctx->j_read, &ctx->j_str, &ctx->j_end, &ctx->j_mode, &ctx->j_cap,
-                      &ctx->j_look, &ctx->j_anc_off, &ctx->j_scr_off, &ctx->j_nanc, &ctx->grp_beg, &ctx->anchors, &ctx->job_scr, &ctx->r_off,
-                      &ctx->r_str, &ctx->r_end};
-    for (DevBuf *b : bufs) b->release();
-    ctx->t_prep.destroy(); ctx->t_sc.destroy(); ctx->t_sg.destroy(); ctx->t_job.destroy(); ctx->t_tail.destroy(); ctx->t_total.destroy();
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
-    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (int l = 0; l < 2; l++) {
+        if (ctx->s_multi[l]) (void)hipStreamSynchronize(ctx->s_multi[l]);
+        if (ctx->s_bulk[l]) (void)hipStreamSynchronize(ctx->s_bulk[l]);
+    }
+    ctx->t_prep.destroy(); ctx->t_job.destroy(); ctx->t_tail.destroy(); ctx->t_total.destroy();
+    for (int l = 0; l < 2; l++) {
+        ctx->js[l].t_seed.destroy();
+        if (ctx->ev_fork[l]) (void)hipEventDestroy(ctx->ev_fork[l]);
+        if (ctx->ev_join[l]) (void)hipEventDestroy(ctx->ev_join[l]);
+        if (ctx->ev_lane[l]) (void)hipEventDestroy(ctx->ev_lane[l]);
+    }
+    if (ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_multi[0]);
+    if (ctx->s_bulk[1]) (void)hipStreamDestroy(ctx->s_bulk[1]);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -822,8 +822,24 @@ __device__ __forceinline__ void dp_window_bounds(const u32 *xs, u32 m, i32 *jlo,
     }
 }
 __device__ __forceinline__ i64 dp_key(int total, int j) { return ((i64)total << 32) | (i64)(u32)(0x7fffffff - j); }
+// One predecessor (uniform) against the lane's anchor.  Most pairs of a repeat-rich window are far off the diagonal and
+// score <= 0; a cheap necessary condition for a positive score is tested first and the full score (division, polynomials)
+// is skipped when NO lane of the wave can be positive:
+//   getApxChainScore : da >= 10 and 7 da >= M  =>  derr >= 14  =>  score_derr >= 126  =>  score < 0
+//   getApxChainScore0: score = 100 - dy - (da < 30 ? 0 : da) > 0 needs dy < 100 and da < 100
 template <int ST>
 __device__ __forceinline__ void dp_eval(i64 &best, u32 px, u32 py, i32 ps, int jj, u32 xi, u32 yi, bool act) {
+    i32 dy = (i32)py - (i32)yi, dx = (i32)px - (i32)xi;
+    i32 t = dx - dy;
+    u32 da = (u32)(t < 0 ? -t : t);
+    bool cand;
+    if (ST) cand = act && dy >= 5 && dy < 100 && da < 100;
+    else {
+        u32 adx = (u32)(dx < 0 ? -dx : dx);
+        u32 M = (u32)(dy < 0 ? 0 : dy); M = M > adx ? M : adx; M = M < 50 ? 50 : M;
+        cand = act && dy >= 10 && da < M && (da < 10 || (u64)da * 7 < (u64)M);
+    }
+    if (__ballot(cand) == 0) return;
     int sc = ST ? chain_score0_bl(px, py, xi, yi) : chain_score_bl(px, py, xi, yi);
     if (act && sc > 0) { i64 key = dp_key(sc + ps, jj); best = key > best ? key : best; }
 }
@@ -1309,6 +1325,7 @@ __global__ void __launch_bounds__(256, 4) k_job_mid(JobArgs A) {
 // =================================================================== tails ====
 struct TailArgs {
     const u32 *read_len; u32 n;
+    const u32 *list;            // optional: the reads this launch covers (n = its length); null = reads 0..n-1
     u64 *cords; const u64 *cords_off; const u32 *cords_cap; u32 *ncords; i32 *read_err;
     char *scratch; const u64 *scr_off; const u32 *scr_cap;   // per read: bytes offset / capacity in cord slots used for sizing
     UP *gaps; const u64 *gaps_off; const u32 *gaps_cap; u32 *ngaps; u32 *remap;
@@ -1317,6 +1334,7 @@ struct TailArgs {
 __global__ void __launch_bounds__(64) k_tail_a(TailArgs T) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= T.n) return;
+    if (T.list) r = T.list[r];
     T.ngaps[r] = 0; T.remap[r] = 0;
     u64 L = T.read_len[r];
     if (L <= 200 || T.read_err[r]) return;
@@ -1330,6 +1348,7 @@ __global__ void __launch_bounds__(64) k_tail_a(TailArgs T) {
 __global__ void __launch_bounds__(64) k_tail_b(TailArgs T) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= T.n) return;
+    if (T.list) r = T.list[r];
     T.nout[r] = 0;
     u64 L = T.read_len[r];
     if (L <= 200 || T.read_err[r]) return;
