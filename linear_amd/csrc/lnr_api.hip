@@ -288,7 +288,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
     u32 nj = hj.size();
     hipStream_t sm = ctx->s_multi[lane], sb = ctx->s_bulk[lane];
     u64 budget = ctx->opts.scratch_budget ? ctx->opts.scratch_budget : (24ULL << 30);
-    const std::vector<u32> &cap = S.cap, &nanc = S.nanc;
+    const std::vector<u32> &nanc = S.nanc;
     std::vector<u64> w(ngrp, 0);
     for (u32 k = 0; k < ngrp; k++) for (u32 j = hj.grp_beg[groups[k]]; j < hj.grp_beg[groups[k] + 1]; j++) w[k] += nanc[j];
     std::vector<u32> order(ngrp);   // indices into `groups`, heaviest first
@@ -317,7 +317,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
     ENSURE(Lx.j_scr_off, (size_t)nj * 8);
     std::vector<u64> &scr_off = Lx.h_scr_off;
     scr_off.assign(nj, 0);
-    auto grp_scr = [&](u32 g) { u64 b = 0; for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) b += align_up(job_scratch_bytes((u64)cap[j] + 2), 256); return b; };
+    auto grp_scr = [&](u32 g) { u64 b = 0; for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) b += align_up(job_scratch_bytes((u64)nanc[j] + 2), 256); return b; };
     u32 g0 = 0;
     while (g0 < ngrp) {
         u64 scr = 0;
@@ -329,7 +329,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         }
         u64 so = 0;
         for (u32 k = g0; k < g1; k++)
-            for (u32 j = hj.grp_beg[dev_order[k]]; j < hj.grp_beg[dev_order[k] + 1]; j++) { scr_off[j] = so; so += align_up(job_scratch_bytes((u64)cap[j] + 2), 256); }
+            for (u32 j = hj.grp_beg[dev_order[k]]; j < hj.grp_beg[dev_order[k] + 1]; j++) { scr_off[j] = so; so += align_up(job_scratch_bytes((u64)nanc[j] + 2), 256); }
         ENSURE(Lx.job_scr, std::max<u64>(so, 16));
         HIPCK(hipMemcpyAsync(Lx.j_scr_off.p, scr_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, sm));
         JobArgs A;

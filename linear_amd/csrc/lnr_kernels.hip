@@ -1176,7 +1176,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
         if (lead) {
             u64 *ag = A.anchors + A.anc_off[j];
             u32 n = A.n_anchors[j];
-            u32 cap = A.job_cap[j] + 2;
+            u32 cap = n + 2;   // scratch is sized by the anchors that passed the Y filter (known before the launch), not by the bucket entries
             LNR_TICK(prof, 0, tk_);
             n = binning_wave(ag, n, dyn_lds, A.nbins);   // uses the dynamic LDS as its histogram
             LNR_TICK(prof, 1, tk_);
