@@ -7,6 +7,7 @@
 #include "../../include/linear_amd.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +34,25 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// pinned host staging (device-to-host copies from pageable memory run at a fraction of the link rate)
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap && p) return true;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t nc = bytes + bytes / 8 + 4096;
+        if (hipHostMalloc(&p, nc, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; (void)hipGetLastError(); return false; }
+        cap = nc;
+        return true;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
     template <class T> T *as() const { return (T *)p; }
 };
 
@@ -77,6 +97,7 @@ struct lnr_ctx {
     DevBuf rlen, rks, nf, f1_off, f1, pk, nm, pk_off;
     DevBuf cords, out_str, out_end, cords_off, cords_cap, ncords, nout, read_err;
     DevBuf gaps, gaps_off, gaps_cap, ngaps, remap;
+    PinBuf h_gaps, h_flags;             // pinned staging of the tail-A results
     // ---- jobs: a JobSet is one seeded job list (device arrays + host mirrors); a Launch is the per-launch state of the
     // job kernels (order, scratch); a TailBuf the per-launch state of a tail kernel.  Two of each: one per lane.
     struct JobSet {
@@ -93,6 +114,7 @@ struct lnr_ctx {
     // ---- results
     DevBuf r_off, r_str, r_end;
     std::vector<u64> h_cord_off, h_cords_str, h_cords_end, h_anchor_off, h_anchors;
+    std::vector<u32> dbg_r0w;   // round-0 anchors per read (LNR_DEBUG_R1 diagnostic)
     u32 last_n = 0;
     u64 last_ncords = 0;
     lnr_stats stats{};
@@ -186,6 +208,18 @@ struct BatchHost {
     std::vector<u64> f1_off, cords_off, gaps_off, pk_off;
 };
 
+// host-side lap timer (LNR_DEBUG_TIMES=1 prints where the host thread spends the step)
+struct Laps {
+    bool on; std::chrono::steady_clock::time_point t0, t; std::string out;
+    Laps() : on(getenv("LNR_DEBUG_TIMES") != nullptr) { t0 = t = std::chrono::steady_clock::now(); }
+    void lap(const char *name) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        char b[96]; snprintf(b, sizeof b, " %s %.2f", name, std::chrono::duration<double, std::milli>(n - t).count());
+        out += b; t = n;
+    }
+    void done() { if (on) fprintf(stderr, "[lnr] host laps (ms):%s | total %.2f\n", out.c_str(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
 typedef lnr_ctx::JobSet JobSet;
 typedef lnr_ctx::Launch Launch;
 typedef lnr_ctx::TailBuf TailBuf;
@@ -498,18 +532,23 @@ lnr_status remap_round(lnr_ctx *ctx, const BatchHost &B, const std::vector<u32> 
     TailArgs T;
     lnr_status s;
     if ((s = tail_prepare(ctx, B, tb, &list, st, T)) != LNR_OK) return s;
+    Laps laps;
+    laps.lap("tail_prepare");
     hipLaunchKernelGGL(k_tail_a, dim3((T.n + 63) / 64), dim3(64), 0, st, T);
     KCHECK();
-    std::vector<u32> remap(n), ngaps(n);
-    HIPCK(hipMemcpyAsync(remap.data(), ctx->remap.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCK(hipMemcpyAsync(ngaps.data(), ctx->ngaps.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (!ctx->h_flags.ensure((size_t)n * 8)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+    u32 *remap = ctx->h_flags.as<u32>(), *ngaps = remap + n;
+    HIPCK(hipMemcpyAsync(remap, ctx->remap.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(ngaps, ctx->ngaps.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
+    laps.lap("tail_a+flags");
     bool any = false;
     for (u32 i : list) if (remap[i] && ngaps[i]) { any = true; break; }
     if (!any) return LNR_OK;
     u64 gtot = B.gaps_off[n - 1] + B.gaps_cap[n - 1];
-    std::vector<UP> gaps(gtot);
-    HIPCK(hipMemcpyAsync(gaps.data(), ctx->gaps.p, gtot * sizeof(UP), hipMemcpyDeviceToHost, st));
+    if (!ctx->h_gaps.ensure(gtot * sizeof(UP))) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+    UP *gaps = ctx->h_gaps.as<UP>();
+    HIPCK(hipMemcpyAsync(gaps, ctx->gaps.p, gtot * sizeof(UP), hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
     for (u32 i : list) {
         if (!(remap[i] && ngaps[i])) continue;
@@ -521,10 +560,27 @@ lnr_status remap_round(lnr_ctx *ctx, const BatchHost &B, const std::vector<u32> 
         }
     }
     j1.grp_beg.push_back(j1.size());
+    laps.lap("gaps-copy+build");
     if ((s = seed_jobs(ctx, S, j1, st)) != LNR_OK) return s;
+    laps.lap("seed1(sync)");
+    if (getenv("LNR_DEBUG_R1")) {   // diagnostic: round-0 anchors of the reads that own the heavy re-map groups
+        std::vector<std::pair<u64, u64> > v;
+        for (u32 g = 0; g + 1 < j1.grp_beg.size(); g++) {
+            u64 w = 0;
+            for (u32 j = j1.grp_beg[g]; j < j1.grp_beg[g + 1]; j++) w += S.nanc[j];
+            if (w >= 2048) v.push_back(std::make_pair(w, (u64)ctx->dbg_r0w[j1.read[j1.grp_beg[g]]]));
+        }
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "[lnr] lane %d: %zu re-map groups with >= 2048 anchors; (r1 anchors, r0 anchors of the read):", lane, v.size());
+        for (size_t k = 0; k < v.size(); k += std::max<size_t>(1, v.size() / 40)) fprintf(stderr, " (%llu,%llu)", (unsigned long long)v[k].first, (unsigned long long)v[k].second);
+        fprintf(stderr, "\n");
+    }
     std::vector<u32> all((size_t)j1.grp_beg.size() - 1);
     for (u32 g = 0; g < all.size(); g++) all[g] = g;
-    return launch_jobs(ctx, S, Lx, j1, all, lane);
+    s = launch_jobs(ctx, S, Lx, j1, all, lane);
+    laps.lap("launch1");
+    laps.done();
+    return s;
 }
 
 lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, lnr_cords_dev *out) {
@@ -539,10 +595,12 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         if (out) out->d_cord_off = ctx->r_off.as<u64>();
         return LNR_OK;
     }
+    Laps laps;
     ctx->t_total.start(ctx->stream);
     BatchHost B;
     lnr_status s = prepare_batch(ctx, d_reads, d_off, n, B);
     if (s != LNR_OK) return s;
+    laps.lap("prepare");
     // round 0: one job per read longer than 200 bases (mapper.cpp:430,440), whole read, default parameters
     HostJobs j0;
     for (u32 i = 0; i < n; i++) {
@@ -551,16 +609,19 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     j0.grp_beg.push_back(j0.size());
     JobSet &S0 = ctx->js[0], &S1 = ctx->js[1];
     if ((s = seed_jobs(ctx, S0, j0, ctx->stream)) != LNR_OK) return s;
+    laps.lap("seed0(sync)");
     // Two lanes.  Lane 0 = the reads with many anchors (they hold the long chaining jobs of both rounds), lane 1 = the bulk.
     // The reference maps read by read, so any interleaving of reads is the same computation; here lane 0 goes through
     // round 0 -> tail A -> re-map round while lane 1 is still in round 0, instead of a batch-wide barrier per round.
     u32 ngrp0 = (u32)j0.grp_beg.size() - 1;
     std::vector<u32> grp[2], reads[2];
     std::vector<char> in_heavy(n, 0);
+    ctx->dbg_r0w.assign(n, 0);
     for (u32 g = 0; g < ngrp0; g++) {
         u64 w = 0;
         for (u32 j = j0.grp_beg[g]; j < j0.grp_beg[g + 1]; j++) w += S0.nanc[j];
         int lane = w >= ctx->split_cap ? 0 : 1;
+        ctx->dbg_r0w[j0.read[j0.grp_beg[g]]] = (u32)w;
         grp[lane].push_back(g);
         if (lane == 0) in_heavy[j0.read[j0.grp_beg[g]]] = 1;
     }
@@ -571,17 +632,21 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     HIPCK(hipStreamWaitEvent(ctx->s_bulk[1], ctx->ev_start, 0));
     if ((s = launch_jobs(ctx, S0, ctx->ln[0], j0, grp[0], 0)) != LNR_OK) return s;
     if ((s = launch_jobs(ctx, S0, ctx->ln[1], j0, grp[1], 1)) != LNR_OK) return s;
+    laps.lap("launch0");
     // lane 0: tail A + re-map round as soon as its round 0 is done (job set 1: lane 1 still reads job set 0)
     HostJobs j1h, j1b;
     if ((s = remap_round(ctx, B, reads[0], 0, S1, ctx->ln[0], ctx->tb[0], j1h)) != LNR_OK) return s;
     // lane 1: the same once the bulk is through round 0; by then nobody reads job set 0 any more
     HIPCK(hipStreamSynchronize(ctx->s_multi[1]));
+    laps.lap("wait-r0");
     if ((s = remap_round(ctx, B, reads[1], 1, S0, ctx->ln[1], ctx->tb[1], j1b)) != LNR_OK) return s;
+    laps.lap("tailA+seed1+launch1");
     HIPCK(hipEventRecord(ctx->ev_lane[0], ctx->s_multi[0]));
     HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_lane[0], 0));   // (lane 1's multi stream is the main stream)
     ctx->t_job.stop(ctx->stream);
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->stats.job_ms += ctx->t_job.ms();
+    laps.lap("wait-r1");
     // tail B: block chaining on both strands, flags, cords_end (pmpfinder.cpp:2764-2801)
     TailArgs T;
     if ((s = tail_prepare(ctx, B, ctx->tb[2], nullptr, ctx->stream, T)) != LNR_OK) return s;
@@ -613,6 +678,8 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     KCHECK();
     ctx->t_total.stop(ctx->stream);
     HIPCK(hipStreamSynchronize(ctx->stream));
+    laps.lap("tailB+gather");
+    laps.done();
     ctx->stats.prep_ms = ctx->t_prep.ms();
     ctx->stats.total_ms = ctx->t_total.ms();
     ctx->stats.cords = tot;
