@@ -28,6 +28,13 @@ __device__ __forceinline__ void WSYNC() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// Ordering point for LDS traffic inside one wave: LDS instructions of a wave execute in issue order, so only the compiler
+// has to be kept from moving accesses across it -- unlike WSYNC it does not wait for outstanding global stores.
+__device__ __forceinline__ void WLDS() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ u64 lanemask_lt() { return (1ULL << lane_id()) - 1ULL; }
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
     for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(v, o); if (lane_id() >= o) v += t; }
@@ -622,7 +629,13 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
         int shift = pass * 8;
         for (int b = lane; b < 256; b += 64) hist[b] = 0;
         WSYNC();
-        for (u32 i = lane; i < n; i += 64) atomicAdd(&hist[(src[i] >> shift) & 255], 1u);
+        for (u32 i0 = 0; i0 < n; i0 += 256) {   // four independent loads in flight per lane
+            u64 k[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { u32 i = i0 + 64 * u + lane; k[u] = i < n ? src[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (i0 + 64 * u + lane < n) atomicAdd(&hist[(k[u] >> shift) & 255], 1u);
+        }
         WSYNC();
         // exclusive prefix over the 256 bins: 4 bins per lane
         u32 c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
@@ -633,22 +646,25 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
         WSYNC();
         hist[4 * lane] = ex; hist[4 * lane + 1] = ex + c0; hist[4 * lane + 2] = ex + c0 + c1; hist[4 * lane + 3] = ex + c0 + c1 + c2;
         WSYNC();
+        u64 knext = lane < n ? src[lane] : 0;     // software pipeline: the next chunk's keys are loaded while this one is placed
         for (u32 base = 0; base < n; base += 64) {
             u32 i = base + lane;
             bool valid = i < n;
-            u64 key = valid ? src[i] : 0;
+            u64 key = knext;
+            knext = i + 64 < n ? src[i + 64] : 0;
             u32 d = (u32)(key >> shift) & 255;
             u64 m = __ballot(valid);
             for (int bit = 0; bit < 8; bit++) { u64 bm = __ballot((d >> bit) & 1); m &= ((d >> bit) & 1) ? bm : ~bm; }
             u32 pos = 0;
             if (valid) pos = hist[d] + (u32)__popcll(m & lanemask_lt());
-            WSYNC();
+            WLDS();                                  // cursor reads before cursor updates (LDS only; the stores need not land)
             if (valid) {
                 dst[pos] = key;
                 if ((m >> lane) >> 1 == 0) hist[d] += (u32)__popcll(m);   // highest lane of the digit group advances the cursor
             }
-            WSYNC();
+            WLDS();
         }
+        WSYNC();                                     // the pass's stores are visible before the next pass reads them
         u64 *t = src; src = dst; dst = t;
     }
     if (src != a) { for (u32 i = lane; i < n; i += 64) a[i] = src[i]; }
