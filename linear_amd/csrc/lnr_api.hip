@@ -85,6 +85,8 @@ struct lnr_ctx {
     u32 heavy_lds_kb = 48;              // LDS arena of k_job_heavy (LNR_HEAVY_LDS_KB)
     u32 mid_cap = 6144, mid_lds_kb = 24;   // reads with at least this many anchors run on 4 waves (k_job_mid: the DP is dealt over the waves); LNR_MID_CAP, LNR_MID_LDS_KB
     u32 heavy_cap = 0xffffffffu;        // reads with at least this many anchors (after the Y filter) take the 16-wave path (LNR_HEAVY_CAP overrides)
+    u32 heavy_cap_r1 = 10000, mid_cap_r1 = 4096;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
+    u32 bulk_delay_ticks = 10000;       // head start (100 MHz ticks) of the multi-wave kernels over the bulk kernel (LNR_BULK_DELAY_US)
     u32 split_cap = 0xffffffffu;               // reads with at least this many anchors form the "heavy lane": their re-map round starts
                                         // while the bulk of the batch is still in round 0 (LNR_SPLIT_CAP; 0xffffffff = one lane)
     // Two lanes of streams: lane 0 = heavy reads, lane 1 = the bulk.  s_multi carries the multi-wave kernels (and the
@@ -340,7 +342,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         for (u32 c = 0; c < NCLS; c++) cnt[c + 1] += cnt[c];
         for (u32 k = 0; k < ngrp; k++) order[cnt[gc[k]]++] = k;
         u32 nh = 0;
-        while (nh < ngrp && w[order[nh]] >= std::min<u64>(ctx->heavy_cap, ctx->mid_cap) / 2) nh++;
+        while (nh < ngrp && w[order[nh]] >= std::min<u64>(std::min(ctx->heavy_cap, ctx->mid_cap), std::min(ctx->heavy_cap_r1, ctx->mid_cap_r1)) / 2) nh++;
         std::stable_sort(order.begin(), order.begin() + nh, [&w](u32 a, u32 b) { return w[a] > w[b]; });
     }
     std::vector<u32> &dev_order = Lx.h_order;
@@ -382,10 +384,13 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         A.lds_bytes = (u32)lds;
         A.arena_lds = (u32)arena;
         // size classes along the (weight-descending) slice: heavy = 16 waves per read, mid = 4 waves, rest = 1 wave
+        // (the re-map round leaves most of the chip idle, so it can afford wider workgroups for more of its reads)
+        bool remap_round_ = nj && hj.mode[0] != 0;
+        u64 hcap = remap_round_ ? ctx->heavy_cap_r1 : ctx->heavy_cap, mcap = remap_round_ ? ctx->mid_cap_r1 : ctx->mid_cap;
         u32 gh = g0;
-        while (gh < g1 && w[order[gh]] >= ctx->heavy_cap) gh++;
+        while (gh < g1 && w[order[gh]] >= hcap) gh++;
         u32 gm = gh;
-        while (gm < g1 && w[order[gm]] >= ctx->mid_cap) gm++;
+        while (gm < g1 && w[order[gm]] >= mcap) gm++;
 #ifdef LNR_PROF
         if (!ctx->prof.p) { if (!ctx->prof.ensure(128 * 8)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->prof.p, 0, 128 * 8, sm); }
         A.prof = ctx->prof.as<unsigned long long>();
@@ -394,8 +399,14 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         if (ctx->tl_round < 4 && g1 <= (1u << 20)) { A.tl = ctx->tl.as<unsigned long long>() + (size_t)ctx->tl_round * (1u << 20) * 4; ctx->tl_n[ctx->tl_round] = g1; ctx->tl_nh[ctx->tl_round] = gm; }
         ctx->tl_round++;
 #endif
-        bool side = gm > g0 && g1 > gm && sb != sm;
-        if (side) HIPCK(hipEventRecord(ctx->ev_fork[lane], sm));    // before the multi-wave launches: the bulk kernel must not wait for them
+        // streams: the 16-wave kernel gets the spare stream when the batch runs as one lane (kernels on one stream would
+        // run back to back), the 4-wave kernel the lane's main stream, the single-wave kernel the lane's bulk stream
+        // streams: kernels on one stream run back to back, so when both multi-wave classes are present and the batch runs as
+        // one lane the 4-wave kernel takes the spare stream; the 16-wave kernel stays on the lane's main stream (it needs no
+        // event wait there and reaches the GPU first); the single-wave kernel goes to the lane's bulk stream.
+        hipStream_t s4 = (gh > g0 && gm > gh && lane == 1 && ctx->split_cap == 0xffffffffu) ? ctx->s_multi[0] : sm;
+        bool fork_m = s4 != sm, fork_b = g1 > gm && sb != sm && gm > g0;
+        if (fork_m || fork_b) HIPCK(hipEventRecord(ctx->ev_fork[lane], sm));    // before any launch: nobody waits for another kernel
         if (gh > g0) {
             JobArgs H = A;
             size_t hl = std::max<size_t>(lds_min, (size_t)ctx->heavy_lds_kb * 1024);
@@ -404,20 +415,24 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
             KCHECK();
         }
         if (gm > gh) {
+            if (fork_m) HIPCK(hipStreamWaitEvent(s4, ctx->ev_fork[lane], 0));
             JobArgs M = A;
             size_t ml = std::max<size_t>(lds_min, (size_t)ctx->mid_lds_kb * 1024);
             M.grp_lo = gh; M.grp_hi = gm; M.lds_bytes = (u32)ml; M.arena_lds = (u32)ml;
-            hipLaunchKernelGGL(k_job_mid, dim3(gm - gh), dim3(256), ml, sm, M);
+            hipLaunchKernelGGL(k_job_mid, dim3(gm - gh), dim3(256), ml, s4, M);
             KCHECK();
+            if (fork_m) HIPCK(hipEventRecord(ctx->ev_join[0], s4));
         }
         if (g1 > gm) {
-            hipStream_t bulk = side ? sb : sm;
-            if (side) HIPCK(hipStreamWaitEvent(sb, ctx->ev_fork[lane], 0));
+            hipStream_t bulk = fork_b ? sb : sm;
+            if (fork_b) HIPCK(hipStreamWaitEvent(sb, ctx->ev_fork[lane], 0));
+            if (gm > g0 && bulk != sm) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, bulk, ctx->bulk_delay_ticks); KCHECK(); }
             A.grp_lo = gm; A.grp_hi = g1;
             hipLaunchKernelGGL(k_job, dim3(g1 - gm), dim3(64), lds, bulk, A);
             KCHECK();
-            if (side) { HIPCK(hipEventRecord(ctx->ev_join[lane], sb)); HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[lane], 0)); }
+            if (fork_b) { HIPCK(hipEventRecord(ctx->ev_join[lane], sb)); HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[lane], 0)); }
         }
+        if (fork_m) HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[0], 0));
         ctx->stats.job_launches++;
         g0 = g1;
         if (g0 < ngrp) HIPCK(hipStreamSynchronize(sm));   // next slice reuses the scratch
@@ -793,10 +808,13 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_JOB_STAGE_KB")) { long kb = atol(e); if (kb >= 0 && kb <= 60) ctx->job_stage_bytes = (size_t)kb * 1024; }
-    if (const char *e = getenv("LNR_HEAVY_CAP")) { long v = atol(e); if (v >= 64) ctx->heavy_cap = (u32)v; }
+    if (const char *e = getenv("LNR_HEAVY_CAP")) { long v = atol(e); if (v >= 64) { ctx->heavy_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->heavy_cap_r1 = ctx->heavy_cap; } }
     if (const char *e = getenv("LNR_HEAVY_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->heavy_lds_kb = (u32)v; }
-    if (const char *e = getenv("LNR_MID_CAP")) { long v = atol(e); if (v >= 64) ctx->mid_cap = (u32)v; }
+    if (const char *e = getenv("LNR_MID_CAP")) { long v = atol(e); if (v >= 64) { ctx->mid_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->mid_cap_r1 = ctx->mid_cap; } }
     if (const char *e = getenv("LNR_MID_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->mid_lds_kb = (u32)v; }
+    if (const char *e = getenv("LNR_HEAVY_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->heavy_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
+    if (const char *e = getenv("LNR_MID_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->mid_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
+    if (const char *e = getenv("LNR_BULK_DELAY_US")) { long v = atol(e); if (v >= 0 && v <= 5000) ctx->bulk_delay_ticks = (u32)v * 100; }
     if (const char *e = getenv("LNR_SPLIT_CAP")) { long v = atol(e); if (v >= 1) ctx->split_cap = (u32)std::min<long>(v, 0xffffffffL); }
     // Three streams in all: the runtime multiplexes streams onto a few hardware queues (4 by default) and two streams on
     // one queue run their kernels back to back (measured: the bulk kernel waited for the 4-wave kernel).  Lane 1 (bulk)

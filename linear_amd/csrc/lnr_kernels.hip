@@ -1338,6 +1338,14 @@ __global__ void __launch_bounds__(256, 4) k_job_mid(JobArgs A) {
     job_group_run<4>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
 }
 
+// Placed on the bulk stream ahead of k_job when multi-wave kernels were launched beside it: a 4- or 16-wave workgroup
+// only finds room while the single-wave kernel has not filled every CU, and the three launches reach the GPU through
+// different queues in no particular order.  100 us (of a ~30 ms kernel) lets the big workgroups take their places.
+__global__ void k_delay(unsigned ticks_100mhz) {
+    unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(32);
+}
+
 // =================================================================== tails ====
 struct TailArgs {
     const u32 *read_len; u32 n;

@@ -34,7 +34,7 @@ for cls, cname in enumerate(["k_job round 0", "k_job round 1 (re-map)", "k_job_h
 # ---- per-workgroup timeline (100 MHz ticks): who runs when, and what the tail consists of
 f.lib.lnr_prof_timeline.restype = C.c_longlong
 f.lib.lnr_prof_timeline.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_ulonglong), C.c_ulonglong, C.POINTER(C.c_uint)]
-for rnd in range(2):
+for rnd in range(4):
     cap = 1 << 20
     buf = np.zeros(cap * 4, dtype=np.uint64)
     nh = C.c_uint(0)
