@@ -949,7 +949,7 @@ lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64
     }
     // bucket-non-empty bitmap for the seed kernel
     {
-        u64 nb = dir_len - 1, nwords = (nb + 31) / 32;
+        u64 nb = dir_len - 1, nwords = (((nb + (1u << BM_GROUP_LOG2) - 1) >> BM_GROUP_LOG2) + 31) / 32;
         ENSURE(ctx->bm, nwords * 4 + 16);
         hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
         IXHIP(hipGetLastError());
@@ -1028,7 +1028,7 @@ lnr_status lnr_index_adopt(lnr_ctx *ctx) {
     if (!ctx) return LNR_ERR_ARG;
     if (!ctx->g.p || !ctx->dir.p || !ctx->hs.p || !ctx->f2.p) return LNR_ERR_NO_INDEX;
     HIPCK(hipSetDevice(ctx->device));
-    u64 nb = ctx->info.dir_len - 1, nwords = (nb + 31) / 32;   // derived structure: rebuilt from the received dir
+    u64 nb = ctx->info.dir_len - 1, nwords = (((nb + (1u << BM_GROUP_LOG2) - 1) >> BM_GROUP_LOG2) + 31) / 32;   // derived structure: rebuilt from the received dir
     ENSURE(ctx->bm, nwords * 4 + 16);
     hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
     KCHECK();
