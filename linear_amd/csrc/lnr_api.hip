@@ -92,13 +92,13 @@ struct lnr_ctx {
     // Two lanes of streams: lane 0 = heavy reads, lane 1 = the bulk.  s_multi carries the multi-wave kernels (and the
     // lane's seed / tail launches), s_bulk the single-wave kernel of the same launch.
     hipStream_t s_multi[2] = {nullptr, nullptr}, s_bulk[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_start = nullptr, ev_lane[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_start = nullptr, ev_lane[2] = {nullptr, nullptr}, ev_prep = nullptr, ev_f1 = nullptr;
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm;   // bm: bucket-non-empty bitmap (derived from dir)
     // ---- batch inputs / per-read arrays
     DevBuf in_reads, in_off;                       // staging for the host-buffer entry points
     DevBuf rlen, rks, nf, f1_off, f1, pk, nm, pk_off;
     DevBuf cords, out_str, out_end, cords_off, cords_cap, ncords, nout, read_err;
-    DevBuf gaps, gaps_off, gaps_cap, ngaps, remap;
+    DevBuf gaps, gaps_off, gaps_cap, ngaps, remap, gdense, gcursor, gpos;
     PinBuf h_gaps, h_flags;             // pinned staging of the tail-A results
     // ---- jobs: a JobSet is one seeded job list (device arrays + host mirrors); a Launch is the per-launch state of the
     // job kernels (order, scratch); a TailBuf the per-launch state of a tail kernel.  Two of each: one per lane.
@@ -479,6 +479,9 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     ENSURE(ctx->out_str, std::max<u64>(co * 8, 16));
     ENSURE(ctx->out_end, std::max<u64>(co * 8, 16));
     ENSURE(ctx->gaps, std::max<u64>(go * sizeof(UP), 16));
+    ENSURE(ctx->gdense, std::max<u64>(go * sizeof(UP), 16));
+    ENSURE(ctx->gcursor, 16);
+    ENSURE(ctx->gpos, (size_t)n * 4);
     ENSURE(ctx->ncords, (size_t)n * 4);
     ENSURE(ctx->nout, (size_t)n * 4);
     ENSURE(ctx->read_err, (size_t)n * 4);
@@ -489,9 +492,13 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     ctx->t_prep.start(ctx->stream);
     hipLaunchKernelGGL(k_prep, dim3(n), dim3(256), 0, ctx->stream, d_reads, d_off, ctx->pk_off.as<u64>(), n, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
     KCHECK();
-    hipLaunchKernelGGL(k_f1, dim3(n), dim3(256), 0, ctx->stream, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->pk_off.as<u64>(), ctx->rlen.as<u32>(), ctx->nf.as<u32>(), ctx->f1_off.as<u64>(), n,
+    // the read features are not needed before the job kernels: k_f1 runs on the side stream beside the seed kernel
+    HIPCK(hipEventRecord(ctx->ev_prep, ctx->stream));
+    HIPCK(hipStreamWaitEvent(ctx->s_bulk[1], ctx->ev_prep, 0));
+    hipLaunchKernelGGL(k_f1, dim3(n), dim3(256), 0, ctx->s_bulk[1], ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->pk_off.as<u64>(), ctx->rlen.as<u32>(), ctx->nf.as<u32>(), ctx->f1_off.as<u64>(), n,
                        ctx->f1.as<F96>());
     KCHECK();
+    HIPCK(hipEventRecord(ctx->ev_f1, ctx->s_bulk[1]));
     ctx->t_prep.stop(ctx->stream);
     ctx->stats.reads = n;
     ctx->stats.bases = B.off[n] - B.off[0];
@@ -526,6 +533,7 @@ lnr_status tail_prepare(lnr_ctx *ctx, const BatchHost &B, TailBuf &tb, const std
     T.read_err = ctx->read_err.as<i32>();
     T.scratch = tb.scr.as<char>(); T.scr_off = tb.off.as<u64>(); T.scr_cap = tb.cap.as<u32>();
     T.gaps = ctx->gaps.as<UP>(); T.gaps_off = ctx->gaps_off.as<u64>(); T.gaps_cap = ctx->gaps_cap.as<u32>(); T.ngaps = ctx->ngaps.as<u32>(); T.remap = ctx->remap.as<u32>();
+    T.gdense = ctx->gdense.as<UP>(); T.gcursor = ctx->gcursor.as<u32>(); T.gpos = ctx->gpos.as<u32>();
     T.out_str = ctx->out_str.as<u64>(); T.out_end = ctx->out_end.as<u64>(); T.nout = ctx->nout.as<u32>();
     return LNR_OK;
 }
@@ -549,28 +557,29 @@ lnr_status remap_round(lnr_ctx *ctx, const BatchHost &B, const std::vector<u32> 
     if ((s = tail_prepare(ctx, B, tb, &list, st, T)) != LNR_OK) return s;
     Laps laps;
     laps.lap("tail_prepare");
+    HIPCK(hipMemsetAsync(ctx->gcursor.p, 0, 4, st));
     hipLaunchKernelGGL(k_tail_a, dim3((T.n + 63) / 64), dim3(64), 0, st, T);
     KCHECK();
-    if (!ctx->h_flags.ensure((size_t)n * 8)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
-    u32 *remap = ctx->h_flags.as<u32>(), *ngaps = remap + n;
+    if (!ctx->h_flags.ensure((size_t)n * 12 + 16)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+    u32 *remap = ctx->h_flags.as<u32>(), *ngaps = remap + n, *gpos = ngaps + n, *gtot_p = gpos + n;
     HIPCK(hipMemcpyAsync(remap, ctx->remap.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCK(hipMemcpyAsync(ngaps, ctx->ngaps.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(gpos, ctx->gpos.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(gtot_p, ctx->gcursor.p, 4, hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
     laps.lap("tail_a+flags");
-    bool any = false;
-    for (u32 i : list) if (remap[i] && ngaps[i]) { any = true; break; }
-    if (!any) return LNR_OK;
-    u64 gtot = B.gaps_off[n - 1] + B.gaps_cap[n - 1];
+    u64 gtot = *gtot_p;
+    if (gtot == 0) return LNR_OK;
     if (!ctx->h_gaps.ensure(gtot * sizeof(UP))) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
     UP *gaps = ctx->h_gaps.as<UP>();
-    HIPCK(hipMemcpyAsync(gaps, ctx->gaps.p, gtot * sizeof(UP), hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(gaps, ctx->gdense.p, gtot * sizeof(UP), hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
     for (u32 i : list) {
         if (!(remap[i] && ngaps[i])) continue;
         ctx->stats.remap_reads++;
         j1.grp_beg.push_back(j1.size());
         for (u32 k = 0; k < ngaps[i]; k++) {
-            UP y = forward_y(gaps[B.gaps_off[i] + k], B.len[i]);
+            UP y = forward_y(gaps[gpos[i] + k], B.len[i]);
             j1.add(i, (u32)y.first, (u32)y.second, 1);
         }
     }
@@ -641,6 +650,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         if (lane == 0) in_heavy[j0.read[j0.grp_beg[g]]] = 1;
     }
     for (u32 i = 0; i < n; i++) reads[in_heavy[i] ? 0 : 1].push_back(i);   // reads without a job go with the bulk
+    HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_f1, 0));   // read features ready (k_f1 ran beside the seed kernel)
     ctx->t_job.start(ctx->stream);
     HIPCK(hipEventRecord(ctx->ev_start, ctx->stream));
     HIPCK(hipStreamWaitEvent(ctx->s_multi[0], ctx->ev_start, 0));
@@ -722,6 +732,7 @@ lnr_status seed_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, bo
     j0.grp_beg.push_back(j0.size());
     if ((s = seed_jobs(ctx, ctx->js[0], j0, ctx->stream)) != LNR_OK) return s;
     if (to_host && (s = export_anchors(ctx, ctx->js[0], j0.size())) != LNR_OK) return s;
+    HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_f1, 0));
     ctx->t_total.stop(ctx->stream);
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->stats.prep_ms = ctx->t_prep.ms();
@@ -820,7 +831,8 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     // one queue run their kernels back to back (measured: the bulk kernel waited for the 4-wave kernel).  Lane 1 (bulk)
     // uses the main stream for its multi-wave kernels, seeds and tails and one side stream for the single-wave kernel;
     // lane 0 (heavy reads, nearly all multi-wave) runs everything on one stream.
-    bool ok = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) == hipSuccess;
+    bool ok = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_f1, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->s_multi[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ctx->s_bulk[1], hipStreamNonBlocking) == hipSuccess;
     ctx->s_bulk[0] = ctx->s_multi[0];
     ctx->s_multi[1] = ctx->stream;
@@ -851,6 +863,8 @@ void lnr_destroy(lnr_ctx *ctx) {
     if (ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_multi[0]);
     if (ctx->s_bulk[1]) (void)hipStreamDestroy(ctx->s_bulk[1]);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
+    if (ctx->ev_f1) (void)hipEventDestroy(ctx->ev_f1);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

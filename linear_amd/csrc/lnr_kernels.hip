@@ -1361,6 +1361,7 @@ struct TailArgs {
     u64 *cords; const u64 *cords_off; const u32 *cords_cap; u32 *ncords; i32 *read_err;
     char *scratch; const u64 *scr_off; const u32 *scr_cap;   // per read: bytes offset / capacity in cord slots used for sizing
     UP *gaps; const u64 *gaps_off; const u32 *gaps_cap; u32 *ngaps; u32 *remap;
+    UP *gdense; u32 *gcursor; u32 *gpos;   // gaps of the reads that go to the re-map round, packed: [gpos[r], gpos[r] + ngaps[r])
     u64 *out_str, *out_end; u32 *nout;
 };
 __global__ void __launch_bounds__(64) k_tail_a(TailArgs T) {
@@ -1375,6 +1376,12 @@ __global__ void __launch_bounds__(64) k_tail_a(TailArgs T) {
     LeaderScratch ls;
     int rc = tail_a(T.cords + T.cords_off[r], nc, L, ar, T.gaps + T.gaps_off[r], T.gaps_cap[r], ng, rm, ls);
     T.ncords[r] = nc; T.ngaps[r] = ng; T.remap[r] = rm;
+    if (rm && ng) {   // hand the gaps to the host densely (one small copy instead of the whole per-read table)
+        u32 pos = atomicAdd(T.gcursor, ng);
+        T.gpos[r] = pos;
+        const UP *g = T.gaps + T.gaps_off[r];
+        for (u32 k = 0; k < ng; k++) T.gdense[pos + k] = g[k];
+    }
     if (rc || ar.ovf) T.read_err[r] = 2;
 }
 __global__ void __launch_bounds__(64) k_tail_b(TailArgs T) {
