@@ -601,20 +601,29 @@ __device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 nbins) {
     u32 nw = (nbins + 1) >> 1;
     for (u32 w = lane; w < nw; w += 64) binw[w] = 0;
     WSYNC();
-    for (u32 i = lane; i < n; i += 64) {
-        u32 b = (u32)(cord_x(a[i]) / 30000);
-        if (b < nbins) {
-            u32 inc = (b & 1) ? 0x10000u : 1u;
-            u32 old = atomicAdd(&binw[b >> 1], inc);
-            u32 half = (b & 1) ? (old >> 16) : (old & 0xffffu);
-            if (half >= 0x8000u) atomicSub(&binw[b >> 1], inc);   // saturate well below carry into the neighbour half
+    for (u32 i0 = 0; i0 < n; i0 += 256) {   // four independent loads in flight per lane
+        u64 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { u32 i = i0 + 64 * u + (u32)lane; v[u] = i < n ? a[i] : ~0ULL; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            u32 i = i0 + 64 * u + (u32)lane;
+            u32 b = (u32)(cord_x(v[u]) / 30000);
+            if (i < n && b < nbins) {
+                u32 inc = (b & 1) ? 0x10000u : 1u;
+                u32 old = atomicAdd(&binw[b >> 1], inc);
+                u32 half = (b & 1) ? (old >> 16) : (old & 0xffffu);
+                if (half >= 0x8000u) atomicSub(&binw[b >> 1], inc);   // saturate well below carry into the neighbour half
+            }
         }
     }
     WSYNC();
     u32 ii = 0;
+    u64 vnext = (u32)lane < n ? a[lane] : 0;   // software pipeline: the next chunk is loaded while this one is compacted
     for (u32 base = 0; base < n; base += 64) {
         u32 i = base + lane;
-        u64 v = i < n ? a[i] : 0;
+        u64 v = vnext;
+        vnext = i + 64 < n ? a[i + 64] : 0;
         bool keep = false;
         if (i < n) {
             u32 b = (u32)(cord_x(v) / 30000);
@@ -952,9 +961,15 @@ __device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int
 __device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {
     int lane = lane_id();
     i64 best = -1;
-    for (u32 j = lane; j < n; j += 64) {
-        int sc = r.score[j];
-        if (sc > -1) { i64 key = ((i64)sc << 32) | (i64)(u32)(0x7fffffff - (int)j); best = key > best ? key : best; }
+    for (u32 j0 = 0; j0 < n; j0 += 256) {   // four independent loads in flight per lane (the scan is latency bound)
+        int sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { u32 j = j0 + 64 * u + (u32)lane; sc[u] = j < n ? r.score[j] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            u32 j = j0 + 64 * u + (u32)lane;
+            if (sc[u] > -1) { i64 key = ((i64)sc[u] << 32) | (i64)(u32)(0x7fffffff - (int)j); best = key > best ? key : best; }
+        }
     }
     best = wave_max_i64(best);
     Tb0Scan s; s.max_score = -1; s.max_2nd = -1; s.max_str = -1; s.max_len = 0;
@@ -962,7 +977,13 @@ __device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {
     s.max_score = (int)(best >> 32);
     s.max_str = 0x7fffffff - (int)(u32)(best & 0xffffffff);
     i64 m2 = -1;
-    for (u32 j = lane; j < (u32)s.max_str; j += 64) { i64 v = r.score[j]; m2 = v > m2 ? v : m2; }
+    for (u32 j0 = 0; j0 < (u32)s.max_str; j0 += 256) {
+        int sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { u32 j = j0 + 64 * u + (u32)lane; sc[u] = j < (u32)s.max_str ? r.score[j] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { i64 v = sc[u]; m2 = v > m2 ? v : m2; }
+    }
     s.max_2nd = (int)wave_max_i64(m2);
     s.max_len = r.len[s.max_str];
     return s;
