@@ -64,6 +64,10 @@ def main():
     ap.add_argument("--small", action="store_true", help="tiny reference/batch (plumbing check)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: everything else (RCCL prints a version banner to stdout at init) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -71,14 +75,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("LNR_BENCH_DIST_AT_1"))   # the env switch rehearses the N>1 plumbing on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from linear_amd import build as lb
     if local_rank == 0:
         lb.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from linear_amd import Filter, synth
     from linear_amd import dist as ldist
@@ -102,7 +110,7 @@ def main():
         info = flt.build_index([ref], args.layout_threads)
         index_s = time.time() - t0
         log(f"[bench] reference generated in {t_ref:.1f}s; index built in {index_s:.2f}s wall ({info.build_ms:.1f} ms device): hs {info.hs_len}, samples {info.n_samples}, f2 {info.f2_len}")
-    if world > 1:
+    if use_dist:
         bcast = ldist.broadcast_index(flt, 0, dev)
         if rank == 0:
             log(f"[bench] index broadcast: {bcast['bytes'] / 1e9:.2f} GB in {bcast['seconds'] * 1e3:.1f} ms ({bcast['bytes'] / 1e9 / max(bcast['seconds'], 1e-9):.1f} GB/s)")
@@ -124,7 +132,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     acc = {}
@@ -134,10 +142,10 @@ def main():
         for k, v in st.items():
             acc[k] = acc.get(k, 0) + v
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -225,9 +233,10 @@ def main():
         log(f"[bench] host-buffer entry point (PCIe in/out) on the {ns}-read sample: {ns / (time.time() - t0):.0f} reads/s")
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     flt.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

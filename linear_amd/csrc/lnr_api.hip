@@ -85,6 +85,7 @@ struct lnr_ctx {
     u32 heavy_lds_kb = 48;              // LDS arena of k_job_heavy (LNR_HEAVY_LDS_KB)
     u32 mid_cap = 6144, mid_lds_kb = 24;   // reads with at least this many anchors run on 4 waves (k_job_mid: the DP is dealt over the waves); LNR_MID_CAP, LNR_MID_LDS_KB
     u32 heavy_cap = 0xffffffffu;        // reads with at least this many anchors (after the Y filter) take the 16-wave path (LNR_HEAVY_CAP overrides)
+    u32 dp_split_cap = 0xffffffffu, dp_split_cap_r1 = 0xffffffffu;   // reads with at least this many anchors take the split path pre -> 16-wave DP -> post (LNR_DP_SPLIT_CAP, LNR_DP_SPLIT_CAP_R1)
     u32 heavy_cap_r1 = 10000, mid_cap_r1 = 4096;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
     u32 bulk_delay_ticks = 10000;       // head start (100 MHz ticks) of the multi-wave kernels over the bulk kernel (LNR_BULK_DELAY_US)
     u32 split_cap = 0xffffffffu;               // reads with at least this many anchors form the "heavy lane": their re-map round starts
@@ -110,7 +111,7 @@ struct lnr_ctx {
         Timer t_seed;
     } js[2];
     // (host vectors that feed asynchronous uploads live here, not on the stack: the launch functions return before the copy ran)
-    struct Launch { DevBuf grp_order, j_scr_off, job_scr; std::vector<u32> h_order; std::vector<u64> h_scr_off; } ln[2];
+    struct Launch { DevBuf grp_order, j_scr_off, job_scr, jstate; std::vector<u32> h_order; std::vector<u64> h_scr_off; } ln[2];
     struct TailBuf { DevBuf off, cap, scr, list; std::vector<u64> h_off; std::vector<u32> h_cap, h_list; } tb[3];
     DevBuf prof, tl; u32 tl_round = 0, tl_n[4] = {0, 0, 0, 0}; u32 tl_nh[4] = {0, 0, 0, 0};
     // ---- results
@@ -342,7 +343,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         for (u32 c = 0; c < NCLS; c++) cnt[c + 1] += cnt[c];
         for (u32 k = 0; k < ngrp; k++) order[cnt[gc[k]]++] = k;
         u32 nh = 0;
-        while (nh < ngrp && w[order[nh]] >= std::min<u64>(std::min(ctx->heavy_cap, ctx->mid_cap), std::min(ctx->heavy_cap_r1, ctx->mid_cap_r1)) / 2) nh++;
+        while (nh < ngrp && w[order[nh]] >= std::min<u64>(std::min(std::min(ctx->heavy_cap, ctx->mid_cap), std::min(ctx->heavy_cap_r1, ctx->mid_cap_r1)), std::min(ctx->dp_split_cap, ctx->dp_split_cap_r1)) / 2) nh++;
         std::stable_sort(order.begin(), order.begin() + nh, [&w](u32 a, u32 b) { return w[a] > w[b]; });
     }
     std::vector<u32> &dev_order = Lx.h_order;
@@ -351,6 +352,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
     lnr_status s;
     if ((s = upload_on(ctx, Lx.grp_order, dev_order, sm)) != LNR_OK) return s;
     ENSURE(Lx.j_scr_off, (size_t)nj * 8);
+    ENSURE(Lx.jstate, (size_t)nj * 8 + 16);
     std::vector<u64> &scr_off = Lx.h_scr_off;
     scr_off.assign(nj, 0);
     auto grp_scr = [&](u32 g) { u64 b = 0; for (u32 j = hj.grp_beg[g]; j < hj.grp_beg[g + 1]; j++) b += align_up(job_scratch_bytes((u64)nanc[j] + 2), 256); return b; };
@@ -377,7 +379,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         A.cords = ctx->cords.as<u64>(); A.cords_off = ctx->cords_off.as<u64>(); A.cords_cap = ctx->cords_cap.as<u32>(); A.ncords = ctx->ncords.as<u32>();
         A.read_err = ctx->read_err.as<i32>();
         A.nbins = ctx->nbins; A.grp_lo = g0; A.grp_hi = g1;
-        A.prof = nullptr; A.tl = nullptr;
+        A.prof = nullptr; A.tl = nullptr; A.jstate = Lx.jstate.as<u32>();
         size_t lds_min = (((size_t)((ctx->nbins + 1) / 2) * 4) + 15) & ~(size_t)15;
         size_t arena = (ctx->job_lds_bytes + 15) & ~(size_t)15;
         size_t lds = std::max<size_t>(lds_min, arena + ctx->job_stage_bytes);
@@ -387,12 +389,15 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         // (the re-map round leaves most of the chip idle, so it can afford wider workgroups for more of its reads)
         bool remap_round_ = nj && hj.mode[0] != 0;
         u64 hcap = remap_round_ ? ctx->heavy_cap_r1 : ctx->heavy_cap, mcap = remap_round_ ? ctx->mid_cap_r1 : ctx->mid_cap;
+        u64 scap = remap_round_ ? ctx->dp_split_cap_r1 : ctx->dp_split_cap;
         u32 gh = g0;
         while (gh < g1 && w[order[gh]] >= hcap) gh++;
-        u32 gm = gh;
+        u32 gs = gh;                                    // [gh, gs): split path (pre -> 16-wave DP -> post)
+        while (gs < g1 && w[order[gs]] >= scap) gs++;
+        u32 gm = gs;                                    // [gs, gm): 4 waves per read
         while (gm < g1 && w[order[gm]] >= mcap) gm++;
 #ifdef LNR_PROF
-        if (!ctx->prof.p) { if (!ctx->prof.ensure(128 * 8)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->prof.p, 0, 128 * 8, sm); }
+        if (!ctx->prof.p) { if (!ctx->prof.ensure(192 * 8)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->prof.p, 0, 192 * 8, sm); }
         A.prof = ctx->prof.as<unsigned long long>();
         // timeline: up to 4 launches of up to 2^20 positions
         if (!ctx->tl.p) { if (!ctx->tl.ensure(4ULL * (1u << 20) * 32)) return LNR_ERR_NOMEM; (void)hipMemsetAsync(ctx->tl.p, 0, 4ULL * (1u << 20) * 32, sm); }
@@ -401,11 +406,12 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
 #endif
         // streams: the 16-wave kernel gets the spare stream when the batch runs as one lane (kernels on one stream would
         // run back to back), the 4-wave kernel the lane's main stream, the single-wave kernel the lane's bulk stream
-        // streams: kernels on one stream run back to back, so when both multi-wave classes are present and the batch runs as
-        // one lane the 4-wave kernel takes the spare stream; the 16-wave kernel stays on the lane's main stream (it needs no
-        // event wait there and reaches the GPU first); the single-wave kernel goes to the lane's bulk stream.
-        hipStream_t s4 = (gh > g0 && gm > gh && lane == 1 && ctx->split_cap == 0xffffffffu) ? ctx->s_multi[0] : sm;
-        bool fork_m = s4 != sm, fork_b = g1 > gm && sb != sm && gm > g0;
+        // streams: kernels on one stream run back to back.  The 16-wave kernel stays on the lane's main stream (no event wait,
+        // it reaches the GPU first); the split-path chain and the 4-wave kernel take the spare stream when the 16-wave class
+        // is present and the batch runs as one lane, else the main stream; the single-wave kernel goes to the lane's bulk stream.
+        bool wide2 = gm > gh;                                   // split and / or 4-wave class present
+        hipStream_t s4 = (gh > g0 && wide2 && lane == 1 && ctx->split_cap == 0xffffffffu) ? ctx->s_multi[0] : sm;
+        bool fork_m = wide2 && s4 != sm, fork_b = g1 > gm && sb != sm && gm > g0;
         if (fork_m || fork_b) HIPCK(hipEventRecord(ctx->ev_fork[lane], sm));    // before any launch: nobody waits for another kernel
         if (gh > g0) {
             JobArgs H = A;
@@ -414,15 +420,25 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
             hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, sm, H);
             KCHECK();
         }
-        if (gm > gh) {
-            if (fork_m) HIPCK(hipStreamWaitEvent(s4, ctx->ev_fork[lane], 0));
+        if (fork_m) HIPCK(hipStreamWaitEvent(s4, ctx->ev_fork[lane], 0));
+        if (gs > gh) {
+            JobArgs P = A;
+            P.grp_lo = gh; P.grp_hi = gs; P.lds_bytes = (u32)lds_min; P.arena_lds = 0;   // global scratch only: pointers must replay
+            hipLaunchKernelGGL(k_job_pre, dim3(gs - gh), dim3(64), lds_min, s4, P);
+            KCHECK();
+            hipLaunchKernelGGL(k_job_dp, dim3(gs - gh), dim3(64 * DP_SPLIT_WAVES), 0, s4, P);
+            KCHECK();
+            hipLaunchKernelGGL(k_job_post, dim3(gs - gh), dim3(64), lds_min, s4, P);
+            KCHECK();
+        }
+        if (gm > gs) {
             JobArgs M = A;
             size_t ml = std::max<size_t>(lds_min, (size_t)ctx->mid_lds_kb * 1024);
-            M.grp_lo = gh; M.grp_hi = gm; M.lds_bytes = (u32)ml; M.arena_lds = (u32)ml;
-            hipLaunchKernelGGL(k_job_mid, dim3(gm - gh), dim3(256), ml, s4, M);
+            M.grp_lo = gs; M.grp_hi = gm; M.lds_bytes = (u32)ml; M.arena_lds = (u32)ml;
+            hipLaunchKernelGGL(k_job_mid, dim3(gm - gs), dim3(256), ml, s4, M);
             KCHECK();
-            if (fork_m) HIPCK(hipEventRecord(ctx->ev_join[0], s4));
         }
+        if (fork_m) HIPCK(hipEventRecord(ctx->ev_join[0], s4));
         if (g1 > gm) {
             hipStream_t bulk = fork_b ? sb : sm;
             if (fork_b) HIPCK(hipStreamWaitEvent(sb, ctx->ev_fork[lane], 0));
@@ -825,6 +841,8 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_MID_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->mid_lds_kb = (u32)v; }
     if (const char *e = getenv("LNR_HEAVY_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->heavy_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_MID_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->mid_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
+    if (const char *e = getenv("LNR_DP_SPLIT_CAP")) { long v = atol(e); if (v >= 64) { ctx->dp_split_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->dp_split_cap_r1 = ctx->dp_split_cap; } }
+    if (const char *e = getenv("LNR_DP_SPLIT_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->dp_split_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_BULK_DELAY_US")) { long v = atol(e); if (v >= 0 && v <= 5000) ctx->bulk_delay_ticks = (u32)v * 100; }
     if (const char *e = getenv("LNR_SPLIT_CAP")) { long v = atol(e); if (v >= 1) ctx->split_cap = (u32)std::min<long>(v, 0xffffffffL); }
     // Three streams in all: the runtime multiplexes streams onto a few hardware queues (4 by default) and two streams on
@@ -1112,7 +1130,7 @@ long long lnr_prof_timeline(lnr_ctx *ctx, unsigned round, unsigned long long *ou
 lnr_status lnr_prof_read(lnr_ctx *ctx, unsigned long long *out16) {
     if (!ctx || !out16 || !ctx->prof.p) return LNR_ERR_ARG;
     HIPCK(hipStreamSynchronize(ctx->stream));
-    HIPCK(hipMemcpy(out16, ctx->prof.p, 128 * 8, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(out16, ctx->prof.p, 192 * 8, hipMemcpyDeviceToHost));
     return LNR_OK;
 }
 #endif

@@ -352,12 +352,19 @@ LNR_HD inline u32 wdist_raw(FeatView f1, FeatView f2, u64 x1, u64 x2) {   // __w
 // In-kernel phase stamps: compiled in only for the diagnostic build (-DLNR_PROF); the shipped
 // kernels contain no stamp.
 #if defined(LNR_PROF) && defined(__HIP_DEVICE_COMPILE__)
+// per-job phase cycles of the leader lane (diagnostic build): reported for the job with the most anchors in the DP
+static __device__ __attribute__((unused)) unsigned long long lnr_job_ph_dummy;
 #define LNR_TICK(prof, idx, last)                                                        \
+    do {                                                                                 \
+        if (prof) { unsigned long long t_ = clock64(); atomicAdd(&(prof)[idx], t_ - (last)); atomicMax(&(prof)[16 + (idx)], t_ - (last)); lnr_job_ph[idx] += t_ - (last); (last) = t_; } \
+    } while (0)
+#define LNR_TICK0(prof, idx, last)                                                       \
     do {                                                                                 \
         if (prof) { unsigned long long t_ = clock64(); atomicAdd(&(prof)[idx], t_ - (last)); atomicMax(&(prof)[16 + (idx)], t_ - (last)); (last) = t_; } \
     } while (0)
 #else
 #define LNR_TICK(prof, idx, last) do { } while (0)
+#define LNR_TICK0(prof, idx, last) do { } while (0)
 #endif
 
 // -------------------------------------------------------------- parameters ----
@@ -1194,16 +1201,16 @@ LNR_HD inline int job_phase3a(u64 *a, u32 m, JobScratch &S, const JobCtx &c, Job
         }
     }
     if (dbg && dbg->hits_chain) { for (u32 i = 0; i < hits.n; i++) dbg->hits_chain[i] = hits[i]; *dbg->nhits_chain = hits.n; }
-    if (!c.traceback_done) LNR_TICK(c.prof, 5, tl_);
+    if (!c.traceback_done) LNR_TICK0(c.prof, 5, tl_);
     job_blocks_gather(S, c);
     prefilter_chains2(hits.p, hits.n, S.sep, S.cuts, S.xy_strs, S.tmp, ls);
-    LNR_TICK(c.prof, 6, tl_);
+    LNR_TICK0(c.prof, 6, tl_);
     job_blocks_scores(S, 0, 1);
     BlockSink bs = job_block_sink(S);
     BlockScratch s = job_block_scratch(S, ls);
     chain_blocks_base(bs, hits.p, S.sep.p, S.sep_score, S.sep.n, c.L, 2, 0, 1, s);   // chainBlocksHits cluster_util.cpp:721-732
     int rc = job_blocks_finish(a, S, bs, dbg, H, nH);
-    LNR_TICK(c.prof, 7, tl_);
+    LNR_TICK0(c.prof, 7, tl_);
     return rc;
 }
 

@@ -590,6 +590,7 @@ struct JobArgs {
     u32 nbins; u32 grp_lo, grp_hi;
     u32 lds_bytes;          // dynamic LDS per block: binning histogram first, then the fast half of the job arena
     u32 arena_lds;          // bytes of that LDS the job arena may use
+    u32 *jstate;            // split path: per job {anchors after binning, anchors after the list filter | ok << 31} handed from the pre to the DP / post kernel
     unsigned long long *prof;   // diagnostic build (-DLNR_PROF) only: per-phase cycle sums of lane 0
     unsigned long long *tl;     // diagnostic build only: per launch position {start, end (100 MHz ticks), hw id, anchors in the DP}
 };
@@ -1172,13 +1173,27 @@ __device__ void best_chains_block(const u32 *xs, const u32 *ys, u32 m, Rec r, in
     else best_chains_block_t<NW, 0>(xs, ys, m, r, jlo, T);
 }
 
+// Replays the allocation sequence of the pre phase (global scratch only) from the two counts it left in jstate: n1 = anchors
+// after binning, m = anchors after the list filter.  Same calls in the same order -> same pointers.
+__device__ __forceinline__ void job_replay(const JobArgs &A, u32 j, u32 n1, u32 m, u32 *dyn_lds, Arena &slow, Arena &ar, u64 *&a, JobScratch &S, int *ovf) {
+    u32 cap = A.n_anchors[j] + 2;
+    slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
+    ar.init((void *)dyn_lds, A.arena_lds); ar.next = &slow;
+    a = A.anchors + A.anc_off[j];
+    if (n1 > 1) { (void)slow.get<u64>(cap); a = ar.get<u64>((u64)n1 + 2); }
+    if (m > 1) (void)slow.get<u64>((u64)m + 2);
+    (void)job_carve(ar, m, S, ovf);
+}
 // One workgroup per read: runs the read's jobs in order (round 0: the whole read; remap round: its gaps), appending
 // cords to the read's cord list exactly like consecutive apxMap_ calls do.
 //   NW == 1 : one wave does everything (the bulk of the reads).
 //   NW == 16: heavy reads.  Wave 0 runs every serial / wave-parallel phase with a large LDS arena; the other waves only
 //             join for the chaining DP (best_chains_block) and otherwise wait at the two workgroup barriers per job.
 struct DpShare { const u32 *xs, *ys; Rec rec; i32 *jlo; u32 m; int score_type; int abort; };
-template <int NW>
+// PHASE: 0 = the whole job; 1 = up to the filled x / y arrays (state -> A.jstate); 2 = from the traceback on (the DP ran
+// in k_job_dp).  Phases 1 and 2 are launched with arena_lds = 0: every array then lives in the job's global scratch and
+// the allocation sequence, replayed from the two counts in jstate, yields the same pointers in all three kernels.
+template <int NW, int PHASE = 0>
 __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
     __shared__ u32 hist[256];
     __shared__ u32 s_m;
@@ -1202,6 +1217,8 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
     cords.n = A.ncords[r];
     unsigned long long tk_ = 0;
 #ifdef LNR_PROF
+    unsigned long long lnr_job_ph[16];
+    for (int q = 0; q < 16; q++) lnr_job_ph[q] = 0;
     tk_ = clock64();
     unsigned long long *tl = (lead && lane == 0 && A.tl) ? A.tl + 4 * (size_t)(A.grp_lo + blockIdx.x) : nullptr;
     if (tl) { tl[0] = wall_clock64(); tl[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); tl[3] = 0; }
@@ -1218,7 +1235,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
         int mode = (int)A.J.mode[j];
         Arena slow, ar;
         bool ok = true;
-        if (lead) {
+        if (lead && PHASE != 2) {
             u64 *ag = A.anchors + A.anc_off[j];
             u32 n = A.n_anchors[j];
             u32 cap = n + 2;   // scratch is sized by the anchors that passed the Y filter (known before the launch), not by the bucket entries
@@ -1255,12 +1272,26 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
                 WSYNC();
             } else if (lane == 0) s_ovf = 1;
             LNR_TICK(prof, 3, tk_);
+            if (PHASE == 1) {
+                if (lane == 0) { A.jstate[2 * j] = n; A.jstate[2 * j + 1] = m | (ok ? 0x80000000u : 0u); }
+                continue;                                 // the DP and everything behind it run in the next kernels
+            }
+        }
+        if (lead && PHASE == 2) {
+            u32 n1 = A.jstate[2 * j], mm = A.jstate[2 * j + 1];
+            job_replay(A, j, n1, mm & 0x7fffffffu, dyn_lds, slow, ar, a, S, &s_ovf);
+            m = mm & 0x7fffffffu;
+            ok = (mm >> 31) != 0;
+            if (!ok && lane == 0) s_ovf = 1;
+            WSYNC();
         }
 #ifdef LNR_PROF
         if (prof) {   // job count, anchors entering the DP, predecessor pairs
             unsigned long long pairs = 0;
             if (ok && m >= 2) { u32 p300 = 0; for (u32 i = 0; i < m; i++) { while (p300 < i && S.xs[p300] - S.xs[i] >= 300) p300++; u32 js = i > 20 ? i - 20 : 0; pairs += i - (p300 < js ? p300 : js); } }
             if (tl) tl[3] += ((unsigned long long)m << 32) | (pairs > 0xffffffffULL ? 0xffffffffULL : pairs);
+            for (int q = 0; q < 16; q++) lnr_job_ph[q] = 0;
+            lnr_job_ph[10] = m; lnr_job_ph[11] = pairs; lnr_job_ph[12] = A.n_anchors[j];
             atomicAdd(&prof[10], 1ULL); atomicAdd(&prof[11], (unsigned long long)m); atomicAdd(&prof[12], pairs); atomicAdd(&prof[13], (unsigned long long)A.n_anchors[j]);
             tk_ = clock64();
         }
@@ -1268,7 +1299,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
         // ---------------- chaining DP
         if (NW == 1) {
             if (!ok) break;
-            if (m >= 2) {
+            if (PHASE == 0 && m >= 2) {
                 best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, S.cnt, s_tile.tleaf);
             }
         } else {
@@ -1336,6 +1367,11 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             }
             WSYNC();
 #ifdef LNR_PROF
+            if (A.prof && lane == 0) {   // phase cycles of the job with the most anchors in the DP (per launch class of 4: A.prof + 128 + 16 * class)
+                unsigned long long *mp = A.prof + 128 + 16 * ((NW > 1 ? 2 : 0) + (A.J.mode[jb] ? 1 : 0));
+                unsigned long long old = atomicMax(&mp[10], lnr_job_ph[10]);
+                if (lnr_job_ph[10] > old) { for (int q = 0; q < 10; q++) mp[q] = lnr_job_ph[q]; mp[11] = lnr_job_ph[11]; mp[12] = lnr_job_ph[12]; }
+            }
             tk_ = clock64();
 #endif
         }
@@ -1345,7 +1381,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             if (s_ovf) break;             // uniform
         }
     }
-    if (lead && lane == 0) { A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
+    if (lead && lane == 0) { if (PHASE != 1) A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
 #ifdef LNR_PROF
     if (tl) tl[1] = wall_clock64();
 #endif
@@ -1355,6 +1391,39 @@ __global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
     extern __shared__ u32 dyn_lds[];
     if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
     job_group_run<1>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
+// Split path for reads with many anchors: k_job_pre (one wave: binning .. x/y arrays) -> k_job_dp (16 waves: the chaining DP
+// and nothing else, so no wave idles through the serial phases) -> k_job_post (one wave: traceback .. cords), on one stream.
+__global__ void __launch_bounds__(64, 4) k_job_pre(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    job_group_run<1, 1>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
+__global__ void __launch_bounds__(64, 4) k_job_post(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    job_group_run<1, 2>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
+#define DP_SPLIT_WAVES 4
+__global__ void __launch_bounds__(64 * DP_SPLIT_WAVES) k_job_dp(JobArgs A) {
+    __shared__ DpTile<DP_SPLIT_WAVES> s_tile;
+    __shared__ DpShare s_dp;
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    u32 grp = A.grp_order[A.grp_lo + blockIdx.x];
+    for (u32 j = A.grp_beg[grp]; j < A.grp_beg[grp + 1]; j++) {
+        if (threadIdx.x == 0) {
+            u32 n1 = A.jstate[2 * j], mm = A.jstate[2 * j + 1];
+            u32 m = mm & 0x7fffffffu;
+            Arena slow, ar; u64 *a; JobScratch S; int ovf = 0;
+            job_replay(A, j, n1, m, nullptr, slow, ar, a, S, &ovf);
+            s_dp.xs = S.xs; s_dp.ys = S.ys; s_dp.rec = S.rec; s_dp.jlo = S.cnt; s_dp.m = (mm >> 31) ? m : 0;
+            s_dp.score_type = job_parm((int)A.J.mode[j]).score_type; s_dp.abort = 0;
+        }
+        __syncthreads();
+        DpShare d = s_dp;
+        if (d.m >= 2) best_chains_block<DP_SPLIT_WAVES>(d.xs, d.ys, d.m, d.rec, d.score_type, d.jlo, s_tile);
+        __syncthreads();
+    }
 }
 __global__ void __launch_bounds__(1024) k_job_heavy(JobArgs A) {
     extern __shared__ u32 dyn_lds[];

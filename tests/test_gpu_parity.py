@@ -101,8 +101,24 @@ def test_gpu_scratch_slicing(oracle_lib):
     f.close()
 
 
+@pytest.mark.parametrize("var,val", [("LNR_MID_CAP", "64"), ("LNR_DP_SPLIT_CAP", "64"), ("LNR_SPLIT_CAP", "300")])
+def test_gpu_other_size_class_paths(case_inputs, monkeypatch, var, val):
+    """Force the reads through the 4-wave kernel, the split path (pre -> 16-wave DP kernel -> post) and the two-lane
+    orchestration: same cords as the reference."""
+    from linear_amd import Filter
+    monkeypatch.setenv(var, val)
+    f = Filter(device=0)
+    for name, T in (("rep", 1), ("edge", 3), ("ont", 4)):
+        refs, reads, off = case_inputs(name)
+        g = np.load(os.path.join(GOLD, f"{name}_T{T}.npz"))
+        f.build_index(refs, T)
+        coff, cs, ce = f.filter_batch(reads, off)
+        assert np.array_equal(coff, g["cord_off"]) and np.array_equal(cs, g["cords_str"]) and np.array_equal(ce, g["cords_end"])
+    f.close()
+
+
 def test_gpu_heavy_path(case_inputs, monkeypatch):
-    """Force every job through the heavy path (pre -> 16-wave DP -> post on a second stream): same cords."""
+    """Force every job through the 16-wave kernel: same cords."""
     from linear_amd import Filter
     monkeypatch.setenv("LNR_HEAVY_CAP", "64")
     f = Filter(device=0)
@@ -113,3 +129,32 @@ def test_gpu_heavy_path(case_inputs, monkeypatch):
         coff, cs, ce = f.filter_batch(reads, off)
         assert np.array_equal(coff, g["cord_off"]) and np.array_equal(cs, g["cords_str"]) and np.array_equal(ce, g["cords_end"])
     f.close()
+
+
+def test_gpu_index_receiver_path(case_inputs):
+    """Multi-GPU receiver path on one device: a second context allocates the index from the owner's metadata
+    (lnr_index_alloc), receives the four device blobs in place (what the RCCL broadcast does; here a device-to-device
+    copy through the same zero-copy tensor views linear_amd.dist uses), adopts it (lnr_index_adopt rebuilds the derived
+    bucket bitmap) and must then produce the reference's cords."""
+    import torch
+    from linear_amd import Filter
+    from linear_amd.dist import blob_tensor
+    for name, T in (("ont", 4), ("edge", 3)):
+        refs, reads, off = case_inputs(name)
+        g = np.load(os.path.join(GOLD, f"{name}_T{T}.npz"))
+        owner = Filter(device=0)
+        owner.build_index(refs, T)
+        recv = Filter(device=0)
+        recv.index_alloc_from(owner.index_info_vec(), owner.seq_len())
+        src, dst = owner.index_blobs(), recv.index_blobs()
+        assert len(src) == len(dst) == 4
+        for (ps, bs), (pd, bd) in zip(src, dst):
+            assert bs == bd
+            if bs:
+                blob_tensor(pd, bd, "cuda:0").copy_(blob_tensor(ps, bs, "cuda:0"))
+        torch.cuda.synchronize()
+        recv.index_adopt()
+        owner.close()
+        coff, cs, ce = recv.filter_batch(reads, off)
+        assert np.array_equal(coff, g["cord_off"]) and np.array_equal(cs, g["cords_str"]) and np.array_equal(ce, g["cords_end"])
+        recv.close()

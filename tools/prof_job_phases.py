@@ -18,7 +18,7 @@ f.build_index([ref], 1)
 d_ref = torch.from_numpy(ref).cuda()
 d_reads, d_off = sample_reads_cuda(d_ref, n, 10000, 0.10, 777, non_n_start=10_510_000)
 f.filter_batch_dev(d_reads.data_ptr(), d_off.data_ptr(), n)
-out = (C.c_ulonglong * 128)()
+out = (C.c_ulonglong * 192)()
 f.lib.lnr_prof_read.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert f.lib.lnr_prof_read(f.h, out) == 0
 names = ["carve+setup", "binning", "radix sort", "phase1: filter list + introsort + xs/ys", "chain DP", "traceback", "gather_blocks + prefilter_chains2",
@@ -30,6 +30,8 @@ for cls, cname in enumerate(["k_job round 0", "k_job round 1 (re-map)", "k_job_h
     print(f"== {cname}: {o[10]} jobs, anchors in {o[13] / jobs:.0f}/job, anchors in DP {o[11] / jobs:.0f}/job, pairs {o[12] / jobs:.0f}/job (window {o[12] / max(o[11], 1):.1f}); lane-0 cycles/job {tot / jobs:.0f}")
     for i, nm in enumerate(names):
         print(f"   {nm:42s} {o[i] / 1e6:10.1f} Mcyc {100.0 * o[i] / max(tot, 1):5.1f} %  per job {o[i] / jobs:9.0f}  max {o[16 + i] / 1e6:8.2f} Mcyc")
+    mp = out[128 + 16 * cls: 128 + 16 * cls + 16]
+    print(f"   biggest job of the class: {mp[12]} anchors in, {mp[10]} in the DP, {mp[11]} pairs; Mcyc per phase: " + " ".join(f"{mp[i] / 1e6:.2f}" for i in range(10)) + f"  (sum {sum(mp[:10]) / 1e6:.1f})")
 
 # ---- per-workgroup timeline (100 MHz ticks): who runs when, and what the tail consists of
 f.lib.lnr_prof_timeline.restype = C.c_longlong
