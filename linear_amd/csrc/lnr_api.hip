@@ -245,12 +245,25 @@ lnr_status upload_on(lnr_ctx *ctx, DevBuf &b, const std::vector<T> &v, hipStream
     return LNR_OK;
 }
 
+// Read features of the whole batch on the side stream, ordered behind whatever the main stream holds right now.  They are
+// not needed before the job kernels, so filter_dev issues this right behind the round-0 seed kernel: k_f1 then runs while
+// the host reads the seed counts back and prepares the launch order (the GPU would idle there), not beside the seed kernel.
+lnr_status launch_f1(lnr_ctx *ctx, u32 n) {
+    HIPCK(hipEventRecord(ctx->ev_prep, ctx->stream));
+    HIPCK(hipStreamWaitEvent(ctx->s_bulk[1], ctx->ev_prep, 0));
+    hipLaunchKernelGGL(k_f1, dim3(n), dim3(256), 0, ctx->s_bulk[1], ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->pk_off.as<u64>(), ctx->rlen.as<u32>(), ctx->nf.as<u32>(), ctx->f1_off.as<u64>(), n,
+                       ctx->f1.as<F96>());
+    KCHECK();
+    HIPCK(hipEventRecord(ctx->ev_f1, ctx->s_bulk[1]));
+    return LNR_OK;
+}
+
 // Seed lookup (k_seed_fused) of the job list `hj` into the job set S, on stream st.  Returns with the stream idle and the
 // per-job counts (bucket entries, lookups, anchors, anchor offsets) mirrored on the host.
-lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st) {
+lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st, u32 f1_reads = 0) {
     u32 nj = hj.size();
     S.cap.assign(nj, 0); S.look.assign(nj, 0); S.nanc.assign(nj, 0); S.anc_off.assign(nj, 0);
-    if (nj == 0) return LNR_OK;
+    if (nj == 0) return f1_reads ? launch_f1(ctx, f1_reads) : LNR_OK;
     lnr_status s;
     if ((s = upload_on(ctx, S.j_read, hj.read, st)) != LNR_OK) return s;
     if ((s = upload_on(ctx, S.j_str, hj.str, st)) != LNR_OK) return s;
@@ -277,6 +290,7 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
         hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->dir.as<i32>(), ctx->bm.as<u32>(), ctx->hs.as<u64>(), nj, O);
         KCHECK();
         S.t_seed.stop(st);
+        if (f1_reads && attempt == 0) { lnr_status fs = launch_f1(ctx, f1_reads); if (fs != LNR_OK) return fs; }
         int ovf = 0;
         HIPCK(hipMemcpyAsync(S.cap.data(), S.j_cap.p, (size_t)nj * 4, hipMemcpyDeviceToHost, st));
         HIPCK(hipMemcpyAsync(S.look.data(), S.j_look.p, (size_t)nj * 4, hipMemcpyDeviceToHost, st));
@@ -508,13 +522,6 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     ctx->t_prep.start(ctx->stream);
     hipLaunchKernelGGL(k_prep, dim3(n), dim3(256), 0, ctx->stream, d_reads, d_off, ctx->pk_off.as<u64>(), n, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
     KCHECK();
-    // the read features are not needed before the job kernels: k_f1 runs on the side stream beside the seed kernel
-    HIPCK(hipEventRecord(ctx->ev_prep, ctx->stream));
-    HIPCK(hipStreamWaitEvent(ctx->s_bulk[1], ctx->ev_prep, 0));
-    hipLaunchKernelGGL(k_f1, dim3(n), dim3(256), 0, ctx->s_bulk[1], ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->pk_off.as<u64>(), ctx->rlen.as<u32>(), ctx->nf.as<u32>(), ctx->f1_off.as<u64>(), n,
-                       ctx->f1.as<F96>());
-    KCHECK();
-    HIPCK(hipEventRecord(ctx->ev_f1, ctx->s_bulk[1]));
     ctx->t_prep.stop(ctx->stream);
     ctx->stats.reads = n;
     ctx->stats.bases = B.off[n] - B.off[0];
@@ -648,7 +655,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     }
     j0.grp_beg.push_back(j0.size());
     JobSet &S0 = ctx->js[0], &S1 = ctx->js[1];
-    if ((s = seed_jobs(ctx, S0, j0, ctx->stream)) != LNR_OK) return s;
+    if ((s = seed_jobs(ctx, S0, j0, ctx->stream, n)) != LNR_OK) return s;
     laps.lap("seed0(sync)");
     // Two lanes.  Lane 0 = the reads with many anchors (they hold the long chaining jobs of both rounds), lane 1 = the bulk.
     // The reference maps read by read, so any interleaving of reads is the same computation; here lane 0 goes through
@@ -746,7 +753,7 @@ lnr_status seed_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, bo
         if (B.len[i] >= 43) { job_of[i] = j0.size(); j0.grp_beg.push_back(j0.size()); j0.add(i, 0, B.len[i], 0); }
     }
     j0.grp_beg.push_back(j0.size());
-    if ((s = seed_jobs(ctx, ctx->js[0], j0, ctx->stream)) != LNR_OK) return s;
+    if ((s = seed_jobs(ctx, ctx->js[0], j0, ctx->stream, n)) != LNR_OK) return s;
     if (to_host && (s = export_anchors(ctx, ctx->js[0], j0.size())) != LNR_OK) return s;
     HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_f1, 0));
     ctx->t_total.stop(ctx->stream);
