@@ -146,6 +146,11 @@ struct PackedSeq {
         return lnr_popc64(bits & 0x5555555555555555ULL) + 2 * lnr_popc64(bits & 0xAAAAAAAAAAAAAAAAULL) + 4 * lnr_popc64(nb);
     }
 };
+// The caller's byte buffer seen the same way (ordinals above 4 clamp to N, positions at or past the end read as 0).
+struct ByteSeq {
+    const u8 *p; u64 L;
+    LNR_HD u8 operator[](u64 i) const { if (i >= L) return 0; u8 b = p[i]; return b > 4 ? (u8)4 : b; }
+};
 struct SeedOut { u32 X; u32 Y; u32 strand; };
 
 template <class Seq> LNR_HD inline int shape_init_skip(const Seq &s) {   // N-skip of hashInit (shape_extend.cpp:95-105)

@@ -390,6 +390,12 @@ __global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, con
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (st0 == 0 && lane == 0) {                 // wave 0, forward step 0: the first 32 bases' N bits are in s_n[0][0][0]
+            // no N among the first 21 bases: hashInit skips nothing; otherwise the serial walk, straight from the caller's bytes
+            // (no other wave's output is needed, so the workgroup never synchronises)
+            ByteSeq bs; bs.p = rd; bs.L = L;
+            read_ks[r] = (s_n[0][0][0] & 0x1FFFFFu) ? shape_init_skip(bs) : 0;
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             u32 st = st0 + u;
@@ -403,11 +409,6 @@ __global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, con
             }
         }
         __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        PackedSeq fwd; fwd.pk = pw; fwd.nm = nw_; fwd.L = L;
-        read_ks[r] = (nw_[0] & 0x1FFFFFu) ? shape_init_skip(fwd) : 0;   // no N among the first 21 bases: nothing to skip
     }
 }
 // read window features of both strands (createFeatures2_48 serial form, pmpfinder.cpp:556-588) from the packed strands:
