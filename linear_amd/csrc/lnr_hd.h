@@ -516,6 +516,50 @@ LNR_HD inline int chain_score_bl(u32 x1, u32 y1, u32 x2, u32 y2) {
     return res;
 }
 
+// What the lane-parallel DP evaluates per pair, in two stages (lnr_kernels.hip dp_eval; fuzzed against the literal scores in
+// tests/test_stage_logic_host.py: wherever the literal score is positive the pair is a candidate with the same score, and no
+// non-positive pair is ever reported positive):
+//   dp_pair_cand : a cheap NECESSARY condition for a positive score (the rest is skipped when no lane of a wave passes)
+//   dp_pair_score: the score under that condition (select-style arithmetic, no branch)
+// getApxChainScore : positive needs score_dy < 100, i.e. dy / 15 < 150 (beyond that score_dy >= 132), and then
+//                    score_dy = (dy / 15) / 5 = dy / 75;  da >= 10 and 7 da >= M  =>  derr >= 14  =>  score_derr >= 126
+// getApxChainScore0: score = 100 - dy - (da < 30 ? 0 : da) > 0 needs 5 <= dy < 100 and da < 100 (da >= M gives -1000)
+struct DpPair { i32 dy; u32 da, M; };
+template <int ST>
+LNR_HD inline bool dp_pair_cand(u32 px, u32 py, u32 xi, u32 yi, DpPair &p) {
+    i32 dy = (i32)py - (i32)yi, dx = (i32)px - (i32)xi;
+    i32 t = dx - dy;
+    u32 da = (u32)(t < 0 ? -t : t);
+    u32 adx = (u32)(dx < 0 ? -dx : dx);
+    u32 M = (u32)(dy < 0 ? 0 : dy); M = M > adx ? M : adx; M = M < 50 ? 50 : M;
+    p.dy = dy; p.da = da; p.M = M;
+    if (ST) return dy >= 5 && dy < 100 && da < 100 && da < M;
+    return dy >= 10 && dy < 2250 && da < M && (da < 10 || (u64)da * 7 < (u64)M);
+}
+template <int ST>
+LNR_HD inline i32 dp_pair_score(const DpPair &p) {
+    i32 dy = p.dy; u32 da = p.da, M = p.M;
+    if (ST) return 100 - dy - (da < 30 ? 0 : (i32)da);
+    u32 sdy = (u32)dy / 75u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float inv = __builtin_amdgcn_rcpf((float)M);
+#else
+    float inv = 1.0f / (float)M;
+#endif
+    u32 dac = da < M ? da : 0;
+    u32 q = (u32)((float)dac * 100.0f * inv);
+    i32 r = (i32)(100u * dac - q * M);              // exact modulo 2^32; the true remainder lies in [-M, 2M)
+    u32 qm = q - 1, qp = q + 1;
+    q = r < 0 ? qm : q;
+    q = (r >= 0 && (u32)r >= M) ? qp : q;
+    u32 e1 = 4 * q, e2 = 6 * q - 10, e3 = q * q - 5 * q;
+    u32 sd = e3;
+    sd = q < 10 ? e2 : sd;
+    sd = q < 5 ? e1 : sd;
+    sd = da < 10 ? 0 : sd;
+    return 100 - (i32)sdy - (i32)sd;
+}
+
 struct Rec { i32 *score, *score2, *len, *p2, *root, *leaf; };   // ChainsRecord as SoA
 
 // Small arrays that only the leader lane touches (introsort stack, tree table of traceBackChains1).  In the

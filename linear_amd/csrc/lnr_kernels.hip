@@ -857,58 +857,53 @@ __device__ __forceinline__ void dp_window_bounds(const u32 *xs, u32 m, i32 *jlo,
     }
 }
 __device__ __forceinline__ i64 dp_key(int total, int j) { return ((i64)total << 32) | (i64)(u32)(0x7fffffff - j); }
-// One predecessor (uniform) against the lane's anchor.  Most pairs of a repeat-rich window are far off the diagonal and
-// score <= 0; a cheap necessary condition for a positive score is tested first and the full score (division, polynomials)
-// is skipped when NO lane of the wave can be positive:
-//   getApxChainScore : da >= 10 and 7 da >= M  =>  derr >= 14  =>  score_derr >= 126  =>  score < 0
-//   getApxChainScore0: score = 100 - dy - (da < 30 ? 0 : da) > 0 needs dy < 100 and da < 100
-template <int ST>
-__device__ __forceinline__ void dp_eval(i64 &best, u32 px, u32 py, i32 ps, int jj, u32 xi, u32 yi, bool act) {
-    i32 dy = (i32)py - (i32)yi, dx = (i32)px - (i32)xi;
-    i32 t = dx - dy;
-    u32 da = (u32)(t < 0 ? -t : t);
-    bool cand;
-    if (ST) cand = act && dy >= 5 && dy < 100 && da < 100;
-    else {
-        u32 adx = (u32)(dx < 0 ? -dx : dx);
-        u32 M = (u32)(dy < 0 ? 0 : dy); M = M > adx ? M : adx; M = M < 50 ? 50 : M;
-        cand = act && dy >= 10 && da < M && (da < 10 || (u64)da * 7 < (u64)M);
-    }
+// One predecessor (uniform) against the lane's anchor (lnr_hd.h dp_pair_cand / dp_pair_score).  Most pairs of a repeat-rich
+// window are far off the diagonal and score <= 0: the score is only computed when some lane of the wave is a candidate.
+// The running best is (total, j) in two registers.  GE = true for scans that visit j in descending order (before the tile:
+// the reference keeps the later, smaller j on equal totals), false for the ascending in-tile steps (the earlier j stays).
+template <int ST, bool GE>
+__device__ __forceinline__ void dp_eval(i32 &btot, i32 &bj, u32 px, u32 py, i32 ps, int jj, u32 xi, u32 yi, bool act) {
+    DpPair p;
+    bool cand = dp_pair_cand<ST>(px, py, xi, yi, p) && act;
     if (__ballot(cand) == 0) return;
-    int sc = ST ? chain_score0_bl(px, py, xi, yi) : chain_score_bl(px, py, xi, yi);
-    if (act && sc > 0) { i64 key = dp_key(sc + ps, jj); best = key > best ? key : best; }
+    i32 sc = dp_pair_score<ST>(p);
+    i32 tot = sc + ps;
+    bool upd = cand && sc > 0 && (GE ? tot >= btot : tot > btot);
+    btot = upd ? tot : btot;
+    bj = upd ? jj : bj;
 }
 // before-tile candidates of this wave's share of the chunks; jl = the lane's j_lo (INT_MAX for an idle lane)
 template <int ST>
 __device__ __forceinline__ i64 dp_before_tile(const u32 *xs, const u32 *ys, const i32 *score, int t0, int lo, u32 xi, u32 yi, int jl, int wave, int nw) {
     int lane = lane_id();
-    i64 best = -1;
+    i32 btot = -1, bj = 0;
     for (int top = t0 - 64 * wave; top > lo; top -= 64 * nw) {   // chunk = predecessors top-1, top-2, ... (at most 64, not below lo)
         int jl_ = top - 1 - lane;
         u32 px = 0, py = 0; i32 ps = 0;
         if (jl_ >= lo) { px = xs[jl_]; py = ys[jl_]; ps = score[jl_]; }
         int cnt = top - lo < 64 ? top - lo : 64;
-#pragma unroll 4
         for (int s_ = 0; s_ < cnt; s_++) {
             u32 qx = (u32)__builtin_amdgcn_readlane((int)px, s_), qy = (u32)__builtin_amdgcn_readlane((int)py, s_);
             i32 qs = __builtin_amdgcn_readlane(ps, s_);
             int jj = top - 1 - s_;
-            dp_eval<ST>(best, qx, qy, qs, jj, xi, yi, jj >= jl);
+            dp_eval<ST, true>(btot, bj, qx, qy, qs, jj, xi, yi, jj >= jl);
         }
     }
-    return best;
+    return btot < 0 ? (i64)-1 : dp_key(btot, bj);
 }
 // in-tile steps, finish and store by ONE wave; `best` = merged before-tile candidate of the lane's anchor
 template <int ST>
 __device__ __forceinline__ void dp_in_tile_finish(i32 *tleaf, int t0, int tn, u32 xi, u32 yi, int jl, i64 best, Rec &r) {
     int lane = lane_id();
+    i32 btot = best >= 0 ? (i32)(best >> 32) : -1, bj = best >= 0 ? 0x7fffffff - (i32)(u32)(best & 0xffffffff) : 0;
     for (int l = 0; l + 1 < tn; l++) {
-        i32 mysc = best >= 0 ? (i32)(best >> 32) : 0;    // final for lane l at step l
+        i32 mysc = btot > 0 ? btot : 0;                  // final for lane l at step l
         u32 qx = (u32)__builtin_amdgcn_readlane((int)xi, l), qy = (u32)__builtin_amdgcn_readlane((int)yi, l);
         i32 qs = __builtin_amdgcn_readlane(mysc, l);
         int jj = t0 + l;
-        dp_eval<ST>(best, qx, qy, qs, jj, xi, yi, lane > l && jj >= jl);
+        dp_eval<ST, false>(btot, bj, qx, qy, qs, jj, xi, yi, lane > l && jj >= jl);
     }
+    best = btot < 0 ? (i64)-1 : dp_key(btot, bj);
     bool live = lane < tn;
     bool has = live && best >= 0;
     int mj = has ? 0x7fffffff - (int)(u32)(best & 0xffffffff) : -1;

@@ -334,6 +334,15 @@ u64 hs_chain_score_fuzz(u64 seed, u64 n) {
         x1 &= 0x3fffffff; y1 &= 0xfffff;
         if (chain_score(x1, y1, x2, y2) != chain_score_bl(x1, y1, x2, y2)) bad++;
         if (chain_score0(x1, y1, x2, y2) != chain_score0_bl(x1, y1, x2, y2)) bad++;
+        // the two-stage form the DP kernel evaluates: positive literal score <=> candidate with the same positive score
+        {
+            DpPair p0, p1;
+            bool c0 = dp_pair_cand<0>(x1, y1, x2, y2, p0), c1 = dp_pair_cand<1>(x1, y1, x2, y2, p1);
+            int l0 = chain_score(x1, y1, x2, y2), l1 = chain_score0(x1, y1, x2, y2);
+            int s0 = c0 ? dp_pair_score<0>(p0) : 0, s1 = c1 ? dp_pair_score<1>(p1) : 0;
+            if (l0 > 0 ? !(c0 && s0 == l0) : (c0 && s0 > 0)) bad++;
+            if (l1 > 0 ? !(c1 && s1 == l1) : (c1 && s1 > 0)) bad++;
+        }
     }
     return bad;
 }
