@@ -336,6 +336,7 @@ lnr_status export_anchors(lnr_ctx *ctx, JobSet &S, u32 nj) {
 lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, const std::vector<u32> &groups, int lane) {
     u32 ngrp = (u32)groups.size();
     if (ngrp == 0) return LNR_OK;
+    Laps laps;
     u32 nj = hj.size();
     hipStream_t sm = ctx->s_multi[lane], sb = ctx->s_bulk[lane];
     u64 budget = ctx->opts.scratch_budget ? ctx->opts.scratch_budget : (24ULL << 30);
@@ -363,8 +364,10 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
     std::vector<u32> &dev_order = Lx.h_order;
     dev_order.resize(ngrp);
     for (u32 k = 0; k < ngrp; k++) dev_order[k] = groups[order[k]];
+    laps.lap("order");
     lnr_status s;
     if ((s = upload_on(ctx, Lx.grp_order, dev_order, sm)) != LNR_OK) return s;
+    laps.lap("upload-order");
     ENSURE(Lx.j_scr_off, (size_t)nj * 8);
     ENSURE(Lx.jstate, (size_t)nj * 8 + 16);
     std::vector<u64> &scr_off = Lx.h_scr_off;
@@ -382,8 +385,11 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         u64 so = 0;
         for (u32 k = g0; k < g1; k++)
             for (u32 j = hj.grp_beg[dev_order[k]]; j < hj.grp_beg[dev_order[k] + 1]; j++) { scr_off[j] = so; so += align_up(job_scratch_bytes((u64)nanc[j] + 2), 256); }
+        laps.lap("scr-layout");
         ENSURE(Lx.job_scr, std::max<u64>(so, 16));
+        laps.lap("ensure-scr");
         HIPCK(hipMemcpyAsync(Lx.j_scr_off.p, scr_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, sm));
+        laps.lap("upload-scr");
         JobArgs A;
         A.grp_order = Lx.grp_order.as<u32>(); A.grp_beg = S.grp_beg.as<u32>(); A.J = job_arrays(S);
         A.anc_off = S.j_anc_off.as<u64>(); A.job_cap = S.j_cap.as<u32>(); A.n_anchors = S.j_nanc.as<u32>(); A.scr_off = Lx.j_scr_off.as<u64>();
@@ -463,10 +469,12 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
             if (fork_b) { HIPCK(hipEventRecord(ctx->ev_join[lane], sb)); HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[lane], 0)); }
         }
         if (fork_m) HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[0], 0));
+        laps.lap("launches");
         ctx->stats.job_launches++;
         g0 = g1;
         if (g0 < ngrp) HIPCK(hipStreamSynchronize(sm));   // next slice reuses the scratch
     }
+    if (laps.on && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - laps.t0).count() > 3.0) laps.done();
     return LNR_OK;
 }
 
