@@ -92,7 +92,7 @@ struct lnr_ctx {
                                         // while the bulk of the batch is still in round 0 (LNR_SPLIT_CAP; 0xffffffff = one lane)
     // Two lanes of streams: lane 0 = heavy reads, lane 1 = the bulk.  s_multi carries the multi-wave kernels (and the
     // lane's seed / tail launches), s_bulk the single-wave kernel of the same launch.
-    hipStream_t s_multi[2] = {nullptr, nullptr}, s_bulk[2] = {nullptr, nullptr};
+    hipStream_t s_multi[2] = {nullptr, nullptr}, s_bulk[2] = {nullptr, nullptr}, s_tail = nullptr;   // s_tail: early tail B of the reads that skip the re-map round
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_start = nullptr, ev_lane[2] = {nullptr, nullptr}, ev_prep = nullptr, ev_f1 = nullptr;
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm;   // bm: bucket-non-empty bitmap (derived from dir)
     // ---- batch inputs / per-read arrays
@@ -697,19 +697,33 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     laps.lap("wait-r0");
     if ((s = remap_round(ctx, B, reads[1], 1, S0, ctx->ln[1], ctx->tb[1], j1b)) != LNR_OK) return s;
     laps.lap("tailA+seed1+launch1");
+    // Tail B (block chaining on both strands, flags, cords_end; pmpfinder.cpp:2764-2801) of the reads that do not go through
+    // the re-map round is final after tail A: it runs on its own stream while the re-map jobs (a few long reads) are busy.
+    std::vector<u32> late_list, early_list;
+    bool early = ctx->split_cap == 0xffffffffu && j1b.size() > 0;
+    if (early) {
+        std::vector<char> in_r1(n, 0);
+        for (u32 q = 0; q < j1b.size(); q++) in_r1[j1b.read[q]] = 1;
+        for (u32 i = 0; i < n; i++) (in_r1[i] ? late_list : early_list).push_back(i);
+        TailArgs TE;
+        if ((s = tail_prepare(ctx, B, ctx->tb[2], &early_list, ctx->s_tail, TE)) != LNR_OK) return s;
+        hipLaunchKernelGGL(k_tail_b, dim3((TE.n + 63) / 64), dim3(64), 0, ctx->s_tail, TE);
+        KCHECK();
+        HIPCK(hipEventRecord(ctx->ev_prep, ctx->s_tail));
+    }
     HIPCK(hipEventRecord(ctx->ev_lane[0], ctx->s_multi[0]));
     HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_lane[0], 0));   // (lane 1's multi stream is the main stream)
     ctx->t_job.stop(ctx->stream);
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->stats.job_ms += ctx->t_job.ms();
     laps.lap("wait-r1");
-    // tail B: block chaining on both strands, flags, cords_end (pmpfinder.cpp:2764-2801)
     TailArgs T;
-    if ((s = tail_prepare(ctx, B, ctx->tb[2], nullptr, ctx->stream, T)) != LNR_OK) return s;
+    if ((s = tail_prepare(ctx, B, ctx->tb[0], early ? &late_list : nullptr, ctx->stream, T)) != LNR_OK) return s;
     ctx->t_tail.start(ctx->stream);
-    hipLaunchKernelGGL(k_tail_b, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, T);
+    hipLaunchKernelGGL(k_tail_b, dim3((T.n + 63) / 64), dim3(64), 0, ctx->stream, T);
     KCHECK();
     ctx->t_tail.stop(ctx->stream);
+    if (early) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
     std::vector<u32> nout(n);
     std::vector<i32> rerr(n);
     HIPCK(hipMemcpyAsync(nout.data(), ctx->nout.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -867,6 +881,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     bool ok = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_f1, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->s_multi[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ctx->s_bulk[1], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->s_tail, hipStreamNonBlocking) == hipSuccess;
     ctx->s_bulk[0] = ctx->s_multi[0];
     ctx->s_multi[1] = ctx->stream;
     for (int l = 0; l < 2 && ok; l++)
@@ -893,6 +908,7 @@ void lnr_destroy(lnr_ctx *ctx) {
         if (ctx->ev_join[l]) (void)hipEventDestroy(ctx->ev_join[l]);
         if (ctx->ev_lane[l]) (void)hipEventDestroy(ctx->ev_lane[l]);
     }
+    if (ctx->s_tail) { (void)hipStreamSynchronize(ctx->s_tail); (void)hipStreamDestroy(ctx->s_tail); }
     if (ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_multi[0]);
     if (ctx->s_bulk[1]) (void)hipStreamDestroy(ctx->s_bulk[1]);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
