@@ -29,7 +29,19 @@ struct DevBuf {
         cap = nc;
         return true;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    // pinned host staging for uploads into this buffer: a copy from pageable memory is staged by the runtime and was
+    // measured to block the host for ~7 ms now and then; from pinned memory it is a plain asynchronous DMA
+    void *hp = nullptr;
+    size_t hcap = 0;
+    void *host_stage(size_t bytes) {
+        if (bytes <= hcap && hp) return hp;
+        if (hp) { (void)hipHostFree(hp); hp = nullptr; hcap = 0; }
+        size_t nc = bytes + bytes / 8 + 4096;
+        if (hipHostMalloc(&hp, nc, hipHostMallocDefault) != hipSuccess) { hp = nullptr; hcap = 0; (void)hipGetLastError(); return nullptr; }
+        hcap = nc;
+        return hp;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; if (hp) (void)hipHostFree(hp); hp = nullptr; hcap = 0; }
     ~DevBuf() { release(); }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
@@ -87,6 +99,7 @@ struct lnr_ctx {
     u32 heavy_cap = 0xffffffffu;        // reads with at least this many anchors (after the Y filter) take the 16-wave path (LNR_HEAVY_CAP overrides)
     u32 dp_split_cap = 0xffffffffu, dp_split_cap_r1 = 0xffffffffu;   // reads with at least this many anchors take the split path pre -> 16-wave DP -> post (LNR_DP_SPLIT_CAP, LNR_DP_SPLIT_CAP_R1)
     u32 heavy_cap_r1 = 10000, mid_cap_r1 = 4096;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
+    bool lane_bulk_first = true;         // two lanes: which lane goes through the re-map round first (LNR_LANE_ORDER=heavy|bulk)
     u32 bulk_delay_ticks = 10000;       // head start (100 MHz ticks) of the multi-wave kernels over the bulk kernel (LNR_BULK_DELAY_US)
     u32 split_cap = 0xffffffffu;               // reads with at least this many anchors form the "heavy lane": their re-map round starts
                                         // while the bulk of the batch is still in round 0 (LNR_SPLIT_CAP; 0xffffffff = one lane)
@@ -151,7 +164,12 @@ namespace {
 template <class T>
 lnr_status upload(lnr_ctx *ctx, DevBuf &b, const std::vector<T> &v) {
     ENSURE(b, std::max<size_t>(v.size() * sizeof(T), 16));
-    if (!v.empty()) HIPCK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    if (!v.empty()) {
+        void *h = b.host_stage(v.size() * sizeof(T));
+        if (!h) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+        memcpy(h, v.data(), v.size() * sizeof(T));
+        HIPCK(hipMemcpyAsync(b.p, h, v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    }
     return LNR_OK;
 }
 
@@ -241,7 +259,12 @@ ReadArrays read_arrays(lnr_ctx *ctx) {
 template <class T>
 lnr_status upload_on(lnr_ctx *ctx, DevBuf &b, const std::vector<T> &v, hipStream_t st) {
     ENSURE(b, std::max<size_t>(v.size() * sizeof(T), 16));
-    if (!v.empty()) HIPCK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    if (!v.empty()) {
+        void *h = b.host_stage(v.size() * sizeof(T));
+        if (!h) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+        memcpy(h, v.data(), v.size() * sizeof(T));
+        HIPCK(hipMemcpyAsync(b.p, h, v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    }
     return LNR_OK;
 }
 
@@ -388,7 +411,12 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         laps.lap("scr-layout");
         ENSURE(Lx.job_scr, std::max<u64>(so, 16));
         laps.lap("ensure-scr");
-        HIPCK(hipMemcpyAsync(Lx.j_scr_off.p, scr_off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, sm));
+        {
+            void *h = Lx.j_scr_off.host_stage((size_t)nj * 8);
+            if (!h) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+            memcpy(h, scr_off.data(), (size_t)nj * 8);
+            HIPCK(hipMemcpyAsync(Lx.j_scr_off.p, h, (size_t)nj * 8, hipMemcpyHostToDevice, sm));
+        }
         laps.lap("upload-scr");
         JobArgs A;
         A.grp_order = Lx.grp_order.as<u32>(); A.grp_beg = S.grp_beg.as<u32>(); A.J = job_arrays(S);
@@ -430,7 +458,11 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         // it reaches the GPU first); the split-path chain and the 4-wave kernel take the spare stream when the 16-wave class
         // is present and the batch runs as one lane, else the main stream; the single-wave kernel goes to the lane's bulk stream.
         bool wide2 = gm > gh;                                   // split and / or 4-wave class present
-        hipStream_t s4 = (gh > g0 && wide2 && lane == 1 && ctx->split_cap == 0xffffffffu) ? ctx->s_multi[0] : sm;
+        bool one_lane = ctx->split_cap == 0xffffffffu;
+        // stream of the split / 4-wave class when the 16-wave class is present too: the spare stream when the batch runs as
+        // one lane; with two lanes the other lane owns that stream, so the class queues behind this lane's (short) bulk kernel
+        hipStream_t s4 = (gh > g0 && wide2) ? ((lane == 1 && one_lane) ? ctx->s_multi[0] : sb) : sm;
+        bool after_bulk = s4 == sb && sb != sm;
         bool fork_m = wide2 && s4 != sm, fork_b = g1 > gm && sb != sm && gm > g0;
         if (fork_m || fork_b) HIPCK(hipEventRecord(ctx->ev_fork[lane], sm));    // before any launch: nobody waits for another kernel
         if (gh > g0) {
@@ -440,7 +472,20 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
             hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, sm, H);
             KCHECK();
         }
-        if (fork_m) HIPCK(hipStreamWaitEvent(s4, ctx->ev_fork[lane], 0));
+        auto launch_bulk = [&]() -> lnr_status {
+            if (g1 <= gm) return LNR_OK;
+            hipStream_t bulk = fork_b ? sb : sm;
+            if (fork_b) HIPCK(hipStreamWaitEvent(sb, ctx->ev_fork[lane], 0));
+            if (gm > g0 && bulk != sm && !after_bulk) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, bulk, ctx->bulk_delay_ticks); KCHECK(); }
+            JobArgs K = A;
+            K.grp_lo = gm; K.grp_hi = g1;
+            hipLaunchKernelGGL(k_job, dim3(g1 - gm), dim3(64), lds, bulk, K);
+            KCHECK();
+            return LNR_OK;
+        };
+        if (after_bulk && (s = launch_bulk()) != LNR_OK) return s;
+        if (fork_m && !after_bulk) HIPCK(hipStreamWaitEvent(s4, ctx->ev_fork[lane], 0));
+        if (fork_m && after_bulk && !(g1 > gm)) HIPCK(hipStreamWaitEvent(s4, ctx->ev_fork[lane], 0));
         if (gs > gh) {
             JobArgs P = A;
             P.grp_lo = gh; P.grp_hi = gs; P.lds_bytes = (u32)lds_min; P.arena_lds = 0;   // global scratch only: pointers must replay
@@ -458,23 +503,16 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
             hipLaunchKernelGGL(k_job_mid, dim3(gm - gs), dim3(256), ml, s4, M);
             KCHECK();
         }
-        if (fork_m) HIPCK(hipEventRecord(ctx->ev_join[0], s4));
-        if (g1 > gm) {
-            hipStream_t bulk = fork_b ? sb : sm;
-            if (fork_b) HIPCK(hipStreamWaitEvent(sb, ctx->ev_fork[lane], 0));
-            if (gm > g0 && bulk != sm) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, bulk, ctx->bulk_delay_ticks); KCHECK(); }
-            A.grp_lo = gm; A.grp_hi = g1;
-            hipLaunchKernelGGL(k_job, dim3(g1 - gm), dim3(64), lds, bulk, A);
-            KCHECK();
-            if (fork_b) { HIPCK(hipEventRecord(ctx->ev_join[lane], sb)); HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[lane], 0)); }
-        }
-        if (fork_m) HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[0], 0));
+        if (fork_m && !after_bulk) HIPCK(hipEventRecord(ctx->ev_join[0], s4));
+        if (!after_bulk && (s = launch_bulk()) != LNR_OK) return s;
+        if (fork_b || (after_bulk && fork_m)) { HIPCK(hipEventRecord(ctx->ev_join[lane], sb)); HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[lane], 0)); }
+        if (fork_m && !after_bulk) HIPCK(hipStreamWaitEvent(sm, ctx->ev_join[0], 0));
         laps.lap("launches");
         ctx->stats.job_launches++;
         g0 = g1;
         if (g0 < ngrp) HIPCK(hipStreamSynchronize(sm));   // next slice reuses the scratch
     }
-    if (laps.on && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - laps.t0).count() > 3.0) laps.done();
+    if (laps.on && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - laps.t0).count() > 1.5) laps.done();
     return LNR_OK;
 }
 
@@ -618,7 +656,7 @@ lnr_status remap_round(lnr_ctx *ctx, const BatchHost &B, const std::vector<u32> 
     laps.lap("gaps-copy+build");
     if ((s = seed_jobs(ctx, S, j1, st)) != LNR_OK) return s;
     laps.lap("seed1(sync)");
-    if (getenv("LNR_DEBUG_R1")) {   // diagnostic: round-0 anchors of the reads that own the heavy re-map groups
+    if (getenv("LNR_DEBUG_R1") && !ctx->dbg_r0w.empty()) {   // diagnostic: round-0 anchors of the reads that own the heavy re-map groups
         std::vector<std::pair<u64, u64> > v;
         for (u32 g = 0; g + 1 < j1.grp_beg.size(); g++) {
             u64 w = 0;
@@ -671,32 +709,38 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     u32 ngrp0 = (u32)j0.grp_beg.size() - 1;
     std::vector<u32> grp[2], reads[2];
     std::vector<char> in_heavy(n, 0);
-    ctx->dbg_r0w.assign(n, 0);
+    const bool dbg_r1 = getenv("LNR_DEBUG_R1") != nullptr;
+    if (dbg_r1) ctx->dbg_r0w.assign(n, 0);
     for (u32 g = 0; g < ngrp0; g++) {
         u64 w = 0;
         for (u32 j = j0.grp_beg[g]; j < j0.grp_beg[g + 1]; j++) w += S0.nanc[j];
         int lane = w >= ctx->split_cap ? 0 : 1;
-        ctx->dbg_r0w[j0.read[j0.grp_beg[g]]] = (u32)w;
+        if (dbg_r1) ctx->dbg_r0w[j0.read[j0.grp_beg[g]]] = (u32)w;
         grp[lane].push_back(g);
         if (lane == 0) in_heavy[j0.read[j0.grp_beg[g]]] = 1;
     }
     for (u32 i = 0; i < n; i++) reads[in_heavy[i] ? 0 : 1].push_back(i);   // reads without a job go with the bulk
+    laps.lap("partition");
     HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_f1, 0));   // read features ready (k_f1 ran beside the seed kernel)
     ctx->t_job.start(ctx->stream);
     HIPCK(hipEventRecord(ctx->ev_start, ctx->stream));
     HIPCK(hipStreamWaitEvent(ctx->s_multi[0], ctx->ev_start, 0));
     HIPCK(hipStreamWaitEvent(ctx->s_bulk[1], ctx->ev_start, 0));
+    laps.lap("events");
     if ((s = launch_jobs(ctx, S0, ctx->ln[0], j0, grp[0], 0)) != LNR_OK) return s;
     if ((s = launch_jobs(ctx, S0, ctx->ln[1], j0, grp[1], 1)) != LNR_OK) return s;
     laps.lap("launch0");
-    // lane 0: tail A + re-map round as soon as its round 0 is done (job set 1: lane 1 still reads job set 0)
+    // Whichever lane finishes round 0 first goes through tail A and the re-map round while the other is still in round 0
+    // (job set 1: the other lane still reads job set 0); the second lane follows, by then nobody reads job set 0 any more.
+    // With LNR_SPLIT_CAP at a few thousand anchors lane 0 holds the long single-wave and the 4-wave jobs -- the tail of
+    // round 0 -- and the bulk lane is through first (LNR_LANE_ORDER=bulk, the default); the heavy-first order is kept for
+    // large split values where lane 0 is a handful of reads.
     HostJobs j1h, j1b;
-    if ((s = remap_round(ctx, B, reads[0], 0, S1, ctx->ln[0], ctx->tb[0], j1h)) != LNR_OK) return s;
-    // lane 1: the same once the bulk is through round 0; by then nobody reads job set 0 any more
-    HIPCK(hipStreamSynchronize(ctx->s_multi[1]));
-    laps.lap("wait-r0");
-    if ((s = remap_round(ctx, B, reads[1], 1, S0, ctx->ln[1], ctx->tb[1], j1b)) != LNR_OK) return s;
-    laps.lap("tailA+seed1+launch1");
+    bool bulk_first = ctx->lane_bulk_first;
+    int first = bulk_first ? 1 : 0, second = 1 - first;
+    if (bulk_first) HIPCK(hipStreamSynchronize(ctx->s_multi[1]));
+    if ((s = remap_round(ctx, B, reads[first], first, S1, ctx->ln[first], ctx->tb[first], first ? j1b : j1h)) != LNR_OK) return s;
+    laps.lap("lane-a");
     // Tail B (block chaining on both strands, flags, cords_end; pmpfinder.cpp:2764-2801) of the reads that do not go through
     // the re-map round is final after tail A: it runs on its own stream while the re-map jobs (a few long reads) are busy.
     std::vector<u32> late_list, early_list;
@@ -711,6 +755,11 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         KCHECK();
         HIPCK(hipEventRecord(ctx->ev_prep, ctx->s_tail));
     }
+    HIPCK(hipStreamSynchronize(ctx->s_multi[0]));
+    HIPCK(hipStreamSynchronize(ctx->s_multi[1]));
+    laps.lap("wait-r0");
+    if ((s = remap_round(ctx, B, reads[second], second, S0, ctx->ln[second], ctx->tb[second], second ? j1b : j1h)) != LNR_OK) return s;
+    laps.lap("tailA+seed1+launch1");
     HIPCK(hipEventRecord(ctx->ev_lane[0], ctx->s_multi[0]));
     HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_lane[0], 0));   // (lane 1's multi stream is the main stream)
     ctx->t_job.stop(ctx->stream);
@@ -742,7 +791,12 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     u64 tot = ctx->h_cord_off[n];
     ENSURE(ctx->r_str, std::max<u64>(tot * 8, 16));
     ENSURE(ctx->r_end, std::max<u64>(tot * 8, 16));
-    HIPCK(hipMemcpyAsync(ctx->r_off.p, ctx->h_cord_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    {
+        void *h = ctx->r_off.host_stage(((size_t)n + 1) * 8);
+        if (!h) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+        memcpy(h, ctx->h_cord_off.data(), ((size_t)n + 1) * 8);
+        HIPCK(hipMemcpyAsync(ctx->r_off.p, h, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     hipLaunchKernelGGL(k_gather_out, dim3(n), dim3(64), 0, ctx->stream, ctx->out_str.as<u64>(), ctx->out_end.as<u64>(), ctx->cords_off.as<u64>(), ctx->nout.as<u32>(),
                        ctx->r_off.as<u64>(), n, ctx->r_str.as<u64>(), ctx->r_end.as<u64>());
     KCHECK();
@@ -873,6 +927,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_DP_SPLIT_CAP")) { long v = atol(e); if (v >= 64) { ctx->dp_split_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->dp_split_cap_r1 = ctx->dp_split_cap; } }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->dp_split_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_BULK_DELAY_US")) { long v = atol(e); if (v >= 0 && v <= 5000) ctx->bulk_delay_ticks = (u32)v * 100; }
+    if (const char *e = getenv("LNR_LANE_ORDER")) ctx->lane_bulk_first = e[0] != 'h';
     if (const char *e = getenv("LNR_SPLIT_CAP")) { long v = atol(e); if (v >= 1) ctx->split_cap = (u32)std::min<long>(v, 0xffffffffL); }
     // Three streams in all: the runtime multiplexes streams onto a few hardware queues (4 by default) and two streams on
     // one queue run their kernels back to back (measured: the bulk kernel waited for the 4-wave kernel).  Lane 1 (bulk)
@@ -883,6 +938,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     ok = ok && hipStreamCreateWithFlags(&ctx->s_multi[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ctx->s_bulk[1], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->s_tail, hipStreamNonBlocking) == hipSuccess;
     ctx->s_bulk[0] = ctx->s_multi[0];
+    if (getenv("LNR_LANE0_BULK_STREAM")) ok = ok && hipStreamCreateWithFlags(&ctx->s_bulk[0], hipStreamNonBlocking) == hipSuccess;   // experiment: own stream for lane 0's single-wave kernel
     ctx->s_multi[1] = ctx->stream;
     for (int l = 0; l < 2 && ok; l++)
         ok = hipEventCreateWithFlags(&ctx->ev_fork[l], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_join[l], hipEventDisableTiming) == hipSuccess &&
@@ -909,6 +965,7 @@ void lnr_destroy(lnr_ctx *ctx) {
         if (ctx->ev_lane[l]) (void)hipEventDestroy(ctx->ev_lane[l]);
     }
     if (ctx->s_tail) { (void)hipStreamSynchronize(ctx->s_tail); (void)hipStreamDestroy(ctx->s_tail); }
+    if (ctx->s_bulk[0] && ctx->s_bulk[0] != ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_bulk[0]);
     if (ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_multi[0]);
     if (ctx->s_bulk[1]) (void)hipStreamDestroy(ctx->s_bulk[1]);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
