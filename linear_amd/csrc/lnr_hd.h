@@ -840,8 +840,17 @@ struct BlockScratch { u32 *ptr; UP *sep_tmp; i32 *score_tmp; Rec rec; i32 *chain
 // chainBlocksBase cluster_util.cpp:533-577, in three steps so that the kernel can run the middle one with all lanes:
 //   prepare (tie-sensitive sort of the blocks by first-x + gather), DP (getBestChains2), traceback.
 LNR_HD inline void chain_blocks_prepare(const u64 *records, const UP *sep, const i32 *sep_score, u32 nb, int f_sort, BlockScratch s) {
-    for (u32 i = 0; i < nb; i++) s.ptr[i] = i;
-    if (f_sort) ref_sort(s.ptr, (long)nb, [records, sep](const u32 &a, const u32 &b) { return cord_x40(records[sep[a].first]) > cord_x40(records[sep[b].first]); }, s.ls->st);
+    if (f_sort) {
+        // The reference sorts block indices with a comparator that dereferences twice (first-x of the block's first record).
+        // The same comparisons on a packed key (first-x << 24 | index; sep_tmp doubles as the key array) give the same
+        // permutation -- the sort only sees comparator results -- without a chain of dependent loads per comparison.
+        u64 *e = (u64 *)s.sep_tmp;
+        for (u32 i = 0; i < nb; i++) e[i] = (cord_x40(records[sep[i].first]) << 24) | (u64)i;
+        ref_sort(e, (long)nb, [](const u64 &a, const u64 &b) { return (a >> 24) > (b >> 24); }, s.ls->st);
+        for (u32 i = 0; i < nb; i++) s.ptr[i] = (u32)(e[i] & 0xffffffu);
+    } else {
+        for (u32 i = 0; i < nb; i++) s.ptr[i] = i;
+    }
     for (u32 i = 0; i < nb; i++) { s.sep_tmp[i] = sep[s.ptr[i]]; s.score_tmp[i] = sep_score[s.ptr[i]]; }
 }
 LNR_HD inline void chain_blocks_trace(BlockSink &sink, u32 nb, BlockScratch s) {

@@ -1060,9 +1060,18 @@ __device__ u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &sep, u32 nb
     int lane = lane_id();
     const u64 mask = 1ULL << 62;
     UP *sp = sep.p;
-    for (u32 i = lane; i < nb; i += 64) { cuts[2 * i] = sp[i].first; cuts[2 * i + 1] = (sp[i].second - 1) | mask; xy_strs[i] = sp[i].first; }
+    // cuts are sorted by the y of the hit they point at; the key travels with the element (y << 32 | end flag << 31 | hit
+    // index) so that the tie-sensitive sort compares array elements only -- same comparator results, same permutation
+    for (u32 i = lane; i < nb; i += 64) {
+        u64 f = sp[i].first, l = sp[i].second - 1;
+        cuts[2 * i] = (cord_y(hits[f]) << 32) | f;
+        cuts[2 * i + 1] = (cord_y(hits[l]) << 32) | (1ULL << 31) | l;
+        xy_strs[i] = f;
+    }
     WSYNC();
-    if (lane == 0) { const u64 *h = hits; ref_sort(cuts, (long)(2 * nb), [h, mask](const u64 &a, const u64 &b) { return cord_y(h[a & ~mask]) < cord_y(h[b & ~mask]); }, ls.st); }
+    if (lane == 0) ref_sort(cuts, (long)(2 * nb), [](const u64 &a, const u64 &b) { return (a >> 32) < (b >> 32); }, ls.st);
+    WSYNC();
+    for (u32 i = lane; i < 2 * nb; i += 64) { u64 e = cuts[i]; cuts[i] = (e & 0x7fffffffULL) | ((e >> 31) & 1 ? mask : 0); }   // back to index | end mask
     WSYNC();
     UP *tp = tmp.p;
     u32 ntmp = 0, tcap = tmp.cap;
@@ -1231,6 +1240,9 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
         int mode = (int)A.J.mode[j];
         Arena slow, ar;
         bool ok = true;
+#ifdef LNR_PROF
+        for (int q = 0; q < 16; q++) lnr_job_ph[q] = 0;
+#endif
         if (lead && PHASE != 2) {
             u64 *ag = A.anchors + A.anc_off[j];
             u32 n = A.n_anchors[j];
@@ -1256,12 +1268,14 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             LNR_TICK(prof, 2, tk_);
             m = n > 1 ? filter_anchor_list_wave(a, n) : n;   // filterAnchors1 (pmpfinder.cpp:2073-2091)
             WSYNC();
+            LNR_TICK(prof, 14, tk_);
             if (m > 1) {
                 // scratch of the sort: position lists in the (dead) radix buffer, task list behind it
                 u32 *Lbuf = (u32 *)s_alt, *Rbuf = Lbuf + (m + 2);
                 u64 *tasks = slow.get<u64>((u64)m + 2);
                 introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, &s_ls);
             }
+            LNR_TICK(prof, 15, tk_);
             ok = job_carve(ar, m, S, &s_ovf) && !slow.ovf;
             if (ok) {
                 job_fill_xy(a, m, S, (u32)lane, 64);
@@ -1286,7 +1300,6 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             unsigned long long pairs = 0;
             if (ok && m >= 2) { u32 p300 = 0; for (u32 i = 0; i < m; i++) { while (p300 < i && S.xs[p300] - S.xs[i] >= 300) p300++; u32 js = i > 20 ? i - 20 : 0; pairs += i - (p300 < js ? p300 : js); } }
             if (tl) tl[3] += ((unsigned long long)m << 32) | (pairs > 0xffffffffULL ? 0xffffffffULL : pairs);
-            for (int q = 0; q < 16; q++) lnr_job_ph[q] = 0;
             lnr_job_ph[10] = m; lnr_job_ph[11] = pairs; lnr_job_ph[12] = A.n_anchors[j];
             atomicAdd(&prof[10], 1ULL); atomicAdd(&prof[11], (unsigned long long)m); atomicAdd(&prof[12], pairs); atomicAdd(&prof[13], (unsigned long long)A.n_anchors[j]);
             tk_ = clock64();
@@ -1366,7 +1379,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             if (A.prof && lane == 0) {   // phase cycles of the job with the most anchors in the DP (per launch class of 4: A.prof + 128 + 16 * class)
                 unsigned long long *mp = A.prof + 128 + 16 * ((NW > 1 ? 2 : 0) + (A.J.mode[jb] ? 1 : 0));
                 unsigned long long old = atomicMax(&mp[10], lnr_job_ph[10]);
-                if (lnr_job_ph[10] > old) { for (int q = 0; q < 10; q++) mp[q] = lnr_job_ph[q]; mp[11] = lnr_job_ph[11]; mp[12] = lnr_job_ph[12]; }
+                if (lnr_job_ph[10] > old) { for (int q = 0; q < 10; q++) mp[q] = lnr_job_ph[q]; mp[11] = lnr_job_ph[11]; mp[12] = lnr_job_ph[12]; mp[14] = lnr_job_ph[14]; mp[15] = lnr_job_ph[15]; }
             }
             tk_ = clock64();
 #endif

@@ -31,7 +31,7 @@ for cls, cname in enumerate(["k_job round 0", "k_job round 1 (re-map)", "k_job_h
     for i, nm in enumerate(names):
         print(f"   {nm:42s} {o[i] / 1e6:10.1f} Mcyc {100.0 * o[i] / max(tot, 1):5.1f} %  per job {o[i] / jobs:9.0f}  max {o[16 + i] / 1e6:8.2f} Mcyc")
     mp = out[128 + 16 * cls: 128 + 16 * cls + 16]
-    print(f"   biggest job of the class: {mp[12]} anchors in, {mp[10]} in the DP, {mp[11]} pairs; Mcyc per phase: " + " ".join(f"{mp[i] / 1e6:.2f}" for i in range(10)) + f"  (sum {sum(mp[:10]) / 1e6:.1f})")
+    print(f"   biggest job of the class: {mp[12]} anchors in, {mp[10]} in the DP, {mp[11]} pairs; Mcyc per phase: " + " ".join(f"{mp[i] / 1e6:.2f}" for i in range(10)) + f"  (sum {sum(mp[:10]) / 1e6:.1f}); list filter {mp[14] / 1e6:.2f}, introsort {mp[15] / 1e6:.2f} (phase 3 column = carve + x/y fill)")
 
 # ---- per-workgroup timeline (100 MHz ticks): who runs when, and what the tail consists of
 f.lib.lnr_prof_timeline.restype = C.c_longlong
