@@ -1026,6 +1026,26 @@ __device__ int traceback1_table_wave(const Rec &r, u32 n, LeaderScratch *ls) {
 }
 // traceBackChains (cluster_util.cpp:306-335) for the anchor DP, lanes cooperating on the scans; lane 0 walks chains
 // and emits hits.  s_flag = one LDS word.
+// A chain is walked by the leader (one dependent load per element: p2) and then emitted by all lanes: hit words and chain
+// scores are independent gathers.  Same effect as AnchorSink::emit; every lane keeps the sink's counters in step.
+struct DeferSink { u32 nchains, first_len, pending; LNR_HD void emit(const i32 *, const i32 *, u32 n) { pending = n; } };
+__device__ void emit_chain_wave(AnchorSink &sink, const Rec &r, const i32 *chain, u32 cn) {
+    int lane = lane_id();
+    Vec<u64> &H = *sink.hits; Vec<i32> &HS = *sink.hscore;
+    u32 base = H.n, sbase = HS.n;
+    u32 fit = cn, sfit = cn;
+    if (base + cn > H.cap) { fit = H.cap - base; if (lane == 0) *H.ovf = 1; }
+    if (sbase + cn > HS.cap) { sfit = HS.cap - sbase; if (lane == 0) *HS.ovf = 1; }
+    for (u32 k = lane; k < cn; k += 64) {
+        i32 idx = chain[k];
+        if (k < fit) H.p[base + k] = hit2cord(sink.anchors[idx]) | (k + 1 == fit ? F_END : 0);
+        if (k < sfit) HS.p[sbase + k] = r.score2[idx];
+    }
+    H.n = base + fit; HS.n = sbase + sfit;
+    if (sink.nchains == 0) sink.first_len = cn;
+    sink.nchains++;
+    WSYNC();
+}
 __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int *s_flag, LeaderScratch *ls) {
     int lane = lane_id();
     for (u32 i = lane; i < n; i += 64) cnt[i] = 0;
@@ -1035,19 +1055,46 @@ __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain
     u32 c = 0;
     for (u32 i = lane; i < n; i += 64) c += (u32)cnt[i];
     u32 root_num = wave_sum(c);
+    const int min_len = 1, abort_score = 45, bestn = 50;
     if (root_num > 50) {
         for (int it = 0; it < 50; it++) {
             Tb0Scan sc = tb0_scan_wave(r, n);
-            if (lane == 0) *s_flag = tb0_step(r, sc, sink, chain, chain_sc, 1, 45, 0.0f) ? 1 : 0;
+            if (lane == 0) {
+                DeferSink ds; ds.nchains = sink.nchains; ds.first_len = sink.first_len; ds.pending = 0;
+                int cont = tb0_step(r, sc, ds, chain, chain_sc, min_len, abort_score, 0.0f) ? 1 : 0;
+                *s_flag = cont | (int)(ds.pending << 1);
+            }
             WSYNC();
-            int cont = *s_flag;
+            int fl = *s_flag;
             WSYNC();
-            if (!cont) break;
+            if (fl >> 1) emit_chain_wave(sink, r, chain, (u32)fl >> 1);
+            if (!(fl & 1)) break;
         }
     } else {
         int nl = traceback1_table_wave(r, n, ls);
-        if (lane == 0) traceback1_emit(r, nl, sink, chain, chain_sc, 1, 45, 50, 0.0f, *ls);
+        if (lane == 0) {   // trees by score (std::sort order, cluster_util.cpp:269)
+            for (int i = 0; i < nl; i++) ls->ranks[i] = ((u64)(u32)ls->l_score[i] << 32) | (u32)i;
+            ref_sort(ls->ranks, (long)nl, [](const u64 &a, const u64 &b) { return (i32)(a >> 32) > (i32)(b >> 32); }, ls->st);
+        }
         WSYNC();
+        int lim = bestn < nl ? bestn : nl;
+        for (int i = 0; i < lim; i++) {
+            int t = (int)(u32)ls->ranks[i];
+            int max_score = ls->l_score[t], max_len = ls->l_len[t], max_str = ls->l_leaf[t];
+            int mean = max_len > 1 ? max_score / (max_len - 1) : abort_score + 1;
+            if (max_len > min_len && mean > abort_score) {
+                if (lane == 0) {
+                    u32 cn = 0;
+                    for (int j = max_str; j != -1; j = r.p2[j]) chain[cn++] = j;
+                    *s_flag = (int)cn;
+                }
+                WSYNC();
+                u32 cn = (u32)*s_flag;
+                WSYNC();
+                // (the f_stop test of the serial form compares against stop_ratio = 0 here and never fires)
+                if (cn) emit_chain_wave(sink, r, chain, cn);
+            }
+        }
     }
 }
 
@@ -1325,7 +1372,8 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
         // ---------------- post: traceback, blocks, windows (leader wave)
         if (lead) {
             AnchorSink sink; sink.anchors = a; sink.hits = &S.hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
-            if (lane == 0) { S.hits.n = 0; S.hscore.n = 0; S.hits.push(F_END); S.hscore.push(0); }
+            S.hits.n = 0; S.hscore.n = 0; S.hits.push_u(F_END); S.hscore.push_u(0);   // every lane tracks the counts
+            WSYNC();
             if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, &s_flag, &s_ls);
             LNR_TICK(prof, 5, tk_);
             JobCtx c;
