@@ -933,7 +933,7 @@ LNR_HD inline u64 next_window(FeatView f1, FeatView f2, u64 cord) {   // pmpfind
 }
 // SIMT-uniform: on the device every lane of the wave executes this with the same arguments (see window_best3);
 // `tail` is the value of cords.back(), carried in a register so that no lane has to re-read the leader's store.
-LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 &tail, u64 cordy_str, u64 cordy_end) {   // pmpfinder.cpp:1152-1178
+LNR_HD inline bool extend_window_serial(FeatView f1, FeatView f2, Vec<u64> &cords, u64 &tail, u64 cordy_str, u64 cordy_end) {   // pmpfinder.cpp:1152-1178
     u32 p_str = cords.n - 1;
     u64 nc;
     while ((nc = previous_window(f1, f2, tail)) && cord_y(nc) >= cordy_str) {
@@ -954,6 +954,91 @@ LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 
     }
     return true;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same walk with the window distances of several steps evaluated at once.  A step only chooses among three
+// neighbouring windows, so the windows reachable within the next few steps form a small frontier: its distances are
+// independent loads (one per lane), and the walk through them is register work.  One memory round trip per frontier instead
+// of one per step; the choices, stop conditions and emitted cords are those of previous_window / next_window.
+//   forward : step s looks at y0 + 5s and x in [x0 + 3s, x0 + 5s]                        -> 7 steps, 63 windows
+//   backward: after d steps the state is (x0 - 5d + c, y0 - 5d + a), a + c <= d; step d looks at y0 - 5d + a (a < d) and
+//             x0 - 5d + u (-1 <= u <= d)                                                   -> 4 steps, 50 windows
+LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 &tail, u64 cordy_str, u64 cordy_end) {
+    const int lane = (int)(threadIdx.x & 63);
+    u32 p_str = cords.n - 1;
+    // ---- backward
+    {
+        int d = lane < 3 ? 1 : (lane < 11 ? 2 : (lane < 26 ? 3 : 4));
+        int pre = d == 1 ? 0 : (d == 2 ? 3 : (d == 3 ? 11 : 26));
+        int idx = lane - pre;
+        int la = idx / (d + 2), lu = idx % (d + 2) - 1;
+        bool stop = false;
+        while (!stop) {
+            u64 gid = cord_id(tail), strand = cord_strand(tail);
+            i64 x0 = (i64)(cord_x(tail) >> 4), y0 = (i64)(cord_y(tail) >> 4);
+            i64 Y = y0 - 5 * d + la, X = x0 - 5 * d + lu;
+            u32 dv = (lane < 50 && Y >= 0 && X >= 0) ? wdist_raw(f1, f2, (u64)Y, (u64)X) : 0xffffffffu;
+            int a = 0, c = 0;
+            for (int k = 0; k < 4; k++) {
+                i64 x = x0 - 5 * k + c, y = y0 - 5 * k + a;       // state before step k + 1
+                if (y < 5 || x < 6) { stop = true; break; }
+                int dd = k + 1;
+                int bl = (dd == 1 ? 0 : (dd == 2 ? 3 : (dd == 3 ? 11 : 26))) + a * (dd + 2) + c;
+                u32 t0 = __shfl(dv, bl), t1 = __shfl(dv, bl + 1), t2 = __shfl(dv, bl + 2);
+                u32 mn = t0; int j = 0;
+                if (t1 < mn) { mn = t1; j = 1; }
+                if (t2 < mn) { mn = t2; j = 2; }
+                if (mn > 36) { stop = true; break; }
+                u64 nc;
+                if (j == 0) { nc = mk_cord((gid << 30) + ((u64)(x - 5) << 4), (u64)(y - 4) << 4, strand); a++; }
+                else { nc = mk_cord((gid << 30) + ((u64)(x - 6 + j) << 4), (u64)(y - 5) << 4, strand); if (j == 2) c++; }
+                if (!(cord_y(nc) >= cordy_str)) { stop = true; break; }
+                if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return false; }
+                cords.push_u(nc); tail = nc;
+            }
+        }
+    }
+    u32 p_end = cords.n;
+    if (p_end - p_str > 1) {
+        lnr_wave_sync();
+        if (lnr_is_leader())
+            for (u32 k = p_str; k < (p_str + p_end) / 2; k++) rs_swap(cords[k], cords[cords.n - k + p_str - 1]);
+        lnr_wave_sync();
+        tail = cords[cords.n - 1];
+    }
+    // ---- forward
+    {
+        int s_ = 1;
+        while ((s_ + 1) * (s_ + 1) - 1 <= lane) s_++;          // lane -> step: s^2 - 1 <= lane < (s + 1)^2 - 1
+        int off = lane - (s_ * s_ - 1);
+        bool stop = false;
+        while (!stop) {
+            u64 gid = cord_id(tail), strand = cord_strand(tail);
+            u64 x0 = cord_x(tail) >> 4, y0 = cord_y(tail) >> 4;
+            u32 dv = lane < 63 ? wdist_raw(f1, f2, y0 + 5 * (u64)s_, x0 + 3 * (u64)s_ + (u64)off) : 0xffffffffu;
+            u64 xc = x0, yc = y0;
+            for (int k = 1; k <= 7; k++) {
+                if (yc + 12 > f1.n || xc + 12 > f2.n) { stop = true; break; }
+                int bl = k * k - 1 + (int)(xc - x0) - 3 * (k - 1);
+                u32 t0 = __shfl(dv, bl), t1 = __shfl(dv, bl + 1), t2 = __shfl(dv, bl + 2);
+                u32 mn = t0; u64 x_min = xc + 3;
+                if (t1 < mn) { mn = t1; x_min = xc + 4; }
+                if (t2 < mn) { mn = t2; x_min = xc + 5; }
+                if (mn > 36) { stop = true; break; }
+                u64 nc = mk_cord((gid << 30) + (x_min << 4), (yc + 5) << 4, strand);   // x_min - xc <= 5: the reference's other branch cannot be taken
+                if (!(cord_y(nc) + 96 < cordy_end)) { stop = true; break; }
+                if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return false; }
+                cords.push_u(nc); tail = nc;
+                xc = x_min; yc += 5;
+            }
+        }
+    }
+    return true;
+}
+#else
+LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 &tail, u64 cordy_str, u64 cordy_end) {
+    return extend_window_serial(f1, f2, cords, tail, cordy_str, cordy_end);
+}
+#endif
 struct GenomeFeat { const F96 *base; const u64 *off; u32 nseq; };   // f2 of all sequences, off[nseq+1] in entries
 LNR_HD inline FeatView f2_view(GenomeFeat g, u64 id) {
     FeatView v;
