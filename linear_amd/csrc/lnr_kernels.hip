@@ -955,7 +955,7 @@ __device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int
 
 // wave-parallel twin of tb0_scan_serial: first index of the maximal score (> -1), the running maximum seen before
 // it (floor -1) and the chain length there.
-__device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {
+__device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {   // first index of the maximal score (> -1) and the chain length there; max_2nd is left open
     int lane = lane_id();
     i64 best = -1;
     for (u32 j0 = 0; j0 < n; j0 += 256) {   // four independent loads in flight per lane (the scan is latency bound)
@@ -973,17 +973,22 @@ __device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {
     if (best < 0) return s;
     s.max_score = (int)(best >> 32);
     s.max_str = 0x7fffffff - (int)(u32)(best & 0xffffffff);
+    s.max_len = r.len[s.max_str];
+    return s;
+}
+// maximum of the scores before index `end` (floor -1): the "second best" of traceBackChains0, needed only when a walk runs
+// into an element an earlier chain already took
+__device__ int tb0_prefix_max_wave(const Rec &r, u32 end) {
+    int lane = lane_id();
     i64 m2 = -1;
-    for (u32 j0 = 0; j0 < (u32)s.max_str; j0 += 256) {
+    for (u32 j0 = 0; j0 < end; j0 += 256) {
         int sc[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { u32 j = j0 + 64 * u + (u32)lane; sc[u] = j < (u32)s.max_str ? r.score[j] : -1; }
+        for (int u = 0; u < 4; u++) { u32 j = j0 + 64 * u + (u32)lane; sc[u] = j < end ? r.score[j] : -1; }
 #pragma unroll
         for (int u = 0; u < 4; u++) { i64 v = sc[u]; m2 = v > m2 ? v : m2; }
     }
-    s.max_2nd = (int)wave_max_i64(m2);
-    s.max_len = r.len[s.max_str];
-    return s;
+    return (int)wave_max_i64(m2);
 }
 // wave-parallel twin of traceback1_table: lanes over the anchors, the (<= 50) trees in LDS.  Trees are numbered by their
 // first leaf: per chunk of 64 anchors the not-yet-listed roots are appended lowest lane first.  The best leaf of a tree is
@@ -1025,7 +1030,7 @@ __device__ int traceback1_table_wave(const Rec &r, u32 n, LeaderScratch *ls) {
     return nl;
 }
 // traceBackChains (cluster_util.cpp:306-335) for the anchor DP, lanes cooperating on the scans; lane 0 walks chains
-// and emits hits.  s_flag = one LDS word.
+// and emits hits.  s_flag = four LDS words.
 // A chain is walked by the leader (one dependent load per element: p2) and then emitted by all lanes: hit words and chain
 // scores are independent gathers.  Same effect as AnchorSink::emit; every lane keeps the sink's counters in step.
 struct DeferSink { u32 nchains, first_len, pending; LNR_HD void emit(const i32 *, const i32 *, u32 n) { pending = n; } };
@@ -1057,18 +1062,50 @@ __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain
     u32 root_num = wave_sum(c);
     const int min_len = 1, abort_score = 45, bestn = 50;
     if (root_num > 50) {
+        // traceBackChains0 (cluster_util.cpp:113-211), one search per iteration.  The reference scans for the best score AND
+        // the best score before it; the second is only consulted when the walk meets an element that an earlier chain took,
+        // so it is computed then -- from the scores after this walk's deletions plus the largest score the walk deleted
+        // (every deleted element lies before max_str), which is the value the up-front scan would have returned.
+        const int delete_score = -1000;
         for (int it = 0; it < 50; it++) {
             Tb0Scan sc = tb0_scan_wave(r, n);
-            if (lane == 0) {
-                DeferSink ds; ds.nchains = sink.nchains; ds.first_len = sink.first_len; ds.pending = 0;
-                int cont = tb0_step(r, sc, ds, chain, chain_sc, min_len, abort_score, 0.0f) ? 1 : 0;
-                *s_flag = cont | (int)(ds.pending << 1);
+            int max_score = sc.max_score, max_str = sc.max_str, max_len = sc.max_len;
+            bool f_done = max_str == -1;
+            if (sink.nchains) { if ((float)max_len > (float)sink.first_len * 0.0f) f_done = false; }
+            if (f_done || max_score == 0) break;
+            bool walk = max_len > min_len && max_score / (max_len - 1) > abort_score;
+            u32 cn = 0;
+            if (walk) {
+                if (lane == 0) {
+                    int hit = -1, m_del = -1;
+                    u32 c2 = 0;
+                    for (int j = max_str; j != -1; j = r.p2[j]) {
+                        int sj = r.score[j];
+                        if (sj != delete_score) {
+                            chain[c2++] = j;
+                            if (j != max_str && sj > m_del) m_del = sj;
+                            r.score[j] = delete_score;
+                        } else { hit = j; break; }
+                    }
+                    s_flag[0] = (int)c2; s_flag[1] = hit; s_flag[2] = m_del;
+                }
+                WSYNC();
+                cn = (u32)s_flag[0];
+                int hit = s_flag[1], m_del = s_flag[2];
+                WSYNC();
+                if (hit >= 0) {
+                    int m2 = tb0_prefix_max_wave(r, (u32)max_str);
+                    int max_2nd = m2 > m_del ? m2 : m_del;
+                    int infix = r.score2[hit];
+                    if (max_score - infix < max_2nd) {
+                        if (lane == 0) for (int k = max_str; k != hit; k = r.p2[k]) r.score[k] = r.score2[k] - infix;
+                        cn = 0;
+                        WSYNC();
+                    }
+                }
+                if (cn) emit_chain_wave(sink, r, chain, cn);
             }
-            WSYNC();
-            int fl = *s_flag;
-            WSYNC();
-            if (fl >> 1) emit_chain_wave(sink, r, chain, (u32)fl >> 1);
-            if (!(fl & 1)) break;
+            if (max_str != -1) { if (lane == 0) r.score[max_str] = delete_score; WSYNC(); }
         }
     } else {
         int nl = traceback1_table_wave(r, n, ls);
@@ -1249,7 +1286,7 @@ template <int NW, int PHASE = 0>
 __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
     __shared__ u32 hist[256];
     __shared__ u32 s_m;
-    __shared__ int s_ovf, s_flag;
+    __shared__ int s_ovf, s_flag[4];
     __shared__ u64 *s_H;
     __shared__ u32 s_nH, s_nhits;
     __shared__ LeaderScratch s_ls;   // introsort stack + tree table: one per workgroup, in LDS
@@ -1374,7 +1411,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             AnchorSink sink; sink.anchors = a; sink.hits = &S.hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
             S.hits.n = 0; S.hscore.n = 0; S.hits.push_u(F_END); S.hscore.push_u(0);   // every lane tracks the counts
             WSYNC();
-            if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, &s_flag, &s_ls);
+            if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, s_flag, &s_ls);
             LNR_TICK(prof, 5, tk_);
             JobCtx c;
             c.traceback_done = 1;
