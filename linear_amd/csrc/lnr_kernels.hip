@@ -1155,10 +1155,43 @@ __device__ u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &sep, u32 nb
     WSYNC();
     if (lane == 0) ref_sort(cuts, (long)(2 * nb), [](const u64 &a, const u64 &b) { return (a >> 32) < (b >> 32); }, ls.st);
     WSYNC();
-    for (u32 i = lane; i < 2 * nb; i += 64) { u64 e = cuts[i]; cuts[i] = (e & 0x7fffffffULL) | ((e >> 31) & 1 ? mask : 0); }   // back to index | end mask
-    WSYNC();
     UP *tp = tmp.p;
     u32 ntmp = 0, tcap = tmp.cap;
+    if (nb <= 64) {
+        // The usual case: one block per lane, its cursor, end and the y at the cursor live in registers; a cut is a packed
+        // element (y in the upper half), so a pass touches memory only where a block really advances.  No store of one lane
+        // is read by another, hence no ordering point inside the loop.
+        bool mine = (u32)lane < nb;
+        u64 lower = mine ? xy_strs[lane] : ~0ULL, kend = mine ? sp[lane].second : 0;
+        u64 ylow = (mine && lower < nhits) ? cord_y(hits[lower]) : 0;
+        for (u32 i = 0; i < 2 * nb; i++) {
+            u64 e = cuts[i];
+            u64 cuty = e >> 32;
+            bool is_end = ((e >> 31) & 1) != 0;
+            u64 mm = __ballot(mine && lower >= nhits);
+            u32 jstar = mm ? (u32)__builtin_ctzll(mm) : nb;   // first block whose cursor already sits at the end of hits
+            bool emit = false;
+            UP piece; piece.first = 0; piece.second = 0;
+            if ((u32)lane < jstar && !(cuty < ylow)) {
+                for (u64 k = lower; k < kend; k++) {
+                    u64 ky = k == lower ? ylow : cord_y(hits[k]);
+                    u64 upper; bool c;
+                    if (is_end) { if (ky == cuty) { upper = k + 1; c = true; } else if (ky > cuty) { upper = k; c = true; } else c = false; }
+                    else { if (ky >= cuty) { upper = k; c = true; } else c = false; }
+                    if (c) {
+                        if (lower != upper) { emit = true; piece.first = lower; piece.second = upper; lower = upper; ylow = lower < nhits ? cord_y(hits[lower]) : 0; }
+                        break;
+                    }
+                }
+            }
+            u64 em = __ballot(emit);
+            if (emit) { u32 pos = ntmp + (u32)__popcll(em & lanemask_lt()); if (pos < tcap) tp[pos] = piece; }
+            ntmp += (u32)__popcll(em);
+        }
+        WSYNC();
+    } else {
+    for (u32 i = lane; i < 2 * nb; i += 64) { u64 e = cuts[i]; cuts[i] = (e & 0x7fffffffULL) | ((e >> 31) & 1 ? mask : 0); }   // back to index | end mask
+    WSYNC();
     for (u32 i = 0; i < 2 * nb; i++) {
         u64 cut = cuts[i];
         u64 cuty = cord_y(hits[cut & ~mask]);
@@ -1194,6 +1227,7 @@ __device__ u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &sep, u32 nb
             ntmp += (u32)__popcll(em);
         }
         WSYNC();
+    }
     }
     if (ntmp > tcap) { if (lane == 0) *tmp.ovf = 1; ntmp = tcap; }
     for (u32 i = lane; i < ntmp; i += 64) sp[i] = tp[i];
