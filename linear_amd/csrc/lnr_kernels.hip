@@ -724,7 +724,12 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
                 ntasks++;
                 break;
             }
-            if (depth == 0) { if (lane == 0) rs_heap_sort(a, (long)first, (long)last, comp); WSYNC(); break; }
+            if (depth == 0) {   // depth limit: heap sort of the range (practically never reached).  Deferred to the task pass below:
+                                // inlined here, its live ranges lifted the whole job kernel from 96 to 98 VGPRs (5 -> 4 waves per SIMD)
+                if (lane == 0) tasks[ntasks] = (u64)first | ((u64)last << 28) | (1ULL << 63);
+                ntasks++;
+                break;
+            }
             --depth;
             if (lane == 0) {   // __move_median_to_first(first, first+1, mid, last-1)
                 u32 A = first + 1, B = first + (last - first) / 2, C = last - 1;
@@ -765,7 +770,8 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
     WSYNC();
     for (u32 t = lane; t < ntasks; t += 64) {
         u64 v = tasks[t];
-        rs_finish_range<16>(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)(v >> 56), comp);   // ranges of <= 32 elements
+        if (v >> 63) rs_heap_sort(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), comp);
+        else rs_finish_range<16>(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)((v >> 56) & 0x7f), comp);   // ranges of <= 32 elements
     }
     WSYNC();
 }
