@@ -100,6 +100,7 @@ struct lnr_ctx {
     u32 dp_split_cap = 0xffffffffu, dp_split_cap_r1 = 0xffffffffu;   // reads with at least this many anchors take the split path pre -> 16-wave DP -> post (LNR_DP_SPLIT_CAP, LNR_DP_SPLIT_CAP_R1)
     u32 heavy_cap_r1 = 10000, mid_cap_r1 = 4096;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
     bool lane_bulk_first = true;         // two lanes: which lane goes through the re-map round first (LNR_LANE_ORDER=heavy|bulk)
+    u32 prep_threads = 256;             // workgroup size of k_prep (LNR_PREP_THREADS: 64, 128 or 256)
     u32 bulk_delay_ticks = 10000;       // head start (100 MHz ticks) of the multi-wave kernels over the bulk kernel (LNR_BULK_DELAY_US)
     u32 split_cap = 0xffffffffu;               // reads with at least this many anchors form the "heavy lane": their re-map round starts
                                         // while the bulk of the batch is still in round 0 (LNR_SPLIT_CAP; 0xffffffff = one lane)
@@ -566,7 +567,7 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     HIPCK(hipMemsetAsync(ctx->ncords.p, 0, (size_t)n * 4, ctx->stream));
     HIPCK(hipMemsetAsync(ctx->read_err.p, 0, (size_t)n * 4, ctx->stream));
     ctx->t_prep.start(ctx->stream);
-    hipLaunchKernelGGL(k_prep, dim3(n), dim3(256), 0, ctx->stream, d_reads, d_off, ctx->pk_off.as<u64>(), n, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
+    hipLaunchKernelGGL(k_prep, dim3(n), dim3(ctx->prep_threads), 0, ctx->stream, d_reads, d_off, ctx->pk_off.as<u64>(), n, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
     KCHECK();
     ctx->t_prep.stop(ctx->stream);
     ctx->stats.reads = n;
@@ -926,6 +927,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_MID_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->mid_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP")) { long v = atol(e); if (v >= 64) { ctx->dp_split_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->dp_split_cap_r1 = ctx->dp_split_cap; } }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->dp_split_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
+    if (const char *e = getenv("LNR_PREP_THREADS")) { long v = atol(e); if (v == 64 || v == 128 || v == 256) ctx->prep_threads = (u32)v; }
     if (const char *e = getenv("LNR_BULK_DELAY_US")) { long v = atol(e); if (v >= 0 && v <= 5000) ctx->bulk_delay_ticks = (u32)v * 100; }
     if (const char *e = getenv("LNR_LANE_ORDER")) ctx->lane_bulk_first = e[0] != 'h';
     if (const char *e = getenv("LNR_SPLIT_CAP")) { long v = atol(e); if (v >= 1) ctx->split_cap = (u32)std::min<long>(v, 0xffffffffL); }

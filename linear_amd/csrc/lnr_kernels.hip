@@ -396,16 +396,17 @@ __global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, con
             ByteSeq bs; bs.p = rd; bs.L = L;
             read_ks[r] = (s_n[0][0][0] & 0x1FFFFFu) ? shape_init_skip(bs) : 0;
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            u32 st = st0 + u;
-            if (st >= 2 * nstep) break;
-            bool rev = st >= nstep;
-            u32 wi = 8 * (rev ? st - nstep : st) + (u32)lane;
-            if (lane < 8 && wi < nw) {
-                u32 base = rev ? nw : 0;
-                pw[base + wi] = s_c[wave][u][lane];
-                nw_[base + wi] = s_n[wave][u][lane];
+        {   // the U steps are consecutive: 8 U packed words (and bitmap words) leave in one store instruction each
+            int u = lane >> 3, w = lane & 7;
+            u32 st = st0 + (u32)u;
+            if (lane < 8 * U && st < 2 * nstep) {
+                bool rev = st >= nstep;
+                u32 wi = 8 * (rev ? st - nstep : st) + (u32)w;
+                if (wi < nw) {
+                    u32 base = rev ? nw : 0;
+                    pw[base + wi] = s_c[wave][u][w];
+                    nw_[base + wi] = s_n[wave][u][w];
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
