@@ -52,8 +52,8 @@ def recorded_traffic(args, launches_per_step):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--err", type=float, default=0.10)
