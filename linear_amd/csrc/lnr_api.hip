@@ -130,7 +130,9 @@ struct lnr_ctx {
     DevBuf prof, tl; u32 tl_round = 0, tl_n[4] = {0, 0, 0, 0}; u32 tl_nh[4] = {0, 0, 0, 0};
     // ---- results
     DevBuf r_off, r_str, r_end;
-    std::vector<u64> h_cord_off, h_cords_str, h_cords_end, h_anchor_off, h_anchors;
+    std::vector<u64> h_cord_off, h_anchor_off, h_anchors;
+    PinBuf h_cords_str, h_cords_end, h_up[2];   // results land in pinned memory (DMA at link rate, no page faults); h_up: upload staging ring
+    hipEvent_t ev_up[2] = {nullptr, nullptr};
     std::vector<u32> dbg_r0w;   // round-0 anchors per read (LNR_DEBUG_R1 diagnostic)
     u32 last_n = 0;
     u64 last_ncords = 0;
@@ -867,7 +869,25 @@ lnr_status stage_reads(lnr_ctx *ctx, const u8 *reads, const u64 *off, u32 n) {
     ENSURE(ctx->in_off, ((size_t)n + 1) * 8);
     std::vector<u64> o((size_t)n + 1);
     for (u32 i = 0; i <= n; i++) o[i] = off[i] - base;
-    if (total) HIPCK(hipMemcpyAsync(ctx->in_reads.p, reads + base, total, hipMemcpyHostToDevice, ctx->stream));
+    // the caller's buffer is pageable: copy it through two pinned staging buffers so that the host memcpy of one chunk
+    // overlaps the DMA of the previous one
+    const u64 CH = 32ULL << 20;
+    if (total) {
+        for (int k = 0; k < 2; k++) {
+            if (!ctx->h_up[k].ensure(CH)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+            if (!ctx->ev_up[k]) HIPCK(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
+        }
+        int k = 0;
+        bool used[2] = {false, false};
+        for (u64 o2 = 0; o2 < total; o2 += CH, k ^= 1) {
+            u64 len = std::min<u64>(CH, total - o2);
+            if (used[k]) HIPCK(hipEventSynchronize(ctx->ev_up[k]));   // the DMA out of this staging buffer has finished
+            memcpy(ctx->h_up[k].p, reads + base + o2, len);
+            HIPCK(hipMemcpyAsync(ctx->in_reads.as<u8>() + o2, ctx->h_up[k].p, len, hipMemcpyHostToDevice, ctx->stream));
+            HIPCK(hipEventRecord(ctx->ev_up[k], ctx->stream));
+            used[k] = true;
+        }
+    }
     HIPCK(hipMemcpyAsync(ctx->in_off.p, o.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCK(hipStreamSynchronize(ctx->stream));
     return LNR_OK;
@@ -970,6 +990,7 @@ void lnr_destroy(lnr_ctx *ctx) {
     if (ctx->s_bulk[0] && ctx->s_bulk[0] != ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_bulk[0]);
     if (ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_multi[0]);
     if (ctx->s_bulk[1]) (void)hipStreamDestroy(ctx->s_bulk[1]);
+    for (int k = 0; k < 2; k++) if (ctx->ev_up[k]) (void)hipEventDestroy(ctx->ev_up[k]);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     if (ctx->ev_f1) (void)hipEventDestroy(ctx->ev_f1);
@@ -1168,15 +1189,15 @@ lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out) {
     if (!ctx || !out) return LNR_ERR_ARG;
     HIPCK(hipSetDevice(ctx->device));
     u64 tot = ctx->last_ncords;
-    ctx->h_cords_str.resize(tot);
-    ctx->h_cords_end.resize(tot);
+    if (!ctx->h_cords_str.ensure(std::max<u64>(tot * 8, 16)) || !ctx->h_cords_end.ensure(std::max<u64>(tot * 8, 16))) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
     if (ctx->h_cord_off.size() != (size_t)ctx->last_n + 1) ctx->h_cord_off.assign((size_t)ctx->last_n + 1, 0);
     if (tot) {
-        HIPCK(hipMemcpy(ctx->h_cords_str.data(), ctx->r_str.p, tot * 8, hipMemcpyDeviceToHost));
-        HIPCK(hipMemcpy(ctx->h_cords_end.data(), ctx->r_end.p, tot * 8, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpyAsync(ctx->h_cords_str.p, ctx->r_str.p, tot * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipMemcpyAsync(ctx->h_cords_end.p, ctx->r_end.p, tot * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
     }
     out->n_reads = ctx->last_n; out->n_cords = tot;
-    out->cord_off = ctx->h_cord_off.data(); out->cords_str = ctx->h_cords_str.data(); out->cords_end = ctx->h_cords_end.data();
+    out->cord_off = ctx->h_cord_off.data(); out->cords_str = ctx->h_cords_str.as<u64>(); out->cords_end = ctx->h_cords_end.as<u64>();
     return LNR_OK;
 }
 lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *off, uint32_t n, lnr_cords *out) {
