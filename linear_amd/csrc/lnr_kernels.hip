@@ -699,7 +699,7 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
 #define SORT_SMALL 32
 struct XDesc { LNR_HD bool operator()(const u64 &p, const u64 &q) const { return anchor_x(p) > anchor_x(q); } };
 
-__device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *tasks, LeaderScratch *ls /* LDS */) {
+__device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *tasks, LeaderScratch *ls /* LDS */, u64 *stage /* free LDS or null */, u32 stage_cap) {
     int lane = lane_id();
     XDesc comp;
     if (n <= SORT_SMALL) {
@@ -769,10 +769,29 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
         }
     }
     WSYNC();
-    for (u32 t = lane; t < ntasks; t += 64) {
-        u64 v = tasks[t];
-        if (v >> 63) rs_heap_sort(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), comp);
-        else rs_finish_range<16>(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)((v >> 56) & 0x7f), comp);   // ranges of <= 32 elements
+    // The deferred ranges, one per lane.  They were emitted left to right (the loop above descends into the left part and
+    // pops the adjacent right part next), so 64 consecutive tasks cover one contiguous span of at most 2048 elements: when
+    // the array lives in global memory and LDS is free, the span is staged into LDS, sorted there (the insertion sorts are
+    // chains of dependent accesses: ~100 instead of ~700 cycles each) and written back.
+    for (u32 b = 0; b < ntasks; b += 64) {
+        u32 t = b + (u32)lane;
+        bool have = t < ntasks;
+        u64 v = have ? tasks[t] : 0;
+        u32 tl = b + 63 < ntasks ? b + 63 : ntasks - 1;
+        u32 span_first = (u32)(tasks[b] & 0xfffffff), span_last = (u32)((tasks[tl] >> 28) & 0xfffffff);
+        bool heap_any = __ballot(have && (v >> 63)) != 0;
+        u32 span = span_last - span_first;
+        if (stage && !heap_any && span <= stage_cap) {
+            for (u32 i = lane; i < span; i += 64) stage[i] = a[span_first + i];
+            WSYNC();
+            if (have) rs_finish_range<16>(stage - span_first, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)((v >> 56) & 0x7f), comp);
+            WSYNC();
+            for (u32 i = lane; i < span; i += 64) a[span_first + i] = stage[i];
+            WSYNC();
+        } else if (have) {
+            if (v >> 63) rs_heap_sort(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), comp);
+            else rs_finish_range<16>(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)((v >> 56) & 0x7f), comp);   // ranges of <= 32 elements
+        }
     }
     WSYNC();
 }
@@ -1398,7 +1417,14 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
                 // scratch of the sort: position lists in the (dead) radix buffer, task list behind it
                 u32 *Lbuf = (u32 *)s_alt, *Rbuf = Lbuf + (m + 2);
                 u64 *tasks = slow.get<u64>((u64)m + 2);
-                introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, &s_ls);
+                // free LDS behind the arena's current mark can stage the final small sorts when `a` itself is in global memory
+                u64 *stg = nullptr; u32 stg_cap = 0;
+                {
+                    bool a_in_lds = (char *)a >= (char *)dyn_lds && (char *)a < (char *)dyn_lds + A.arena_lds;
+                    u64 used = (ar.off + 15) & ~15ULL;
+                    if (!a_in_lds && A.arena_lds > used + 4096) { stg = (u64 *)((char *)dyn_lds + used); stg_cap = (u32)((A.arena_lds - used) / 8); }
+                }
+                introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, &s_ls, stg, stg_cap);
             }
             LNR_TICK(prof, 15, tk_);
             ok = job_carve(ar, m, S, &s_ovf) && !slow.ovf;
