@@ -754,8 +754,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         for (u32 i = 0; i < n; i++) (in_r1[i] ? late_list : early_list).push_back(i);
         TailArgs TE;
         if ((s = tail_prepare(ctx, B, ctx->tb[2], &early_list, ctx->s_tail, TE)) != LNR_OK) return s;
-        hipLaunchKernelGGL(k_tail_b, dim3((TE.n + 63) / 64), dim3(64), 0, ctx->s_tail, TE);
-        KCHECK();
+        if (TE.n) { hipLaunchKernelGGL(k_tail_b, dim3((TE.n + 63) / 64), dim3(64), 0, ctx->s_tail, TE); KCHECK(); }   // (every read may be in the re-map round)
         HIPCK(hipEventRecord(ctx->ev_prep, ctx->s_tail));
     }
     HIPCK(hipStreamSynchronize(ctx->s_multi[0]));
@@ -772,8 +771,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     TailArgs T;
     if ((s = tail_prepare(ctx, B, ctx->tb[0], early ? &late_list : nullptr, ctx->stream, T)) != LNR_OK) return s;
     ctx->t_tail.start(ctx->stream);
-    hipLaunchKernelGGL(k_tail_b, dim3((T.n + 63) / 64), dim3(64), 0, ctx->stream, T);
-    KCHECK();
+    if (T.n) { hipLaunchKernelGGL(k_tail_b, dim3((T.n + 63) / 64), dim3(64), 0, ctx->stream, T); KCHECK(); }
     ctx->t_tail.stop(ctx->stream);
     if (early) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
     std::vector<u32> nout(n);

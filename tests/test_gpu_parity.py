@@ -158,3 +158,19 @@ def test_gpu_index_receiver_path(case_inputs):
         coff, cs, ce = recv.filter_batch(reads, off)
         assert np.array_equal(coff, g["cord_off"]) and np.array_equal(cs, g["cords_str"]) and np.array_equal(ce, g["cords_end"])
         recv.close()
+
+
+def test_gpu_every_read_in_the_remap_round(oracle_lib):
+    """A small batch in which every read goes through the re-map round (found by tools/stress_parity.py: the early tail-B
+    launch then has nothing to do and must be skipped, not launched with an empty grid)."""
+    from linear_amd import Filter, synth
+    refs = [synth.repeat_ref(400_000, 2024), synth.add_n_runs(synth.random_ref(250_000, 2025), 2026, lead=1000), synth.repeat_ref(150_000, 2027, n_families=4)]
+    f = Filter(device=0)
+    f.build_index(refs, 2)
+    o = oracle_lib.Checker("oracle", refs, 2)
+    for nreads, L, err, seed in ((12, 700, 0.15, 5), (64, 700, 0.1, 6), (8, 3000, 0.15, 7)):
+        reads, off, _ = synth.sample_reads(refs, nreads, L, err, seed, "random")
+        coff, cs, ce = f.filter_batch(reads, off)
+        ooff, ocs, oce, _ = o.map_batch(reads, off, threads=2)
+        assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
+    f.close()

@@ -15,6 +15,11 @@ from linear_amd import build as lb  # noqa: E402
 from oracle import pyorc  # noqa: E402
 
 
+OPTION_SETS = [{}, {}, {}, {"LNR_MID_CAP": "64"}, {"LNR_HEAVY_CAP": "64"}, {"LNR_DP_SPLIT_CAP": "64"}, {"LNR_SPLIT_CAP": "200"},
+               {"LNR_SPLIT_CAP": "200", "LNR_LANE_ORDER": "heavy"}, {"LNR_MID_CAP": "300", "LNR_HEAVY_CAP": "900"}, {"LNR_JOB_LDS_KB": "2"}]
+ALL_KEYS = sorted({k for o in OPTION_SETS for k in o})
+
+
 def main():
     ncfg = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -26,9 +31,9 @@ def main():
         s = int(rng.integers(1, 1 << 30))
         kind = int(rng.integers(0, 3))
         T = int(rng.choice([1, 2, 3, 4, 8]))
-        L = int(rng.choice([260, 700, 3000, 9000, 20000, 40000]))
+        L = int(rng.choice([201, 260, 700, 3000, 9000, 20000, 40000, 120000]))
         err = float(rng.choice([0.0, 0.03, 0.1, 0.15]))
-        nreads = int(rng.choice([64, 300, 1500]))
+        nreads = int(rng.choice([1, 7, 64, 300, 1500]))
         if kind == 0:
             refs = [synth.random_ref(int(rng.integers(200_000, 900_000)), s)]
         elif kind == 1:
@@ -37,6 +42,11 @@ def main():
             refs = [synth.repeat_ref(400_000, s), synth.add_n_runs(synth.random_ref(250_000, s + 1), s + 2, lead=int(rng.integers(0, 5000))),
                     synth.repeat_ref(150_000, s + 3, n_families=4)]
         reads, off, _ = synth.sample_reads(refs, nreads, L, err, s + 7, "random", len_jitter=float(rng.choice([0.0, 0.5])))
+        # library options (read at lnr_create): exercise the other size classes and orchestration modes now and then
+        opt = OPTION_SETS[int(rng.integers(0, len(OPTION_SETS)))]
+        for kv in ALL_KEYS:
+            os.environ.pop(kv, None)
+        os.environ.update(opt)
         t0 = time.time()
         o = pyorc.Checker("oracle", refs, T)
         ooff, ocs, oce, _ = o.map_batch(reads, off, threads=8)
@@ -47,7 +57,7 @@ def main():
         f.close()
         same = bool(np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce))
         bad += 0 if same else 1
-        print(f"[stress] cfg {k}: kind {kind} T {T} L {L} err {err} reads {nreads} cords {cs.size}: {'ok' if same else 'MISMATCH'} (oracle {t1 - t0:.1f}s)", flush=True)
+        print(f"[stress] cfg {k}: kind {kind} T {T} L {L} err {err} reads {nreads} opts {opt} cords {cs.size}: {'ok' if same else 'MISMATCH'} (oracle {t1 - t0:.1f}s)", flush=True)
     print(f"[stress] {ncfg - bad}/{ncfg} configurations bit-exact")
     sys.exit(1 if bad else 0)
 
