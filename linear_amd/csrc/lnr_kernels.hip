@@ -869,7 +869,9 @@ __device__ u32 filter_anchor_list_wave(u64 *a, u32 n) {
 #define DP_TILE 64
 template <int NW>
 struct DpTile {
-    long long wkey[NW > 1 ? NW : 1][DP_TILE];   // per-wave before-tile candidates (multi-wave workgroups only)
+    // multi-wave workgroups only (kept at one element otherwise: every byte of static LDS costs the single-wave kernel occupancy)
+    long long wfar[NW >= 8 ? 2 : 1][NW >= 8 ? NW : 1][NW >= 8 ? DP_TILE : 1];   // per-wave candidates from the predecessors before the previous tile (pipelined form, double buffered)
+    long long wnear[NW > 1 ? NW : 1][NW > 1 ? DP_TILE : 1];                     // ... from the previous tile itself (pipelined form) / from all predecessors (flat form)
     i32 tleaf[DP_TILE];
 };
 // j_lo(i) = min(first j with xs[j] - xs[i] < 300, max(0, i - 20)); xs is non-increasing -> binary search
@@ -1295,8 +1297,64 @@ __device__ void best_chains2_wave(const u64 *hits, const UP *sep, const i32 *sep
 
 // Workgroup form of the tiled DP for the multi-wave kernels: the before-tile chunks are dealt out over the NW waves,
 // wave 0 merges the candidates and runs the in-tile steps.  Every thread of the workgroup calls it (workgroup barriers).
+// candidates of this wave's share of ONE chunk of predecessors [top - cnt, top): the steps are dealt over the waves
+template <int ST>
+__device__ __forceinline__ i64 dp_chunk_by_steps(const u32 *xs, const u32 *ys, const i32 *score, int top, int cnt, u32 xi, u32 yi, int jl, int wave, int nw) {
+    int lane = lane_id();
+    i32 btot = -1, bj = 0;
+    int jl_ = top - 1 - lane;
+    u32 px = 0, py = 0; i32 ps = 0;
+    if (lane < cnt) { px = xs[jl_]; py = ys[jl_]; ps = score[jl_]; }
+    for (int s_ = wave; s_ < cnt; s_ += nw) {
+        u32 qx = (u32)__builtin_amdgcn_readlane((int)px, s_), qy = (u32)__builtin_amdgcn_readlane((int)py, s_);
+        i32 qs = __builtin_amdgcn_readlane(ps, s_);
+        int jj = top - 1 - s_;
+        dp_eval<ST, true>(btot, bj, qx, qy, qs, jj, xi, yi, jj >= jl);
+    }
+    return btot < 0 ? (i64)-1 : dp_key(btot, bj);
+}
+// Workgroup form of the tiled DP for the multi-wave kernels, software pipelined over the tiles: while wave 0 runs the
+// in-tile steps of tile k (the serial part), the other waves already score tile k+1 against the predecessors that lie before
+// tile k (final by then); after a barrier all waves share the one remaining chunk -- tile k itself -- by steps.  Wave 0 then
+// merges the candidates and goes on with tile k+1.  Every thread of the workgroup calls it (two barriers per tile).
 template <int NW, int ST>
 __device__ void best_chains_block_t(const u32 *xs, const u32 *ys, u32 m, Rec r, i32 *jlo, DpTile<NW> &T) {
+    int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    dp_window_bounds(xs, m, jlo, tid, NW * 64);
+    __syncthreads();
+    u32 ntiles = (m + DP_TILE - 1) / DP_TILE;
+    for (u32 k = 0; k < ntiles; k++) {
+        u32 t0 = k * DP_TILE;
+        int tn = (int)(m - t0 < DP_TILE ? m - t0 : DP_TILE);
+        bool more = k + 1 < ntiles;
+        u32 t1 = t0 + DP_TILE;                                  // next tile
+        int tn1 = more ? (int)(m - t1 < DP_TILE ? m - t1 : DP_TILE) : 0;
+        u32 x1 = 0, y1 = 0; int jl1 = 0x7fffffff;
+        if (more && lane < tn1) { x1 = xs[t1 + lane]; y1 = ys[t1 + lane]; jl1 = jlo[t1 + lane]; }
+        if (wave == 0) {
+            u32 xi = 0, yi = 0; int jl = 0x7fffffff;
+            if (lane < tn) { xi = xs[t0 + lane]; yi = ys[t0 + lane]; jl = jlo[t0 + lane]; }
+            i64 best = -1;
+            if (k > 0) {
+#pragma unroll
+                for (int w = 1; w < NW; w++) { i64 v = T.wfar[k & 1][w][lane]; best = v > best ? v : best; }
+#pragma unroll
+                for (int w = 0; w < NW; w++) { i64 v = T.wnear[w][lane]; best = v > best ? v : best; }
+            }
+            dp_in_tile_finish<ST>(T.tleaf, (int)t0, tn, xi, yi, jl, best, r);
+        } else if (more) {
+            int lo1 = __builtin_amdgcn_readfirstlane(jl1);
+            T.wfar[(k + 1) & 1][wave][lane] = dp_before_tile<ST>(xs, ys, r.score, (int)t0, lo1, x1, y1, jl1, wave - 1, NW - 1);
+        }
+        __syncthreads();   // tile k is final and visible; the far candidates of tile k+1 are stored
+        if (more) T.wnear[wave][lane] = dp_chunk_by_steps<ST>(xs, ys, r.score, (int)t0 + tn, tn, x1, y1, jl1, wave, NW);
+        __syncthreads();
+    }
+}
+// The un-pipelined form: all waves share the predecessor chunks, then wave 0 runs the in-tile steps.  Measured better for
+// the 4-wave kernel (three helper waves cannot hide the chunks behind the in-tile steps; round 0: 27.8 vs 29.0 ms).
+template <int NW, int ST>
+__device__ void best_chains_block_flat(const u32 *xs, const u32 *ys, u32 m, Rec r, i32 *jlo, DpTile<NW> &T) {
     int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     dp_window_bounds(xs, m, jlo, tid, NW * 64);
     __syncthreads();
@@ -1305,12 +1363,12 @@ __device__ void best_chains_block_t(const u32 *xs, const u32 *ys, u32 m, Rec r, 
         u32 xi = 0, yi = 0; int jl = 0x7fffffff;
         if (lane < tn) { xi = xs[t0 + lane]; yi = ys[t0 + lane]; jl = jlo[t0 + lane]; }
         int lo = __builtin_amdgcn_readfirstlane(jl);
-        T.wkey[wave][lane] = dp_before_tile<ST>(xs, ys, r.score, (int)t0, lo, xi, yi, jl, wave, NW);
+        T.wnear[wave][lane] = dp_before_tile<ST>(xs, ys, r.score, (int)t0, lo, xi, yi, jl, wave, NW);
         __syncthreads();
         if (wave == 0) {
             i64 best = -1;
 #pragma unroll
-            for (int w = 0; w < NW; w++) { i64 v = T.wkey[w][lane]; best = v > best ? v : best; }
+            for (int w = 0; w < NW; w++) { i64 v = T.wnear[w][lane]; best = v > best ? v : best; }
             dp_in_tile_finish<ST>(T.tleaf, (int)t0, tn, xi, yi, jl, best, r);
         }
         __syncthreads();
@@ -1318,8 +1376,13 @@ __device__ void best_chains_block_t(const u32 *xs, const u32 *ys, u32 m, Rec r, 
 }
 template <int NW>
 __device__ void best_chains_block(const u32 *xs, const u32 *ys, u32 m, Rec r, int score_type, i32 *jlo, DpTile<NW> &T) {
-    if (score_type) best_chains_block_t<NW, 1>(xs, ys, m, r, jlo, T);
-    else best_chains_block_t<NW, 0>(xs, ys, m, r, jlo, T);
+    if (NW >= 8) {
+        if (score_type) best_chains_block_t<NW, 1>(xs, ys, m, r, jlo, T);
+        else best_chains_block_t<NW, 0>(xs, ys, m, r, jlo, T);
+    } else {
+        if (score_type) best_chains_block_flat<NW, 1>(xs, ys, m, r, jlo, T);
+        else best_chains_block_flat<NW, 0>(xs, ys, m, r, jlo, T);
+    }
 }
 
 // Replays the allocation sequence of the pre phase (global scratch only) from the two counts it left in jstate: n1 = anchors
