@@ -100,6 +100,7 @@ struct lnr_ctx {
     u32 dp_split_cap = 0xffffffffu, dp_split_cap_r1 = 0xffffffffu;   // reads with at least this many anchors take the split path pre -> 16-wave DP -> post (LNR_DP_SPLIT_CAP, LNR_DP_SPLIT_CAP_R1)
     u32 heavy_cap_r1 = 10000, mid_cap_r1 = 4096;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
     bool lane_bulk_first = true;         // two lanes: which lane goes through the re-map round first (LNR_LANE_ORDER=heavy|bulk)
+    u32 stop_after = 0;                  // diagnostic: LNR_STOP_AFTER (see JobArgs)
     u32 prep_threads = 256;             // workgroup size of k_prep (LNR_PREP_THREADS: 64, 128 or 256)
     u32 bulk_delay_ticks = 10000;       // head start (100 MHz ticks) of the multi-wave kernels over the bulk kernel (LNR_BULK_DELAY_US)
     u32 split_cap = 0xffffffffu;               // reads with at least this many anchors form the "heavy lane": their re-map round starts
@@ -430,7 +431,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         A.cords = ctx->cords.as<u64>(); A.cords_off = ctx->cords_off.as<u64>(); A.cords_cap = ctx->cords_cap.as<u32>(); A.ncords = ctx->ncords.as<u32>();
         A.read_err = ctx->read_err.as<i32>();
         A.nbins = ctx->nbins; A.grp_lo = g0; A.grp_hi = g1;
-        A.prof = nullptr; A.tl = nullptr; A.jstate = Lx.jstate.as<u32>();
+        A.prof = nullptr; A.tl = nullptr; A.jstate = Lx.jstate.as<u32>(); A.stop_after = ctx->stop_after;
         size_t lds_min = (((size_t)((ctx->nbins + 1) / 2) * 4) + 15) & ~(size_t)15;
         size_t arena = (ctx->job_lds_bytes + 15) & ~(size_t)15;
         size_t lds = std::max<size_t>(lds_min, arena + ctx->job_stage_bytes);
@@ -569,7 +570,7 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     HIPCK(hipMemsetAsync(ctx->ncords.p, 0, (size_t)n * 4, ctx->stream));
     HIPCK(hipMemsetAsync(ctx->read_err.p, 0, (size_t)n * 4, ctx->stream));
     ctx->t_prep.start(ctx->stream);
-    hipLaunchKernelGGL(k_prep, dim3(n), dim3(ctx->prep_threads), 0, ctx->stream, d_reads, d_off, ctx->pk_off.as<u64>(), n, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
+    hipLaunchKernelGGL(k_prep, dim3((n + PREP_READS_PER_WG - 1) / PREP_READS_PER_WG), dim3(ctx->prep_threads), 0, ctx->stream, d_reads, d_off, ctx->pk_off.as<u64>(), n, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
     KCHECK();
     ctx->t_prep.stop(ctx->stream);
     ctx->stats.reads = n;
@@ -945,6 +946,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_MID_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->mid_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP")) { long v = atol(e); if (v >= 64) { ctx->dp_split_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->dp_split_cap_r1 = ctx->dp_split_cap; } }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->dp_split_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
+    if (const char *e = getenv("LNR_STOP_AFTER")) { long v = atol(e); if (v >= 0 && v < 16) ctx->stop_after = (u32)v; }
     if (const char *e = getenv("LNR_PREP_THREADS")) { long v = atol(e); if (v == 64 || v == 128 || v == 256) ctx->prep_threads = (u32)v; }
     if (const char *e = getenv("LNR_BULK_DELAY_US")) { long v = atol(e); if (v >= 0 && v <= 5000) ctx->bulk_delay_ticks = (u32)v * 100; }
     if (const char *e = getenv("LNR_LANE_ORDER")) ctx->lane_bulk_first = e[0] != 'h';

@@ -331,12 +331,8 @@ __device__ __forceinline__ u32 prep_load4(const u8 *rd, u32 L, u32 i, bool rev, 
     x &= valid * 255u;
     return x;
 }
-__global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, const u64 *pk_off, u32 n, u64 *pk, u32 *nm, i32 *read_ks) {
-    const int U = 4;                                 // loads in flight per wave
-    __shared__ u64 s_c[4][U][8];  // per wave and step in flight: 64 code bytes = 8 packed words
-    __shared__ u32 s_n[4][U][8];  // per wave and step in flight: 32 N bytes   = 8 bitmap words
-    u32 r = blockIdx.x;
-    if (r >= n) return;
+template <int U>
+__device__ __forceinline__ void prep_one_read(const u8 *src, const u64 *off, const u64 *pk_off, u32 r, u64 *pk, u32 *nm, i32 *read_ks, u64 (*s_c)[U][8], u32 (*s_n)[U][8]) {
     u64 o = off[r];
     u32 L = (u32)(off[r + 1] - o);
     u32 nw = (u32)packed_words(L);
@@ -411,6 +407,16 @@ __global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, con
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+// Several reads per workgroup: with one read per workgroup (10^5 workgroups of a few microseconds each) the kernel ran at the
+// workgroup dispatch rate, not at memory speed.
+#define PREP_READS_PER_WG 1
+__global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, const u64 *pk_off, u32 n, u64 *pk, u32 *nm, i32 *read_ks) {
+    const int U = 8;                                 // dword loads in flight per lane (the kernel is latency bound: 4 -> 8 measured)
+    __shared__ u64 s_c[4][U][8];  // per wave and step in flight: 64 code bytes = 8 packed words
+    __shared__ u32 s_n[4][U][8];  // per wave and step in flight: 32 N bytes   = 8 bitmap words
+    u32 r0 = blockIdx.x * PREP_READS_PER_WG;
+    for (u32 r = r0; r < r0 + PREP_READS_PER_WG && r < n; r++) prep_one_read<U>(src, off, pk_off, r, pk, nm, read_ks, s_c, s_n);
 }
 // read window features of both strands (createFeatures2_48 serial form, pmpfinder.cpp:556-588) from the packed strands:
 // 16-base cells are counted once into LDS, an entry is the sum of three consecutive cells.
@@ -592,6 +598,7 @@ struct JobArgs {
     u32 nbins; u32 grp_lo, grp_hi;
     u32 lds_bytes;          // dynamic LDS per block: binning histogram first, then the fast half of the job arena
     u32 arena_lds;          // bytes of that LDS the job arena may use
+    u32 stop_after;         // diagnostic (LNR_STOP_AFTER, single-wave kernel only): leave the job after phase stop_after - 1; 0 = run everything
     u32 *jstate;            // split path: per job {anchors after binning, anchors after the list filter | ok << 31} handed from the pre to the DP / post kernel
     unsigned long long *prof;   // diagnostic build (-DLNR_PROF) only: per-phase cycle sums of lane 0
     unsigned long long *tl;     // diagnostic build only: per launch position {start, end (100 MHz ticks), hw id, anchors in the DP}
@@ -1457,6 +1464,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             LNR_TICK(prof, 0, tk_);
             n = binning_wave(ag, n, dyn_lds, A.nbins);   // uses the dynamic LDS as its histogram
             LNR_TICK(prof, 1, tk_);
+            if (NW == 1 && A.stop_after == 2) break;
             // two-level arena: dynamic LDS first (re-used once binning is done), the job's global scratch behind it
             slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
             ar.init((void *)dyn_lds, A.arena_lds); ar.next = &slow;
@@ -1473,6 +1481,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
                 WSYNC();
             }
             LNR_TICK(prof, 2, tk_);
+            if (NW == 1 && A.stop_after == 3) break;
             m = n > 1 ? filter_anchor_list_wave(a, n) : n;   // filterAnchors1 (pmpfinder.cpp:2073-2091)
             WSYNC();
             LNR_TICK(prof, 14, tk_);
@@ -1490,6 +1499,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
                 introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, &s_ls, stg, stg_cap);
             }
             LNR_TICK(prof, 15, tk_);
+            if (NW == 1 && A.stop_after == 4) break;
             ok = job_carve(ar, m, S, &s_ovf) && !slow.ovf;
             if (ok) {
                 job_fill_xy(a, m, S, (u32)lane, 64);
@@ -1536,6 +1546,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             if (d.m >= 2) best_chains_block<NW>(d.xs, d.ys, d.m, d.rec, d.score_type, d.jlo, s_tile);   // ends with a workgroup barrier
         }
         LNR_TICK(prof, 4, tk_);
+        if (NW == 1 && A.stop_after == 5) break;   // after the DP
         // ---------------- post: traceback, blocks, windows (leader wave)
         if (lead) {
             AnchorSink sink; sink.anchors = a; sink.hits = &S.hits; sink.hscore = &S.hscore; sink.first_len = 0; sink.nchains = 0;
@@ -1543,6 +1554,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             WSYNC();
             if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, s_flag, &s_ls);
             LNR_TICK(prof, 5, tk_);
+            if (NW == 1 && A.stop_after == 6) break;
             JobCtx c;
             c.traceback_done = 1;
             c.L = L; c.read_str = A.J.str[j]; c.read_end = A.J.end[j]; c.mode = mode;
@@ -1559,6 +1571,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             nb = prefilter_chains2_wave(S.hits.p, S.hits.n, S.sep, nb, S.cuts, S.xy_strs, S.tmp, s_ls);
             S.sep.n = nb;
             LNR_TICK(prof, 6, tk_);
+            if (NW == 1 && A.stop_after == 7) break;
             job_blocks_scores(S, (u32)lane, 64);
             WSYNC();
             BlockScratch bsx = job_block_scratch(S, s_ls);
@@ -1576,6 +1589,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             }
             WSYNC();
             LNR_TICK(prof, 7, tk_);
+            if (NW == 1 && A.stop_after == 8) break;
             if (!s_ovf) {
                 u64 *H = s_H; u32 nH = s_nH;
                 if (nH >= 2) {
@@ -1585,6 +1599,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
                     WSYNC();
                     nH = s_nH;
                     LNR_TICK(prof, 8, tk_);
+                    if (NW == 1 && A.stop_after == 9) break;   // after filter_hits
                     path_dst_2(H, nH, c.f1, c.g, cords, c.read_str, c.read_end, L);   // SIMT-uniform: candidates evaluated by lanes 0..2
                     LNR_TICK(prof, 9, tk_);
                 }
