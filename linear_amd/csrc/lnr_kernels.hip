@@ -1578,15 +1578,18 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             if (nb >= 2) {
                 if (lane == 0) chain_blocks_prepare(S.hits.p, S.sep.p, S.sep_score, nb, 1, bsx);
                 WSYNC();
+                if (NW == 1 && A.stop_after == 10) break;
                 best_chains2_wave(S.hits.p, bsx.sep_tmp, bsx.score_tmp, nb, bsx.rec);
+                if (NW == 1 && A.stop_after == 11) break;
             }
             if (lane == 0) {
                 BlockSink bs = job_block_sink(S);
                 if (nb >= 2) chain_blocks_trace(bs, nb, bsx);
                 u64 *H = nullptr; u32 nH = 0;
-                if (job_blocks_finish(a, S, bs, nullptr, H, nH)) s_ovf = 1;
+                if (A.stop_after != 12 && job_blocks_finish(a, S, bs, nullptr, H, nH)) s_ovf = 1;
                 s_H = H; s_nH = nH;
             }
+            if (NW == 1 && A.stop_after == 12) break;
             WSYNC();
             LNR_TICK(prof, 7, tk_);
             if (NW == 1 && A.stop_after == 8) break;
