@@ -536,11 +536,9 @@ LNR_HD inline bool dp_pair_cand(u32 px, u32 py, u32 xi, u32 yi, DpPair &p) {
     if (ST) return dy >= 5 && dy < 100 && da < 100 && da < M;
     return dy >= 10 && dy < 2250 && da < M && (da < 10 || (u64)da * 7 < (u64)M);
 }
-template <int ST>
-LNR_HD inline i32 dp_pair_score(const DpPair &p) {
-    i32 dy = p.dy; u32 da = p.da, M = p.M;
-    if (ST) return 100 - dy - (da < 30 ? 0 : (i32)da);
-    u32 sdy = (u32)dy / 75u;
+// score_derr of getApxChainScore for a candidate pair (0 when da < 10): floor(100 da / M) by float estimate + exact correction
+LNR_HD inline u32 dp_pair_sderr(const DpPair &p) {
+    u32 da = p.da, M = p.M;
 #if defined(__HIP_DEVICE_COMPILE__)
     float inv = __builtin_amdgcn_rcpf((float)M);
 #else
@@ -556,8 +554,12 @@ LNR_HD inline i32 dp_pair_score(const DpPair &p) {
     u32 sd = e3;
     sd = q < 10 ? e2 : sd;
     sd = q < 5 ? e1 : sd;
-    sd = da < 10 ? 0 : sd;
-    return 100 - (i32)sdy - (i32)sd;
+    return da < 10 ? 0 : sd;
+}
+template <int ST>
+LNR_HD inline i32 dp_pair_score(const DpPair &p) {
+    if (ST) return 100 - p.dy - (p.da < 30 ? 0 : (i32)p.da);
+    return 100 - (i32)((u32)p.dy / 75u) - (i32)dp_pair_sderr(p);
 }
 
 struct Rec { i32 *score, *score2, *len, *p2, *root, *leaf; };   // ChainsRecord as SoA

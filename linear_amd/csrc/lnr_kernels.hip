@@ -901,7 +901,14 @@ __device__ __forceinline__ void dp_eval(i32 &btot, i32 &bj, u32 px, u32 py, i32 
     DpPair p;
     bool cand = dp_pair_cand<ST>(px, py, xi, yi, p) && act;
     if (__ballot(cand) == 0) return;
-    i32 sc = dp_pair_score<ST>(p);
+    i32 sc;
+    if (ST) sc = dp_pair_score<1>(p);
+    else {
+        // the division is only needed for da >= 10: neighbours on a true diagonal usually stay below that
+        u32 sd = 0;
+        if (__ballot(cand && p.da >= 10)) sd = dp_pair_sderr(p);
+        sc = 100 - (i32)((u32)p.dy / 75u) - (i32)sd;
+    }
     i32 tot = sc + ps;
     bool upd = cand && sc > 0 && (GE ? tot >= btot : tot > btot);
     btot = upd ? tot : btot;
