@@ -1492,6 +1492,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             m = n > 1 ? filter_anchor_list_wave(a, n) : n;   // filterAnchors1 (pmpfinder.cpp:2073-2091)
             WSYNC();
             LNR_TICK(prof, 14, tk_);
+            if (NW == 1 && A.stop_after == 13) break;   // after the list filter
             if (m > 1) {
                 // scratch of the sort: position lists in the (dead) radix buffer, task list behind it
                 u32 *Lbuf = (u32 *)s_alt, *Rbuf = Lbuf + (m + 2);
