@@ -841,14 +841,15 @@ __device__ u32 filter_anchor_list_wave(u64 *a, u32 n) {
             u32 thd = (mx - mn) >> 10; thd = thd < 2 ? 2 : thd;
             u32 iend = closes ? i0 + take : n - 1;                // the block is emitted as [bs, iend)
             if (cnt > thd) {
+                // forward copy in place, no ordering point needed: a chunk's loads return before its stores issue (data
+                // dependence), every store lands below the chunk it was read from (ii <= bs), and nothing read later -- the next
+                // chunks, the next blocks' anchors and their ak2 -- lies below the current block start
                 for (u32 j0 = bs; j0 < iend; j0 += 64) {
                     u32 j = j0 + (u32)lane;
                     u64 v = j < iend ? a[j] : 0;
-                    WSYNC();
                     if (j < iend) a[ii + (j - bs)] = v;
                 }
                 ii += iend - bs;
-                WSYNC();
             }
             if (!closes) break;
             bs = iend;
