@@ -998,20 +998,23 @@ __device__ void best_chains_wave(const u32 *xs, const u32 *ys, u32 m, Rec r, int
 
 // wave-parallel twin of tb0_scan_serial: first index of the maximal score (> -1), the running maximum seen before
 // it (floor -1) and the chain length there.
-__device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {   // first index of the maximal score (> -1) and the chain length there; max_2nd is left open
+// (score, first index) key of the maximal score > -1 in [lo, hi), -1 when there is none; every lane returns it
+__device__ __forceinline__ i64 tb0_range_best(const Rec &r, u32 lo, u32 hi) {
     int lane = lane_id();
     i64 best = -1;
-    for (u32 j0 = 0; j0 < n; j0 += 256) {   // four independent loads in flight per lane (the scan is latency bound)
+    for (u32 j0 = lo; j0 < hi; j0 += 256) {   // four independent loads in flight per lane (the scan is latency bound)
         int sc[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { u32 j = j0 + 64 * u + (u32)lane; sc[u] = j < n ? r.score[j] : -1; }
+        for (int u = 0; u < 4; u++) { u32 j = j0 + 64 * u + (u32)lane; sc[u] = j < hi ? r.score[j] : -1; }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             u32 j = j0 + 64 * u + (u32)lane;
             if (sc[u] > -1) { i64 key = ((i64)sc[u] << 32) | (i64)(u32)(0x7fffffff - (int)j); best = key > best ? key : best; }
         }
     }
-    best = wave_max_i64(best);
+    return wave_max_i64(best);
+}
+__device__ __forceinline__ Tb0Scan tb0_scan_result(const Rec &r, i64 best) {
     Tb0Scan s; s.max_score = -1; s.max_2nd = -1; s.max_str = -1; s.max_len = 0;
     if (best < 0) return s;
     s.max_score = (int)(best >> 32);
@@ -1019,12 +1022,15 @@ __device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {   // first index of the 
     s.max_len = r.len[s.max_str];
     return s;
 }
+__device__ Tb0Scan tb0_scan_wave(const Rec &r, u32 n) {   // first index of the maximal score (> -1) and the chain length there; max_2nd is left open
+    return tb0_scan_result(r, tb0_range_best(r, 0, n));
+}
 // maximum of the scores before index `end` (floor -1): the "second best" of traceBackChains0, needed only when a walk runs
 // into an element an earlier chain already took
-__device__ int tb0_prefix_max_wave(const Rec &r, u32 end) {
+__device__ int tb0_prefix_max_wave(const Rec &r, u32 lo, u32 end) {
     int lane = lane_id();
     i64 m2 = -1;
-    for (u32 j0 = 0; j0 < end; j0 += 256) {
+    for (u32 j0 = lo; j0 < end; j0 += 256) {
         int sc[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) { u32 j = j0 + 64 * u + (u32)lane; sc[u] = j < end ? r.score[j] : -1; }
@@ -1032,6 +1038,53 @@ __device__ int tb0_prefix_max_wave(const Rec &r, u32 end) {
         for (int u = 0; u < 4; u++) { i64 v = sc[u]; m2 = v > m2 ? v : m2; }
     }
     return (int)wave_max_i64(m2);
+}
+// Long score arrays (repeat-rich reads: 10^4 anchors, 50 searches): the scores are cut into at most 64 chunks and lane c
+// keeps an UPPER BOUND of chunk c's scores.  During traceBackChains0 a score only ever goes down -- it is set to
+// delete_score, or to score2 - score2[hit], and a later walk through the same element meets its first deleted element no
+// further down the chain than the earlier one did, where score2 is no smaller -- so a bound taken once stays valid and is
+// tightened whenever its chunk is rescanned.  A search looks at the first chunk with the largest bound; if that chunk's
+// exact maximum equals the bound, no earlier chunk can hold the same score and no chunk a larger one.
+#define TB0_CHUNKED_MIN 1024
+__device__ __forceinline__ u32 tb0_chunk_len(u32 n) { return 256u * ((n + 16383u) / 16384u); }
+__device__ i32 tb0_chunk_bounds(const Rec &r, u32 n, u32 C) {
+    int lane = lane_id();
+    i32 bound = -1;
+    u32 c = 0;
+    for (u32 lo = 0; lo < n; lo += C, c++) {
+        u32 hi = lo + C < n ? lo + C : n;
+        i32 mx = tb0_prefix_max_wave(r, lo, hi);
+        if ((u32)lane == c) bound = mx;
+    }
+    return bound;
+}
+__device__ Tb0Scan tb0_scan_chunked(const Rec &r, u32 n, u32 C, i32 &bound) {
+    int lane = lane_id();
+    for (;;) {
+        i64 top = wave_max_i64(bound > -1 ? (((i64)bound << 32) | (i64)(u32)(0x7fffffff - lane)) : (i64)-1);
+        if (top < 0) return tb0_scan_result(r, -1);
+        u32 c = (u32)(0x7fffffff - (int)(u32)(top & 0xffffffff));
+        u32 lo = c * C, hi = lo + C < n ? lo + C : n;
+        i64 best = tb0_range_best(r, lo, hi);
+        i32 t = best < 0 ? -1 : (i32)(best >> 32);
+        if ((u32)lane == c) bound = t;
+        if (t == (i32)(top >> 32)) return tb0_scan_result(r, best);
+    }
+}
+// exact maximum of the scores in [0, end) (floor -1) from the chunk bounds: the partial chunk is scanned, a whole chunk only
+// while its bound still exceeds what has been found
+__device__ int tb0_prefix_max_chunked(const Rec &r, u32 end, u32 C, i32 &bound) {
+    int lane = lane_id();
+    u32 cend = end / C;                                   // chunks [0, cend) lie wholly before `end`
+    int m2 = tb0_prefix_max_wave(r, cend * C, end);
+    for (;;) {
+        i64 top = wave_max_i64(((u32)lane < cend && bound > m2) ? (((i64)bound << 32) | (i64)(u32)lane) : (i64)-1);
+        if (top < 0) return m2;
+        u32 c = (u32)(top & 0xffffffff);
+        i32 t = tb0_prefix_max_wave(r, c * C, c * C + C);
+        if ((u32)lane == c) bound = t;
+        m2 = t > m2 ? t : m2;
+    }
 }
 // wave-parallel twin of traceback1_table: lanes over the anchors, the (<= 50) trees in LDS.  Trees are numbered by their
 // first leaf: per chunk of 64 anchors the not-yet-listed roots are appended lowest lane first.  The best leaf of a tree is
@@ -1110,8 +1163,11 @@ __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain
         // so it is computed then -- from the scores after this walk's deletions plus the largest score the walk deleted
         // (every deleted element lies before max_str), which is the value the up-front scan would have returned.
         const int delete_score = -1000;
+        const bool chunked = n > TB0_CHUNKED_MIN;
+        const u32 C = tb0_chunk_len(n);
+        i32 bound = chunked ? tb0_chunk_bounds(r, n, C) : -1;
         for (int it = 0; it < 50; it++) {
-            Tb0Scan sc = tb0_scan_wave(r, n);
+            Tb0Scan sc = chunked ? tb0_scan_chunked(r, n, C, bound) : tb0_scan_wave(r, n);
             int max_score = sc.max_score, max_str = sc.max_str, max_len = sc.max_len;
             bool f_done = max_str == -1;
             if (sink.nchains) { if ((float)max_len > (float)sink.first_len * 0.0f) f_done = false; }
@@ -1137,7 +1193,7 @@ __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain
                 int hit = s_flag[1], m_del = s_flag[2];
                 WSYNC();
                 if (hit >= 0) {
-                    int m2 = tb0_prefix_max_wave(r, (u32)max_str);
+                    int m2 = chunked ? tb0_prefix_max_chunked(r, (u32)max_str, C, bound) : tb0_prefix_max_wave(r, 0, (u32)max_str);
                     int max_2nd = m2 > m_del ? m2 : m_del;
                     int infix = r.score2[hit];
                     if (max_score - infix < max_2nd) {
