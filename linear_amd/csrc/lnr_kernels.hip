@@ -629,19 +629,31 @@ __device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 nbins) {
     }
     WSYNC();
     u32 ii = 0;
-    u64 vnext = (u32)lane < n ? a[lane] : 0;   // software pipeline: the next chunk is loaded while this one is compacted
-    for (u32 base = 0; base < n; base += 64) {
-        u32 i = base + lane;
-        u64 v = vnext;
-        vnext = i + 64 < n ? a[i + 64] : 0;
-        bool keep = false;
-        if (i < n) {
-            u32 b = (u32)(cord_x(v) / 30000);
-            if (b < nbins) { u32 w = binw[b >> 1]; keep = ((b & 1) ? (w >> 16) : (w & 0xffffu)) > 10; }
+    // software pipeline: the next 256 anchors are in flight while this group of four chunks is compacted (in place: a
+    // store lands at or below the chunk being compacted, i.e. below everything that is still to be read)
+    u64 vn[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { u32 i = 64 * u + (u32)lane; vn[u] = i < n ? a[i] : 0; }
+    for (u32 base = 0; base < n; base += 256) {
+        u64 vc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vc[u] = vn[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { u32 i = base + 256 + 64 * u + (u32)lane; vn[u] = i < n ? a[i] : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (base + 64 * u >= n) break;               // uniform
+            u32 i = base + 64 * u + (u32)lane;
+            u64 v = vc[u];
+            bool keep = false;
+            if (i < n) {
+                u32 b = (u32)(cord_x(v) / 30000);
+                if (b < nbins) { u32 w = binw[b >> 1]; keep = ((b & 1) ? (w >> 16) : (w & 0xffffu)) > 10; }
+            }
+            u64 mask = __ballot(keep);
+            if (keep) a[ii + __popcll(mask & lanemask_lt())] = v;
+            ii += (u32)__popcll(mask);
         }
-        u64 mask = __ballot(keep);
-        if (keep) a[ii + __popcll(mask & lanemask_lt())] = v;
-        ii += (u32)__popcll(mask);
     }
     WSYNC();
     return ii ? ii : n;   // nothing survives -> everything is kept (pmpfinder.cpp:2007-2010)
@@ -673,23 +685,34 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
         WSYNC();
         hist[4 * lane] = ex; hist[4 * lane + 1] = ex + c0; hist[4 * lane + 2] = ex + c0 + c1; hist[4 * lane + 3] = ex + c0 + c1 + c2;
         WSYNC();
-        u64 knext = lane < n ? src[lane] : 0;     // software pipeline: the next chunk's keys are loaded while this one is placed
-        for (u32 base = 0; base < n; base += 64) {
-            u32 i = base + lane;
-            bool valid = i < n;
-            u64 key = knext;
-            knext = i + 64 < n ? src[i + 64] : 0;
-            u32 d = (u32)(key >> shift) & 255;
-            u64 m = __ballot(valid);
-            for (int bit = 0; bit < 8; bit++) { u64 bm = __ballot((d >> bit) & 1); m &= ((d >> bit) & 1) ? bm : ~bm; }
-            u32 pos = 0;
-            if (valid) pos = hist[d] + (u32)__popcll(m & lanemask_lt());
-            WLDS();                                  // cursor reads before cursor updates (LDS only; the stores need not land)
-            if (valid) {
-                dst[pos] = key;
-                if ((m >> lane) >> 1 == 0) hist[d] += (u32)__popcll(m);   // highest lane of the digit group advances the cursor
+        // software pipeline: the next 256 keys are in flight while this group of four chunks is placed
+        u64 kn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { u32 i = 64 * u + lane; kn[u] = i < n ? src[i] : 0; }
+        for (u32 base = 0; base < n; base += 256) {
+            u64 kc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) kc[u] = kn[u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { u32 i = base + 256 + 64 * u + lane; kn[u] = i < n ? src[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (base + 64 * u >= n) break;           // uniform
+                u32 i = base + 64 * u + lane;
+                bool valid = i < n;
+                u64 key = kc[u];
+                u32 d = (u32)(key >> shift) & 255;
+                u64 m = __ballot(valid);
+                for (int bit = 0; bit < 8; bit++) { u64 bm = __ballot((d >> bit) & 1); m &= ((d >> bit) & 1) ? bm : ~bm; }
+                u32 pos = 0;
+                if (valid) pos = hist[d] + (u32)__popcll(m & lanemask_lt());
+                WLDS();                                  // cursor reads before cursor updates (LDS only; the stores need not land)
+                if (valid) {
+                    dst[pos] = key;
+                    if ((m >> lane) >> 1 == 0) hist[d] += (u32)__popcll(m);   // highest lane of the digit group advances the cursor
+                }
+                WLDS();
             }
-            WLDS();
         }
         WSYNC();                                     // the pass's stores are visible before the next pass reads them
         u64 *t = src; src = dst; dst = t;
@@ -750,16 +773,23 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
             WSYNC();
             u32 xp = (u32)anchor_x(a[first]);
             u32 lo = first + 1, nL = 0, nR = 0;
-            for (u32 base = lo; base < last; base += 64) {
-                u32 i = base + lane;
-                bool in = i < last;
-                u32 x = in ? (u32)anchor_x(a[i]) : 0;
-                bool fL = in && !(x > xp);    // !comp(a[i], p): the left scan stops here
-                bool fR = in && !(xp > x);    // !comp(p, a[i]): the right scan stops here
-                u64 mL = __ballot(fL), mR = __ballot(fR);
-                if (fL) Lbuf[nL + __popcll(mL & lanemask_lt())] = i;
-                if (fR) Rbuf[nR + __popcll(mR & lanemask_lt())] = i;
-                nL += (u32)__popcll(mL); nR += (u32)__popcll(mR);
+            for (u32 base = lo; base < last; base += 256) {   // four chunks of loads in flight (global memory for long arrays)
+                u32 xs4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { u32 i = base + 64 * u + lane; xs4[u] = i < last ? (u32)anchor_x(a[i]) : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (base + 64 * u >= last) break;       // uniform
+                    u32 i = base + 64 * u + lane;
+                    bool in = i < last;
+                    u32 x = xs4[u];
+                    bool fL = in && !(x > xp);    // !comp(a[i], p): the left scan stops here
+                    bool fR = in && !(xp > x);    // !comp(p, a[i]): the right scan stops here
+                    u64 mL = __ballot(fL), mR = __ballot(fR);
+                    if (fL) Lbuf[nL + __popcll(mL & lanemask_lt())] = i;
+                    if (fR) Rbuf[nR + __popcll(mR & lanemask_lt())] = i;
+                    nL += (u32)__popcll(mL); nR += (u32)__popcll(mR);
+                }
             }
             WSYNC();
             u32 lim = nL < nR ? nL : nR, cnt = 0;
