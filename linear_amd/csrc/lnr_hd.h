@@ -525,16 +525,32 @@ LNR_HD inline int chain_score_bl(u32 x1, u32 y1, u32 x2, u32 y2) {
 //                    score_dy = (dy / 15) / 5 = dy / 75;  da >= 10 and 7 da >= M  =>  derr >= 14  =>  score_derr >= 126
 // getApxChainScore0: score = 100 - dy - (da < 30 ? 0 : da) > 0 needs 5 <= dy < 100 and da < 100 (da >= M gives -1000)
 struct DpPair { i32 dy; u32 da, M; };
-template <int ST>
+// SORTED = the caller guarantees px >= xi (the anchor DP: predecessors come earlier in the x-descending order), which
+// spares the |dx| and makes M one three-way maximum.
+template <int ST, bool SORTED = false>
 LNR_HD inline bool dp_pair_cand(u32 px, u32 py, u32 xi, u32 yi, DpPair &p) {
     i32 dy = (i32)py - (i32)yi, dx = (i32)px - (i32)xi;
     i32 t = dx - dy;
     u32 da = (u32)(t < 0 ? -t : t);
-    u32 adx = (u32)(dx < 0 ? -dx : dx);
-    u32 M = (u32)(dy < 0 ? 0 : dy); M = M > adx ? M : adx; M = M < 50 ? 50 : M;
+    u32 M;
+    if (SORTED) { i32 m = dy > dx ? dy : dx; M = (u32)(m < 50 ? 50 : m); }      // dx >= 0: a negative dy never wins
+    else {
+        u32 adx = (u32)(dx < 0 ? -dx : dx);
+        M = (u32)(dy < 0 ? 0 : dy); M = M > adx ? M : adx; M = M < 50 ? 50 : M;
+    }
     p.dy = dy; p.da = da; p.M = M;
     if (ST) return dy >= 5 && dy < 100 && da < 100 && da < M;
-    return dy >= 10 && dy < 2250 && da < M && (da < 10 || (u64)da * 7 < (u64)M);
+    // dy in [10, 2250) && da < M && (da < 10 || 7 da < M), without the 64-bit product and without a branch: da < 10 passes
+    // (M >= 50); otherwise 7 da < M forces da < 375 -- M = max(dy, 50) < 2250 gives da < 322, M = |dx| > dy needs dx > 0 (else
+    // da = dy + |dx| > M) and 7 (dx - dy) < dx, i.e. dx < 2625 -- so da >= 512 is rejected outright and 7 da only has to be
+    // right for da < 512 (a 24-bit multiply on the GPU)
+    u32 e = da < 10 ? 0u : da;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 e7 = (u32)__umul24(e, 7u);
+#else
+    u32 e7 = (e & 0xffffffu) * 7u;
+#endif
+    return (u32)(dy - 10) < 2240u && e < 512u && e7 < M;
 }
 // score_derr of getApxChainScore for a candidate pair (0 when da < 10): floor(100 da / M) by float estimate + exact correction
 LNR_HD inline u32 dp_pair_sderr(const DpPair &p) {

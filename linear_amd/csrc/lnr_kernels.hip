@@ -964,8 +964,10 @@ __device__ __forceinline__ i64 dp_key(int total, int j) { return ((i64)total << 
 template <int ST, bool GE>
 __device__ __forceinline__ void dp_eval(i32 &btot, i32 &bj, u32 px, u32 py, i32 ps, int jj, u32 xi, u32 yi, bool act) {
     DpPair p;
-    bool cand = dp_pair_cand<ST>(px, py, xi, yi, p) && act;
+    bool cand = dp_pair_cand<ST, true>(px, py, xi, yi, p) && act;   // predecessors have the larger (or equal) x
+#ifndef LNR_DP_NOSKIP
     if (__ballot(cand) == 0) return;
+#endif
     i32 sc;
     if (ST) sc = dp_pair_score<1>(p);
     else {
@@ -988,7 +990,7 @@ __device__ __forceinline__ i64 dp_before_tile(const u32 *xs, const u32 *ys, cons
         int jl_ = top - 1 - lane;
         u32 px = 0, py = 0; i32 ps = 0;
         if (jl_ >= lo) { px = xs[jl_]; py = ys[jl_]; ps = score[jl_]; }
-        int cnt = top - lo < 64 ? top - lo : 64;
+        int cnt = __builtin_amdgcn_readfirstlane(top - lo < 64 ? top - lo : 64);   // scalar loop bound
         for (int s_ = 0; s_ < cnt; s_++) {
             u32 qx = (u32)__builtin_amdgcn_readlane((int)px, s_), qy = (u32)__builtin_amdgcn_readlane((int)py, s_);
             i32 qs = __builtin_amdgcn_readlane(ps, s_);

@@ -342,6 +342,11 @@ u64 hs_chain_score_fuzz(u64 seed, u64 n) {
             int s0 = c0 ? dp_pair_score<0>(p0) : 0, s1 = c1 ? dp_pair_score<1>(p1) : 0;
             if (l0 > 0 ? !(c0 && s0 == l0) : (c0 && s0 > 0)) bad++;
             if (l1 > 0 ? !(c1 && s1 == l1) : (c1 && s1 > 0)) bad++;
+            if (x1 >= x2) {   // the form for x-sorted predecessors (dx >= 0) must agree with the general one
+                DpPair q0, q1;
+                bool d0 = dp_pair_cand<0, true>(x1, y1, x2, y2, q0), d1 = dp_pair_cand<1, true>(x1, y1, x2, y2, q1);
+                if (d0 != c0 || d1 != c1 || q0.M != p0.M || q0.da != p0.da || q0.dy != p0.dy || q1.M != p1.M) bad++;
+            }
         }
     }
     return bad;
