@@ -763,6 +763,9 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
 #define SORT_SMALL 32
 struct XDesc { LNR_HD bool operator()(const u64 &p, const u64 &q) const { return anchor_x(p) > anchor_x(q); } };
 
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+}
 __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *tasks, LeaderScratch *ls /* LDS */, u64 *stage /* free LDS or null */, u32 stage_cap) {
     int lane = lane_id();
     XDesc comp;
@@ -780,7 +783,7 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
     u32 ntasks = 0;
     while (sp > 0) {
         --sp;
-        WSYNC();
+        WLDS();   // the stack is in LDS; the array itself was ordered by the WSYNC that ended the previous partition
         u32 first = (u32)stk_first[sp], last = (u32)stk_last[sp];
         int depth = stk_depth[sp];
         while (true) {
@@ -796,16 +799,18 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
                 break;
             }
             --depth;
-            if (lane == 0) {   // __move_median_to_first(first, first+1, mid, last-1)
-                u32 A = first + 1, B = first + (last - first) / 2, C = last - 1;
-                u64 va = a[A], vb = a[B], vc = a[C];
-                u32 pick;
-                if (comp(va, vb)) pick = comp(vb, vc) ? B : (comp(va, vc) ? C : A);
-                else pick = comp(va, vc) ? A : (comp(vb, vc) ? C : B);
-                u64 t = a[first]; a[first] = a[pick]; a[pick] = t;
-            }
-            WSYNC();
-            u32 xp = (u32)anchor_x(a[first]);
+            // __move_median_to_first(first, first+1, mid, last-1): the four elements are loaded by four lanes at once and the
+            // scan below does not wait for the swap's stores -- it knows what a[pick] holds
+            u32 iA = first + 1, iB = first + (last - first) / 2, iC = last - 1;
+            u64 v4 = 0;
+            if (lane < 4) v4 = a[lane == 0 ? iA : lane == 1 ? iB : lane == 2 ? iC : first];
+            u64 va = readlane_u64(v4, 0), vb = readlane_u64(v4, 1), vc = readlane_u64(v4, 2), vf = readlane_u64(v4, 3);
+            u32 pick;
+            if (comp(va, vb)) pick = comp(vb, vc) ? iB : (comp(va, vc) ? iC : iA);
+            else pick = comp(va, vc) ? iA : (comp(vb, vc) ? iC : iB);
+            u64 vp = pick == iA ? va : (pick == iB ? vb : vc);
+            if (lane == 0) { a[first] = vp; a[pick] = vf; }
+            u32 xp = (u32)anchor_x(vp), xf = (u32)anchor_x(vf);
             u32 lo = first + 1, nL = 0, nR = 0;
             for (u32 base = lo; base < last; base += 256) {   // four chunks of loads in flight (global memory for long arrays)
                 u32 xs4[4];
@@ -816,7 +821,7 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
                     if (base + 64 * u >= last) break;       // uniform
                     u32 i = base + 64 * u + lane;
                     bool in = i < last;
-                    u32 x = xs4[u];
+                    u32 x = i == pick ? xf : xs4[u];
                     bool fL = in && !(x > xp);    // !comp(a[i], p): the left scan stops here
                     bool fR = in && !(xp > x);    // !comp(p, a[i]): the right scan stops here
                     u64 mL = __ballot(fL), mR = __ballot(fR);
@@ -1044,6 +1049,7 @@ __device__ __forceinline__ void dp_in_tile_finish(i32 *tleaf, int t0, int tn, u3
 template <int ST>
 __device__ void best_chains_wave_t(const u32 *xs, const u32 *ys, u32 m, Rec r, i32 *jlo, i32 *tleaf) {
     int lane = lane_id();
+    m = (u32)__builtin_amdgcn_readfirstlane((int)m);   // uniform: tile bounds and loop counts stay in scalar registers
     dp_window_bounds(xs, m, jlo, lane, 64);
     WSYNC();
     for (u32 t0 = 0; t0 < m; t0 += DP_TILE) {
@@ -1109,8 +1115,10 @@ __device__ int tb0_prefix_max_wave(const Rec &r, u32 lo, u32 end) {
 // keeps an UPPER BOUND of chunk c's scores.  During traceBackChains0 a score only ever goes down -- it is set to
 // delete_score, or to score2 - score2[hit], and a later walk through the same element meets its first deleted element no
 // further down the chain than the earlier one did, where score2 is no smaller -- so a bound taken once stays valid and is
-// tightened whenever its chunk is rescanned.  A search looks at the first chunk with the largest bound; if that chunk's
-// exact maximum equals the bound, no earlier chunk can hold the same score and no chunk a larger one.
+// tightened whenever its chunk is rescanned -- except by a rescan made while a walk's elements are provisionally deleted
+// (the second-best scan below): those bounds are only kept when the chain is accepted.  A search looks at the first chunk
+// with the largest bound; if that chunk's exact maximum equals the bound, no earlier chunk can hold the same score and no
+// chunk a larger one.
 #define TB0_CHUNKED_MIN 1024
 __device__ __forceinline__ u32 tb0_chunk_len(u32 n) { return 256u * ((n + 16383u) / 16384u); }
 __device__ i32 tb0_chunk_bounds(const Rec &r, u32 n, u32 C) {
@@ -1259,14 +1267,17 @@ __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain
                 int hit = s_flag[1], m_del = s_flag[2];
                 WSYNC();
                 if (hit >= 0) {
-                    int m2 = chunked ? tb0_prefix_max_chunked(r, (u32)max_str, C, bound) : tb0_prefix_max_wave(r, 0, (u32)max_str);
+                    // the bounds this scan tightens see the walk's elements as deleted: they only become the lane's bounds when
+                    // the chain is accepted -- a rejected walk puts (smaller) scores back
+                    i32 b2 = bound;
+                    int m2 = chunked ? tb0_prefix_max_chunked(r, (u32)max_str, C, b2) : tb0_prefix_max_wave(r, 0, (u32)max_str);
                     int max_2nd = m2 > m_del ? m2 : m_del;
                     int infix = r.score2[hit];
                     if (max_score - infix < max_2nd) {
                         if (lane == 0) for (int k = max_str; k != hit; k = r.p2[k]) r.score[k] = r.score2[k] - infix;
                         cn = 0;
                         WSYNC();
-                    }
+                    } else bound = b2;
                 }
                 if (cn) emit_chain_wave(sink, r, chain, cn);
             }

@@ -174,3 +174,20 @@ def test_gpu_every_read_in_the_remap_round(oracle_lib):
         ooff, ocs, oce, _ = o.map_batch(reads, off, threads=2)
         assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
     f.close()
+
+
+def test_gpu_traceback_of_long_score_arrays_with_rejected_chains(oracle_lib):
+    """Repeat-rich reference, 1500 reads: reads with more than 1024 anchors in the chaining DP take the chunk-bound search
+    of the anchor traceback, and many of their walks are rejected and put scores back (found by tools/stress_parity.py,
+    seed 4242 configuration 110: bounds tightened while a walk's elements were provisionally deleted went stale)."""
+    from linear_amd import Filter, synth
+    s = 229311090
+    refs = [synth.repeat_ref(843667, s, n_families=6)]
+    reads, off, _ = synth.sample_reads(refs, 1500, 9000, 0.03, s + 7, "random", len_jitter=0.0)
+    f = Filter(device=0)
+    f.build_index(refs, 3)
+    coff, cs, ce = f.filter_batch(reads, off)
+    f.close()
+    o = oracle_lib.Checker("oracle", refs, 3)
+    ooff, ocs, oce, _ = o.map_batch(reads, off, threads=8)
+    assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity stress on the GPU box: many small configurations (reference type, index layout, read length, error
 rate, N runs, several sequences), HIP path through the C ABI against the CPU oracle, bit-exact.  Not part of the test
-suites (it takes minutes); run as  python tools/stress_parity.py [n_configs] [seed]."""
+suites (it takes minutes); run as  python tools/stress_parity.py [n_configs] [seed].
+LNR_STRESS_ONLY=3,17 re-runs just those configurations of the sequence; LNR_STRESS_LIBS=a.so,b.so checks each of them with
+several builds of the library (bisecting a mismatch)."""
 import os
 import sys
 import time
@@ -27,6 +29,8 @@ def main():
     pyorc.build(ref=False)
     rng = np.random.default_rng(seed0)
     bad = 0
+    only = {int(x) for x in os.environ.get("LNR_STRESS_ONLY", "").split(",") if x}
+    libs = [x for x in os.environ.get("LNR_STRESS_LIBS", "").split(",") if x]
     for k in range(ncfg):
         s = int(rng.integers(1, 1 << 30))
         kind = int(rng.integers(0, 3))
@@ -41,9 +45,12 @@ def main():
         else:
             refs = [synth.repeat_ref(400_000, s), synth.add_n_runs(synth.random_ref(250_000, s + 1), s + 2, lead=int(rng.integers(0, 5000))),
                     synth.repeat_ref(150_000, s + 3, n_families=4)]
-        reads, off, _ = synth.sample_reads(refs, nreads, L, err, s + 7, "random", len_jitter=float(rng.choice([0.0, 0.5])))
+        jitter = float(rng.choice([0.0, 0.5]))
         # library options (read at lnr_create): exercise the other size classes and orchestration modes now and then
         opt = OPTION_SETS[int(rng.integers(0, len(OPTION_SETS)))]
+        if only and k not in only:
+            continue
+        reads, off, _ = synth.sample_reads(refs, nreads, L, err, s + 7, "random", len_jitter=jitter)
         for kv in ALL_KEYS:
             os.environ.pop(kv, None)
         os.environ.update(opt)
@@ -51,6 +58,20 @@ def main():
         o = pyorc.Checker("oracle", refs, T)
         ooff, ocs, oce, _ = o.map_batch(reads, off, threads=8)
         t1 = time.time()
+        for lib in libs:
+            from linear_amd import api
+            api.SO = os.path.abspath(lib)
+            f = Filter(device=0)
+            f.build_index(refs, T)
+            coff, cs, ce = f.filter_batch(reads, off)
+            f.close()
+            same = bool(np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce))
+            nd = -1
+            if not same and np.array_equal(coff, ooff):
+                d = np.nonzero((cs != ocs) | (ce != oce))[0]
+                rd = np.unique(np.searchsorted(ooff, d, side="right") - 1)
+                nd = len(rd)
+            print(f"[stress] cfg {k} lib {lib}: {'ok' if same else 'MISMATCH'} (reads differing: {nd})", flush=True)
         f = Filter(device=0)
         f.build_index(refs, T)
         coff, cs, ce = f.filter_batch(reads, off)
@@ -58,7 +79,8 @@ def main():
         same = bool(np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce))
         bad += 0 if same else 1
         print(f"[stress] cfg {k}: kind {kind} T {T} L {L} err {err} reads {nreads} opts {opt} cords {cs.size}: {'ok' if same else 'MISMATCH'} (oracle {t1 - t0:.1f}s)", flush=True)
-    print(f"[stress] {ncfg - bad}/{ncfg} configurations bit-exact")
+    nrun = len(only) if only else ncfg
+    print(f"[stress] {nrun - bad}/{nrun} configurations bit-exact")
     sys.exit(1 if bad else 0)
 
 
