@@ -102,6 +102,7 @@ struct lnr_ctx {
     bool lane_bulk_first = true;         // two lanes: which lane goes through the re-map round first (LNR_LANE_ORDER=heavy|bulk)
     u32 stop_after = 0;                  // diagnostic: LNR_STOP_AFTER (see JobArgs)
     u32 prep_threads = 256;             // workgroup size of k_prep (LNR_PREP_THREADS: 64, 128 or 256)
+    u32 prep_grid = 4096;               // workgroups of k_prep (LNR_PREP_GRID): they loop over the reads
     u32 bulk_delay_ticks = 10000;       // head start (100 MHz ticks) of the multi-wave kernels over the bulk kernel (LNR_BULK_DELAY_US)
     u32 split_cap = 0xffffffffu;               // reads with at least this many anchors form the "heavy lane": their re-map round starts
                                         // while the bulk of the batch is still in round 0 (LNR_SPLIT_CAP; 0xffffffff = one lane)
@@ -570,7 +571,7 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
     HIPCK(hipMemsetAsync(ctx->ncords.p, 0, (size_t)n * 4, ctx->stream));
     HIPCK(hipMemsetAsync(ctx->read_err.p, 0, (size_t)n * 4, ctx->stream));
     ctx->t_prep.start(ctx->stream);
-    hipLaunchKernelGGL(k_prep, dim3((n + PREP_READS_PER_WG - 1) / PREP_READS_PER_WG), dim3(ctx->prep_threads), 0, ctx->stream, d_reads, d_off, ctx->pk_off.as<u64>(), n, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
+    hipLaunchKernelGGL(k_prep, dim3(n < ctx->prep_grid ? n : ctx->prep_grid), dim3(ctx->prep_threads), 0, ctx->stream, d_reads, d_off, ctx->pk_off.as<u64>(), n, ctx->pk.as<u64>(), ctx->nm.as<u32>(), ctx->rks.as<i32>());
     KCHECK();
     ctx->t_prep.stop(ctx->stream);
     ctx->stats.reads = n;
@@ -895,6 +896,32 @@ lnr_status stage_reads(lnr_ctx *ctx, const u8 *reads, const u64 *off, u32 n) {
 }  // namespace
 
 // ======================================================================= C ABI ====
+// diagnostic (LNR_PREP_DIAG): k_prep on private synthetic buffers, timed with events -- where in the life of the process does it slow down?
+static void prep_selftest(const char *tag, const void *src_override = nullptr, u32 n_override = 0) {
+    if (!getenv("LNR_PREP_DIAG")) return;
+    const u32 n = 100000, L = 10000;
+    static void *src = nullptr, *off = nullptr, *po = nullptr, *pk = nullptr, *nm = nullptr, *ks = nullptr;
+    if (!src) {
+        std::vector<u64> h_off(n + 1), h_po(n + 1); u64 p = 0;
+        for (u32 i = 0; i <= n; i++) { h_off[i] = (u64)i * L; h_po[i] = p; p += 2 * packed_words(L); }
+        (void)hipMalloc(&src, (size_t)n * L + 64); (void)hipMalloc(&off, (n + 1) * 8); (void)hipMalloc(&po, (n + 1) * 8); (void)hipMalloc(&pk, p * 8); (void)hipMalloc(&nm, p * 4); (void)hipMalloc(&ks, n * 4);
+        (void)hipMemset(src, 2, (size_t)n * L + 64);
+        (void)hipMemcpy(off, h_off.data(), (n + 1) * 8, hipMemcpyHostToDevice); (void)hipMemcpy(po, h_po.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+    }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    const void *use_src = src_override ? src_override : src;
+    u32 use_n = n_override ? (n_override < n ? n_override : n) : n;
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_prep, dim3(use_n), dim3(256), 0, 0, (const u8 *)use_src, (const u64 *)off, (const u64 *)po, use_n, (u64 *)pk, (u32 *)nm, (i32 *)ks);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    fprintf(stderr, "[lnr] k_prep selftest %-28s %.3f ms\n", tag, best);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+}
+
 extern "C" {
 
 void lnr_opts_default(lnr_opts *o) {
@@ -947,6 +974,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_DP_SPLIT_CAP")) { long v = atol(e); if (v >= 64) { ctx->dp_split_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->dp_split_cap_r1 = ctx->dp_split_cap; } }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->dp_split_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_STOP_AFTER")) { long v = atol(e); if (v >= 0 && v < 16) ctx->stop_after = (u32)v; }
+    if (const char *e = getenv("LNR_PREP_GRID")) { long v = atol(e); if (v > 0) ctx->prep_grid = (u32)v; }
     if (const char *e = getenv("LNR_PREP_THREADS")) { long v = atol(e); if (v == 64 || v == 128 || v == 256) ctx->prep_threads = (u32)v; }
     if (const char *e = getenv("LNR_BULK_DELAY_US")) { long v = atol(e); if (v >= 0 && v <= 5000) ctx->bulk_delay_ticks = (u32)v * 100; }
     if (const char *e = getenv("LNR_LANE_ORDER")) ctx->lane_bulk_first = e[0] != 'h';
@@ -968,6 +996,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (!ok) { lnr_destroy(ctx); return LNR_ERR_HIP; }
     ctx->t_prep.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();
     *out = ctx;
+    prep_selftest("end of lnr_create");
     return LNR_OK;
 }
 
@@ -999,6 +1028,7 @@ void lnr_destroy(lnr_ctx *ctx) {
 }
 
 lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64_t *len, uint32_t nseq, uint32_t T) {
+    prep_selftest("start of lnr_index_build");
     if (!ctx) return LNR_ERR_ARG;
     if (!seq || !len || nseq == 0) { ctx->err = "null/empty sequence set"; return LNR_ERR_ARG; }
     if (nseq >= 1024) { ctx->err = "at most 1023 reference sequences (cord id field; linear.cpp:107)"; return LNR_ERR_LIMIT; }
@@ -1183,7 +1213,10 @@ lnr_status lnr_index_adopt(lnr_ctx *ctx) {
 lnr_status lnr_filter_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_off, uint32_t n, lnr_cords_dev *out) {
     if (!ctx || !d_off || (n && !d_reads)) return LNR_ERR_ARG;
     HIPCK(hipSetDevice(ctx->device));
-    return filter_dev(ctx, d_reads, d_off, n, out);
+    prep_selftest("before filter_dev");
+    lnr_status st_ = filter_dev(ctx, d_reads, d_off, n, out);
+    prep_selftest("after filter_dev");
+    return st_;
 }
 lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out) {
     if (!ctx || !out) return LNR_ERR_ARG;
@@ -1206,7 +1239,11 @@ lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *
     if (!ctx->has_index) { ctx->err = "no index"; return LNR_ERR_NO_INDEX; }
     lnr_status s = stage_reads(ctx, reads, off, n);
     if (s != LNR_OK) return s;
+    prep_selftest("before filter_dev (host entry)");
     if ((s = filter_dev(ctx, ctx->in_reads.as<u8>(), ctx->in_off.as<u64>(), n, nullptr)) != LNR_OK) return s;
+    prep_selftest("after filter_dev (host entry)");
+    prep_selftest("same, synthetic, n reads", nullptr, n);
+    prep_selftest("same, the caller's reads", ctx->in_reads.p, n);
     return lnr_cords_to_host(ctx, out);
 }
 

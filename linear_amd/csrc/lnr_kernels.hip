@@ -342,115 +342,148 @@ __global__ void __launch_bounds__(256) k_f2(const u8 *g, const u64 *seq_off, con
 // ================================================================ read prep ====
 // Per read: both strands 2-bit packed + N bitmaps (the reverse complement is _compltRvseStr, base.cpp:335-344) and the
 // N-skip hashInit would take at the read start.  Packed layout per read: [forward words | reverse-complement words],
-// packed_words(L) each (slack words zero).  One workgroup per read.  A lane takes 4 bases with one (unaligned) dword
-// load and folds them to 8 code bits + 4 N bits with SWAR arithmetic; a wave step covers 256 bases = 8 packed words,
-// transposed through 96 bytes of LDS so that the global stores are whole words.
-__device__ __forceinline__ u32 prep_load4(const u8 *rd, u32 L, u32 i, bool rev, u32 &valid) {
-    // strand positions i .. i+3 as bytes 0..3 (0 behind the end).  One dword load whatever the position: near the end the
-    // load window is clamped into the read and the result shifted, so there is no byte loop and no branch to wait in.
-    // (L >= 4; shorter reads take the serial path of k_prep.)  No branch at all: a lane behind the end loads the first
-    // dword of the read and masks it away, so the loads of several steps can be in flight together.
-    bool in = i < L;
-    u32 ii = in ? i : 0;
-    u32 want = rev ? L - 4 - ii : ii;               // forward address of the window (may run off the read)
-    u32 f = rev ? ((i32)want < 0 ? 0u : want) : (want > L - 4 ? L - 4 : want);
-    u32 d = rev ? f - want : want - f;              // bytes the window was moved by (<= 3)
-    u32 x;
-    __builtin_memcpy(&x, rd + f, 4);
-    x = rev ? __builtin_bswap32(x) : x;
-    x >>= 8 * d;
-    u32 nv = L - ii < 4 ? L - ii : 4;
-    valid = 0x01010101u & (nv == 4 ? 0xFFFFFFFFu : (1u << (8 * nv)) - 1u);
-    valid = in ? valid : 0;
-    x &= valid * 255u;
-    return x;
-}
-template <int U>
-__device__ __forceinline__ void prep_one_read(const u8 *src, const u64 *off, const u64 *pk_off, u32 r, u64 *pk, u32 *nm, i32 *read_ks, u64 (*s_c)[U][8], u32 (*s_n)[U][8]) {
-    u64 o = off[r];
-    u32 L = (u32)(off[r + 1] - o);
-    u32 nw = (u32)packed_words(L);
-    const u8 *rd = src + o;
-    u64 *pw = pk + pk_off[r];
-    u32 *nw_ = nm + pk_off[r];
-    int lane = lane_id();
-    u32 wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    if (L < 4) {                                     // degenerate read: one thread, literal form
-        if (threadIdx.x == 0) {
-            for (u32 w = 0; w < 2 * nw; w++) { pw[w] = 0; nw_[w] = 0; }
-            for (u32 sd = 0; sd < 2; sd++)
-                for (u32 i = 0; i < L; i++) {
-                    u32 a = rd[sd ? L - 1 - i : i];
-                    a = a > 4 ? 4 : a;
-                    if (a == 4) nw_[sd * nw] |= 1u << i; else pw[sd * nw] |= (u64)(sd ? 3 - a : a) << (2 * i);
-                }
-            PackedSeq fwd; fwd.pk = pw; fwd.nm = nw_; fwd.L = L;
-            read_ks[r] = shape_init_skip(fwd);
-        }
-        return;
+// packed_words(L) each (slack words zero).  A lane takes 16 strand positions: one 16-byte load (unaligned; for the reverse
+// strand the window is read forwards and byte-reversed in registers), SWAR arithmetic folds the four dwords into 32 code
+// bits + 16 N bits, and every lane stores its half word and its 16 bitmap bits -- consecutive lanes, consecutive addresses.
+// Only the one window per strand that straddles the end of the read is assembled byte by byte.
+__device__ __forceinline__ void prep_fold16(const u32 *x, bool rev, u32 vmask /* 0x01 per valid byte, same for the 4 dwords unless partial */,
+                                            const u32 *vm4 /* per-dword masks or null */, u32 &codes, u32 &nbits) {
+    codes = 0; nbits = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        u32 v = x[q];
+        u32 vm = vm4 ? vm4[q] : vmask;
+        u32 y = v & 0xFCFCFCFCu;                                           // ordinal > 3 -> N (values above 4 are clamped to N)
+        u32 n01 = ((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) >> 7) & 0x01010101u;
+        u32 t = v & 0x03030303u;
+        if (rev) t ^= vm * 3u;                                             // complement, not behind the end
+        t &= ~(n01 * 255u);
+        u32 c8 = (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
+        u32 n4 = (n01 | (n01 >> 7) | (n01 >> 14) | (n01 >> 21)) & 0xFu;
+        codes |= c8 << (8 * q); nbits |= n4 << (4 * q);
     }
-    u32 nstep = (nw + 7) >> 3;                       // steps per strand (8 words each)
-    for (u32 st0 = wave * U; st0 < 2 * nstep; st0 += nwaves * U) {
-        u32 xv[U], vv[U];
+}
+// Strand positions 16 g .. 16 g + 15 of strand `rev` (g may lie wholly behind the end: zeros).  Two halves so that a lane
+// can have the loads of several groups in flight: the address computation has no branch (a group behind the end loads the
+// first window of the read and is masked away; the window that straddles the end is moved back inside the read and shifted
+// down in registers -- a byte loop there would be a chain of dependent loads).  Reads of at least 16 bases.
+struct PrepGroup { u32 d[4]; u32 cnt; };
+__device__ __forceinline__ void prep_group_load(const u8 *rd, u32 L, u32 g, bool rev, bool live, PrepGroup &p) {
+    u32 i = 16 * g;
+    bool in = live && i < L;
+    u32 cnt = in ? (L - i < 16 ? L - i : 16) : 0;
+    u32 sh = in ? 16 - cnt : 0;                          // bytes the window is moved by (0: the common case)
+    u32 a = in ? (rev ? L - 16 - i + sh : i - sh) : 0;
+    __builtin_memcpy(p.d, rd + a, 16);
+    p.cnt = cnt;
+}
+__device__ __forceinline__ void prep_group_fold(const PrepGroup &p, bool rev, u32 &codes, u32 &nbits) {
+    u32 x[4];
+    if (rev) { x[0] = __builtin_bswap32(p.d[3]); x[1] = __builtin_bswap32(p.d[2]); x[2] = __builtin_bswap32(p.d[1]); x[3] = __builtin_bswap32(p.d[0]); }
+    else { x[0] = p.d[0]; x[1] = p.d[1]; x[2] = p.d[2]; x[3] = p.d[3]; }
+    if (p.cnt == 16) { prep_fold16(x, rev, 0x01010101u, nullptr, codes, nbits); return; }
+    codes = 0; nbits = 0;
+    if (p.cnt == 0) return;
+    u64 lo = x[0] | ((u64)x[1] << 32), hi = x[2] | ((u64)x[3] << 32);
+    u32 b = 8 * (16 - p.cnt);                            // 8 .. 120
+    if (b >= 64) { lo = hi >> (b - 64); hi = 0; } else { lo = (lo >> b) | (hi << (64 - b)); hi >>= b; }
+    x[0] = (u32)lo; x[1] = (u32)(lo >> 32); x[2] = (u32)hi; x[3] = (u32)(hi >> 32);
+    u32 vm[4];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            u32 st = st0 + u;
-            bool rev = st >= nstep;
-            u32 i = 256 * (rev ? st - nstep : st) + 4 * (u32)lane;   // first of this lane's 4 strand positions
-            i = st < 2 * nstep ? i : L;                               // a step past the end loads nothing useful (masked)
-            xv[u] = prep_load4(rd, L, i, rev, vv[u]);
-        }
+    for (int q = 0; q < 4; q++) {
+        u32 c = p.cnt > 4u * q ? p.cnt - 4u * q : 0; c = c > 4 ? 4 : c;
+        vm[q] = 0x01010101u & (c == 4 ? 0xFFFFFFFFu : (1u << (8 * c)) - 1u);
+        x[q] &= vm[q] * 255u;
+    }
+    prep_fold16(x, rev, 0, vm, codes, nbits);
+}
+// reads shorter than one window: byte by byte
+__device__ __forceinline__ void prep_group_short(const u8 *rd, u32 L, u32 g, bool rev, u32 &codes, u32 &nbits) {
+    codes = 0; nbits = 0;
+    u32 i = 16 * g;
+    if (i >= L) return;
+    u32 x[4] = {0, 0, 0, 0}, vm[4] = {0, 0, 0, 0};
+    for (u32 k = 0; i + k < L && k < 16; k++) {
+        u32 b = rd[rev ? L - 1 - (i + k) : i + k];
+        x[k >> 2] |= b << (8 * (k & 3)); vm[k >> 2] |= 1u << (8 * (k & 3));
+    }
+    prep_fold16(x, rev, 0, vm, codes, nbits);
+}
+// N-skip of hashInit at the read start (shape_init_skip: the first position that begins 21 consecutive non-N bases; positions
+// behind the end count as non-N) by a whole wave: 62 x 16 start positions per step, each lane looking at its own 16 N bits and
+// the 20 that follow.  A read that begins inside a long N run would otherwise have one lane walk it byte by byte -- 10^4
+// dependent loads, milliseconds during which the kernel cannot end.  L >= 16, all 64 lanes active.
+__device__ int prep_nskip_wave(const u8 *rd, u32 L) {
+    int lane = lane_id();
+    for (u32 base = 0;; base += 62 * 16) {
+        PrepGroup pg;
+        prep_group_load(rd, L, base / 16 + (u32)lane, false, true, pg);
+        u32 c, nb;
+        prep_group_fold(pg, false, c, nb);
+        (void)c;
+        u32 n1 = (u32)__shfl_down((int)nb, 1), n2 = (u32)__shfl_down((int)nb, 2);
+        u64 z = ~((u64)nb | ((u64)n1 << 16) | ((u64)(n2 & 0xFu) << 32));             // 1 = not N, 36 positions
+        u64 r2 = z & (z >> 1), r4 = r2 & (r2 >> 2), r8 = r4 & (r4 >> 4), r16 = r8 & (r8 >> 8);
+        u32 m = (u32)(r16 & (r4 >> 16) & (z >> 20)) & 0xFFFFu;                        // bit s: positions s .. s+20 are all non-N
+        u32 P = (lane < 62 && m) ? base + 16u * (u32)lane + (u32)__builtin_ctz(m) : 0xFFFFFFFFu;
+        P = wave_min_u32(P);
+        if (P != 0xFFFFFFFFu) return (int)P;
+    }
+}
+#define PREP_UNROLL 4
+__global__ void __launch_bounds__(256) k_prep(const u8 *__restrict__ src, const u64 *__restrict__ off, const u64 *__restrict__ pk_off, u32 n, u64 *__restrict__ pk, u32 *__restrict__ nm, i32 *__restrict__ read_ks) {
+    for (u32 r = blockIdx.x; r < n; r += gridDim.x) {     // one read per workgroup by default (LNR_PREP_GRID); fewer workgroups loop
+        u64 o = off[r];
+        u32 L = (u32)(off[r + 1] - o);
+        u32 nw = (u32)packed_words(L);
+        const u8 *rd = src + o;
+        u64 *pk64 = pk + pk_off[r];
+        u32 *nm32 = nm + pk_off[r];
+        u32 G = 2 * nw;                                   // groups of 16 positions per strand (slack included: zeros)
+        for (u32 t0 = threadIdx.x; t0 < 2 * G; t0 += PREP_UNROLL * blockDim.x) {
+            u32 codes[PREP_UNROLL], nbits[PREP_UNROLL];
+            if (L >= 16) {
+                PrepGroup pg[PREP_UNROLL];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            bool rev = st0 + u >= nstep;
-            u32 x = xv[u];
-            u32 y = x & 0xFCFCFCFCu;                                           // ordinal > 3 -> N (values above 4 are clamped to N)
-            u32 n01 = ((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) >> 7) & 0x01010101u;
-            u32 t = x & 0x03030303u;
-            if (rev) t ^= 0x03030303u & (vv[u] * 3u);                          // complement, not behind the end
-            t &= ~(n01 * 255u);
-            u32 c8 = (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
-            u32 n4 = (n01 | (n01 >> 7) | (n01 >> 14) | (n01 >> 21)) & 0xFu;
-            u32 n8 = n4 | ((u32)__shfl_down((int)n4, 1) << 4);
-            ((u8 *)s_c[wave][u])[lane] = (u8)c8;
-            if (!(lane & 1)) ((u8 *)s_n[wave][u])[lane >> 1] = (u8)n8;
-        }
-        // LDS is in order within a wave: only the compiler must not move the reads above the writes, and the previous
-        // iteration's reads must have returned before these writes (they have: their values were stored already)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (st0 == 0 && lane == 0) {                 // wave 0, forward step 0: the first 32 bases' N bits are in s_n[0][0][0]
-            // no N among the first 21 bases: hashInit skips nothing; otherwise the serial walk, straight from the caller's bytes
-            // (no other wave's output is needed, so the workgroup never synchronises)
-            ByteSeq bs; bs.p = rd; bs.L = L;
-            read_ks[r] = (s_n[0][0][0] & 0x1FFFFFu) ? shape_init_skip(bs) : 0;
-        }
-        {   // the U steps are consecutive: 8 U packed words (and bitmap words) leave in one store instruction each
-            int u = lane >> 3, w = lane & 7;
-            u32 st = st0 + (u32)u;
-            if (lane < 8 * U && st < 2 * nstep) {
-                bool rev = st >= nstep;
-                u32 wi = 8 * (rev ? st - nstep : st) + (u32)w;
-                if (wi < nw) {
-                    u32 base = rev ? nw : 0;
-                    pw[base + wi] = s_c[wave][u][w];
-                    nw_[base + wi] = s_n[wave][u][w];
+                for (int u = 0; u < PREP_UNROLL; u++) {
+                    u32 t = t0 + u * blockDim.x;
+                    bool rev = t >= G;
+                    prep_group_load(rd, L, rev ? t - G : t, rev, t < 2 * G, pg[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < PREP_UNROLL; u++) prep_group_fold(pg[u], t0 + u * blockDim.x >= G, codes[u], nbits[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < PREP_UNROLL; u++) {
+                    u32 t = t0 + u * blockDim.x;
+                    bool rev = t >= G;
+                    codes[u] = 0; nbits[u] = 0;
+                    if (t < 2 * G) prep_group_short(rd, L, rev ? t - G : t, rev, codes[u], nbits[u]);
+                }
+            }
+            if (t0 < 64) {                                // wave 0, first pass: tasks 0 and 1 hold the N bits of the first 32 bases
+                u32 nb0 = (u32)__builtin_amdgcn_readlane((int)nbits[0], 0), nb1 = (u32)__builtin_amdgcn_readlane((int)nbits[0], 1);
+                // no N among the first 21 bases: hashInit skips nothing
+                int ks = 0;
+                if ((nb0 | (nb1 << 16)) & 0x1FFFFFu) {    // wave-uniform
+                    if (L >= 16 && 2 * G >= 64) ks = prep_nskip_wave(rd, L);
+                    else if (t0 == 0) { ByteSeq bs; bs.p = rd; bs.L = L; ks = shape_init_skip(bs); }   // short read: the literal walk
+                }
+                if (t0 == 0) read_ks[r] = ks;
+            }
+            // whole words leave the wave: the even lane of a pair stores the packed word and the bitmap word of both lanes (G and
+            // the task index of an even lane are even, so a pair never straddles the strands or the end)
+#pragma unroll
+            for (int u = 0; u < PREP_UNROLL; u++) {
+                u32 t = t0 + u * blockDim.x;
+                u32 c_hi = DPP_MOV(0, codes[u], DPP_QUAD_XOR1, 0xf), n_hi = DPP_MOV(0, nbits[u], DPP_QUAD_XOR1, 0xf);
+                if (t < 2 * G && !(t & 1)) {
+                    pk64[t >> 1] = (u64)codes[u] | ((u64)c_hi << 32);
+                    nm32[t >> 1] = nbits[u] | (n_hi << 16);
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
-}
-// Several reads per workgroup: with one read per workgroup (10^5 workgroups of a few microseconds each) the kernel ran at the
-// workgroup dispatch rate, not at memory speed.
-#define PREP_READS_PER_WG 1
-__global__ void __launch_bounds__(256) k_prep(const u8 *src, const u64 *off, const u64 *pk_off, u32 n, u64 *pk, u32 *nm, i32 *read_ks) {
-    const int U = 8;                                 // dword loads in flight per lane (the kernel is latency bound: 4 -> 8 measured)
-    __shared__ u64 s_c[4][U][8];  // per wave and step in flight: 64 code bytes = 8 packed words
-    __shared__ u32 s_n[4][U][8];  // per wave and step in flight: 32 N bytes   = 8 bitmap words
-    u32 r0 = blockIdx.x * PREP_READS_PER_WG;
-    for (u32 r = r0; r < r0 + PREP_READS_PER_WG && r < n; r++) prep_one_read<U>(src, off, pk_off, r, pk, nm, read_ks, s_c, s_n);
 }
 // read window features of both strands (createFeatures2_48 serial form, pmpfinder.cpp:556-588) from the packed strands:
 // 16-base cells are counted once into LDS, an entry is the sum of three consecutive cells.
