@@ -98,7 +98,7 @@ struct lnr_ctx {
     u32 mid_cap = 6144, mid_lds_kb = 24;   // reads with at least this many anchors run on 4 waves (k_job_mid: the DP is dealt over the waves); LNR_MID_CAP, LNR_MID_LDS_KB
     u32 heavy_cap = 0xffffffffu;        // reads with at least this many anchors (after the Y filter) take the 16-wave path (LNR_HEAVY_CAP overrides)
     u32 dp_split_cap = 0xffffffffu, dp_split_cap_r1 = 0xffffffffu;   // reads with at least this many anchors take the split path pre -> 16-wave DP -> post (LNR_DP_SPLIT_CAP, LNR_DP_SPLIT_CAP_R1)
-    u32 heavy_cap_r1 = 10000, mid_cap_r1 = 4096;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
+    u32 heavy_cap_r1 = 7000, mid_cap_r1 = 3000;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
     bool lane_bulk_first = true;         // two lanes: which lane goes through the re-map round first (LNR_LANE_ORDER=heavy|bulk)
     u32 stop_after = 0;                  // diagnostic: LNR_STOP_AFTER (see JobArgs)
     u32 prep_threads = 256;             // workgroup size of k_prep (LNR_PREP_THREADS: 64, 128 or 256)

@@ -788,6 +788,90 @@ __device__ void radix_sort_wave(u64 *a, u64 *alt, u32 n, u32 *hist) {
     WSYNC();
 }
 
+// The same sort by a multi-wave workgroup (k_job_mid / k_job_heavy): every wave counts and places one contiguous slice of
+// the keys; per pass the per-wave digit counts are turned into per-wave cursors (bin b of wave w starts behind all smaller
+// bins and behind bin b of the waves before it), so equal digits keep their order -- the result is the one of the wave form.
+// rh = NW x 256 LDS words, tot = 256, flag = 1.  Every wave of the workgroup calls this; it ends with a workgroup barrier.
+template <int NW>
+__device__ void radix_sort_block(u64 *a, u64 *alt, u32 n, u32 (*rh)[256], u32 *tot, u32 *flag) {
+    int lane = lane_id();
+    int wave = (int)(threadIdx.x >> 6);
+    u32 tid = threadIdx.x;
+    u32 per = (((n + NW - 1) / NW) + 63u) & ~63u;            // slice length, whole chunks of 64
+    u32 lo = (u32)wave * per; lo = lo < n ? lo : n;
+    u32 hi = lo + per < n ? lo + per : n;
+    u32 *hist = rh[wave];
+    u64 *src = a, *dst = alt;
+    if (tid == 0) *flag = 0;
+    for (int pass = 0; pass < 8; pass++) {
+        int shift = pass * 8;
+        for (int b = lane; b < 256; b += 64) hist[b] = 0;
+        WLDS();
+        for (u32 i0 = lo; i0 < hi; i0 += 256) {              // four independent loads in flight per lane
+            u64 k[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { u32 i = i0 + 64 * u + lane; k[u] = i < hi ? src[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (i0 + 64 * u + lane < hi) atomicAdd(&hist[(k[u] >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            u32 t = 0;
+            for (int w = 0; w < NW; w++) t += rh[w][tid];
+            tot[tid] = t;
+            if (t == n) *flag = (u32)pass + 1;                // every key has this digit: the pass is the identity
+        }
+        __syncthreads();
+        if (*flag == (u32)pass + 1) continue;                 // uniform; the next write to flag lies behind the next barrier
+        if (wave == 0) {                                      // exclusive prefix over the 256 bins: 4 bins per lane
+            u32 c0 = tot[4 * lane], c1 = tot[4 * lane + 1], c2 = tot[4 * lane + 2], c3 = tot[4 * lane + 3];
+            u32 s4 = c0 + c1 + c2 + c3;
+            u32 ex = wave_incl_scan(s4) - s4;
+            tot[4 * lane] = ex; tot[4 * lane + 1] = ex + c0; tot[4 * lane + 2] = ex + c0 + c1; tot[4 * lane + 3] = ex + c0 + c1 + c2;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            u32 run = tot[tid];
+            for (int w = 0; w < NW; w++) { u32 c = rh[w][tid]; rh[w][tid] = run; run += c; }
+        }
+        __syncthreads();
+        {   // place this wave's slice (radix_sort_wave's loop with the wave's own cursors)
+            u64 kn[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { u32 i = lo + 64 * u + lane; kn[u] = i < hi ? src[i] : 0; }
+            for (u32 base = lo; base < hi; base += 256) {
+                u64 kc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) kc[u] = kn[u];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { u32 i = base + 256 + 64 * u + lane; kn[u] = i < hi ? src[i] : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (base + 64 * u >= hi) break;           // uniform within the wave
+                    u32 i = base + 64 * u + lane;
+                    bool valid = i < hi;
+                    u64 key = kc[u];
+                    u32 d = (u32)(key >> shift) & 255;
+                    u64 m = __ballot(valid);
+                    for (int bit = 0; bit < 8; bit++) { u64 bm = __ballot((d >> bit) & 1); m &= ((d >> bit) & 1) ? bm : ~bm; }
+                    u32 pos = 0;
+                    if (valid) pos = hist[d] + (u32)__popcll(m & lanemask_lt());
+                    WLDS();
+                    if (valid) {
+                        dst[pos] = key;
+                        if ((m >> lane) >> 1 == 0) hist[d] += (u32)__popcll(m);
+                    }
+                    WLDS();
+                }
+            }
+        }
+        __syncthreads();                                      // the pass's stores are visible to the waves that read them next
+        u64 *t = src; src = dst; dst = t;
+    }
+    if (src != a) { for (u32 i = tid; i < n; i += NW * 64) a[i] = src[i]; }
+    __syncthreads();
+}
+
 // Wave-parallel, bit-exact std::sort(anchors, by getAnchorX descending) -- the tie-sensitive sort of
 // chainAnchorsHits (pmpfinder.cpp:2465).  Algorithm = ref_sort.h's ref_sort_model: ranges above SORT_SMALL are
 // partitioned by the whole wave with the list formulation of std::__unguarded_partition (ballot compaction of the
@@ -1583,6 +1667,8 @@ __device__ __forceinline__ void job_replay(const JobArgs &A, u32 j, u32 n1, u32 
 //   NW == 16: heavy reads.  Wave 0 runs every serial / wave-parallel phase with a large LDS arena; the other waves only
 //             join for the chaining DP (best_chains_block) and otherwise wait at the two workgroup barriers per job.
 struct DpShare { const u32 *xs, *ys; Rec rec; i32 *jlo; u32 m; int score_type; int abort; };
+struct RadixShare { u64 *a, *alt; u32 n; };
+#define RADIX_BLOCK_MIN 2048
 // PHASE: 0 = the whole job; 1 = up to the filled x / y arrays (state -> A.jstate); 2 = from the traceback on (the DP ran
 // in k_job_dp).  Phases 1 and 2 are launched with arena_lds = 0: every array then lives in the job's global scratch and
 // the allocation sequence, replayed from the two counts in jstate, yields the same pointers in all three kernels.
@@ -1596,6 +1682,9 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
     __shared__ LeaderScratch s_ls;   // introsort stack + tree table: one per workgroup, in LDS
     __shared__ DpTile<NW> s_tile;    // tiled chaining DP: leaf flags (+ the per-wave candidates of a multi-wave workgroup)
     __shared__ DpShare s_dp;         // NW > 1: what the helper waves need for the DP
+    __shared__ RadixShare s_rs;      // NW > 1: ... and for the radix sort
+    __shared__ u32 s_rhist[NW > 1 ? NW : 1][256];   // per-wave digit counts / cursors of the workgroup radix sort
+    __shared__ u32 s_rtot[NW > 1 ? 256 : 1], s_rflag;
     int lane = lane_id();
     int wave = (int)(threadIdx.x >> 6);
     const bool lead = NW == 1 || wave == 0;
@@ -1631,10 +1720,12 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
 #ifdef LNR_PROF
         for (int q = 0; q < 16; q++) lnr_job_ph[q] = 0;
 #endif
+        u64 *ag = nullptr, *s_alt = nullptr;
+        u32 n = 0, cap = 0;
         if (lead && PHASE != 2) {
-            u64 *ag = A.anchors + A.anc_off[j];
-            u32 n = A.n_anchors[j];
-            u32 cap = n + 2;   // scratch is sized by the anchors that passed the Y filter (known before the launch), not by the bucket entries
+            ag = A.anchors + A.anc_off[j];
+            n = A.n_anchors[j];
+            cap = n + 2;   // scratch is sized by the anchors that passed the Y filter (known before the launch), not by the bucket entries
             LNR_TICK(prof, 0, tk_);
             n = binning_wave(ag, n, dyn_lds, A.nbins);   // uses the dynamic LDS as its histogram
             LNR_TICK(prof, 1, tk_);
@@ -1643,14 +1734,25 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
             ar.init((void *)dyn_lds, A.arena_lds); ar.next = &slow;
             a = ag;
-            u64 *s_alt = nullptr;
             if (n > 1) {
                 u64 *alt = slow.get<u64>(cap);
                 s_alt = alt;
                 a = ar.get<u64>((u64)n + 2);          // sorted anchors move next to the lanes (LDS when they fit)
                 if (lane == 0) ag[0] = 0;   // filterAnchorsList pmpfinder.cpp:2031
                 WSYNC();
-                radix_sort_wave(ag, alt, n, hist);
+                if (NW == 1) radix_sort_wave(ag, alt, n, hist);
+            }
+        }
+        if (NW > 1 && PHASE != 2) {
+            // the radix sort of a multi-wave workgroup is dealt over its waves (long arrays only: five barriers per pass)
+            if (threadIdx.x == 0) { s_rs.a = ag; s_rs.alt = s_alt; s_rs.n = (n > 1 && n >= RADIX_BLOCK_MIN) ? n : 0; }
+            __syncthreads();
+            RadixShare rs = s_rs;
+            if (rs.n) radix_sort_block<NW>(rs.a, rs.alt, rs.n, s_rhist, s_rtot, &s_rflag);   // ends with a workgroup barrier
+            else if (lead && n > 1) radix_sort_wave(ag, s_alt, n, hist);
+        }
+        if (lead && PHASE != 2) {
+            if (n > 1) {
                 for (u32 i = lane; i < n; i += 64) a[i] = ag[i];
                 WSYNC();
             }
