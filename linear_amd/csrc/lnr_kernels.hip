@@ -989,6 +989,151 @@ __device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *t
     WSYNC();
 }
 
+// ---- the same sort by a multi-wave workgroup --------------------------------------------------------------------
+// What introsort does with a range depends on that range alone (its elements and its depth budget), so ranges can be
+// finished in any order and by different waves.  Wave 0 partitions from the top and hands every range of at most n / NW
+// elements to a queue in LDS instead of descending into it; after a barrier the waves take ranges from the queue and run
+// the single-wave algorithm on them, each with its own stack, its own slice of the staging area and the parts of the
+// position lists / task list that lie at the range's own indices (a range of s elements needs at most s entries of each).
+#define SORT_DQ 96
+struct SortDeferQ { u32 n, next; u32 first[SORT_DQ], last[SORT_DQ]; int depth[SORT_DQ]; };
+// introsort of a[first0, last0) with depth budget depth0 by one wave; ranges of at most defer_thresh elements go to q (if any)
+__device__ void introsort_xdesc_sub(u64 *a, u32 first0, u32 last0, int depth0, u32 *Lbuf, u32 *Rbuf, u64 *tasks, SortStack *st /* LDS */,
+                                    u64 *stage /* free LDS or null */, u32 stage_cap, u32 defer_thresh, SortDeferQ *q) {
+    int lane = lane_id();
+    XDesc comp;
+    if (last0 - first0 <= SORT_SMALL) {
+        if (lane == 0) rs_finish_range<16>(a, (long)first0, (long)last0, depth0, comp);
+        WSYNC();
+        return;
+    }
+    int *stk_first = st->first, *stk_last = st->last, *stk_depth = st->depth;
+    if (lane == 0) { stk_first[0] = (int)first0; stk_last[0] = (int)last0; stk_depth[0] = depth0; }
+    int sp = 1;
+    u32 ntasks = 0, qn = 0;
+    while (sp > 0) {
+        --sp;
+        WLDS();
+        u32 first = (u32)stk_first[sp], last = (u32)stk_last[sp];
+        int depth = stk_depth[sp];
+        while (true) {
+            if (last - first <= SORT_SMALL) {
+                if (lane == 0) tasks[ntasks] = (u64)first | ((u64)last << 28) | ((u64)depth << 56);
+                ntasks++;
+                break;
+            }
+            if (q && last - first <= defer_thresh && qn < SORT_DQ) {
+                if (lane == 0) { q->first[qn] = first; q->last[qn] = last; q->depth[qn] = depth; }
+                qn++;
+                break;
+            }
+            if (depth == 0) {
+                if (lane == 0) tasks[ntasks] = (u64)first | ((u64)last << 28) | (1ULL << 63);
+                ntasks++;
+                break;
+            }
+            --depth;
+            u32 iA = first + 1, iB = first + (last - first) / 2, iC = last - 1;
+            u64 v4 = 0;
+            if (lane < 4) v4 = a[lane == 0 ? iA : lane == 1 ? iB : lane == 2 ? iC : first];
+            u64 va = readlane_u64(v4, 0), vb = readlane_u64(v4, 1), vc = readlane_u64(v4, 2), vf = readlane_u64(v4, 3);
+            u32 pick;
+            if (comp(va, vb)) pick = comp(vb, vc) ? iB : (comp(va, vc) ? iC : iA);
+            else pick = comp(va, vc) ? iA : (comp(vb, vc) ? iC : iB);
+            u64 vp = pick == iA ? va : (pick == iB ? vb : vc);
+            if (lane == 0) { a[first] = vp; a[pick] = vf; }
+            u32 xp = (u32)anchor_x(vp), xf = (u32)anchor_x(vf);
+            u32 lo = first + 1, nL = 0, nR = 0;
+            for (u32 base = lo; base < last; base += 256) {
+                u32 xs4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { u32 i = base + 64 * u + lane; xs4[u] = i < last ? (u32)anchor_x(a[i]) : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (base + 64 * u >= last) break;
+                    u32 i = base + 64 * u + lane;
+                    bool in = i < last;
+                    u32 x = i == pick ? xf : xs4[u];
+                    bool fL = in && !(x > xp);
+                    bool fR = in && !(xp > x);
+                    u64 mL = __ballot(fL), mR = __ballot(fR);
+                    if (fL) Lbuf[nL + __popcll(mL & lanemask_lt())] = i;
+                    if (fR) Rbuf[nR + __popcll(mR & lanemask_lt())] = i;
+                    nL += (u32)__popcll(mL); nR += (u32)__popcll(mR);
+                }
+            }
+            WSYNC();
+            u32 lim = nL < nR ? nL : nR, cnt = 0;
+            for (u32 k = lane; k < lim; k += 64) cnt += Lbuf[k] < Rbuf[nR - 1 - k] ? 1u : 0u;
+            u32 K = wave_sum(cnt);
+            for (u32 k = lane; k < K; k += 64) { u32 i = Lbuf[k], j = Rbuf[nR - 1 - k]; u64 t = a[i]; a[i] = a[j]; a[j] = t; }
+            u32 cut = last;
+            if (K < nL) cut = Lbuf[K];
+            if (K >= 1) { u32 r = Rbuf[nR - K]; cut = r < cut ? r : cut; }
+            WSYNC();
+            if (lane == 0) { stk_first[sp] = (int)cut; stk_last[sp] = (int)last; stk_depth[sp] = depth; }
+            ++sp;
+            last = cut;
+        }
+    }
+    if (q && lane == 0) q->n = qn;
+    WSYNC();
+    // the small ranges, one per lane; as many consecutive ones per pass as the staging slice holds
+    for (u32 b = 0; b < ntasks;) {
+        u32 t = b + (u32)lane;
+        bool have = t < ntasks;
+        u64 v = have ? tasks[t] : 0;
+        u32 span_first = (u32)(tasks[b] & 0xfffffff);
+        bool heap_any = __ballot(have && (v >> 63)) != 0;
+        u64 fits = __ballot(have && (u32)((v >> 28) & 0xfffffff) - span_first <= stage_cap);   // ends increase with the lane: a prefix
+        if (stage && !heap_any && fits) {
+            u32 cntf = (u32)__popcll(fits);
+            u32 span_last = (u32)((tasks[b + cntf - 1] >> 28) & 0xfffffff);
+            u32 span = span_last - span_first;
+            for (u32 i = lane; i < span; i += 64) stage[i] = a[span_first + i];
+            WSYNC();
+            if ((u32)lane < cntf) rs_finish_range<16>(stage - span_first, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)((v >> 56) & 0x7f), comp);
+            WSYNC();
+            for (u32 i = lane; i < span; i += 64) a[span_first + i] = stage[i];
+            WSYNC();
+            b += cntf;
+        } else {
+            if (have) {
+                if (v >> 63) rs_heap_sort(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), comp);
+                else rs_finish_range<16>(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)((v >> 56) & 0x7f), comp);
+            }
+            b += 64;
+        }
+    }
+    WSYNC();
+}
+// every wave of the workgroup calls this; ends with a workgroup barrier.  stacks = NW sort stacks in LDS.
+template <int NW>
+__device__ void introsort_xdesc_block(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *tasks, SortStack *stacks, SortDeferQ *q, u64 *stage, u32 stage_cap) {
+    int lane = lane_id();
+    int wave = (int)(threadIdx.x >> 6);
+    if (wave == 0) {
+        if (lane == 0) { q->n = 0; q->next = 0; }
+        int lg = 0;
+        for (u32 t = n; t > 1; t >>= 1) lg++;
+        u32 thresh = n / NW; thresh = thresh < 4 * SORT_SMALL ? 4 * SORT_SMALL : thresh;
+        introsort_xdesc_sub(a, 0, n, lg * 2, Lbuf, Rbuf, tasks, &stacks[0], stage, stage_cap, thresh, q);
+    }
+    __syncthreads();
+    u32 nq = q->n;
+    u32 cap_w = stage_cap / NW;
+    u64 *stg_w = (stage && cap_w >= 2 * SORT_SMALL) ? stage + (size_t)wave * cap_w : nullptr;
+    for (;;) {
+        u32 i = 0;
+        if (lane == 0) i = atomicAdd(&q->next, 1u);
+        i = (u32)__builtin_amdgcn_readfirstlane((int)i);
+        if (i >= nq) break;
+        u32 f = q->first[i], l = q->last[i];
+        introsort_xdesc_sub(a, f, l, q->depth[i], Lbuf + f, Rbuf + f, tasks + f, &stacks[wave], stg_w, cap_w, 0, nullptr);
+    }
+    __syncthreads();
+}
+
 // wave-parallel twin of filter_anchor_list (filterAnchorsList, pmpfinder.cpp:2025-2071).  The serial loop compares anchor i
 // with ak2 = a[(block_str + i - 1) >> 1]: inside a block that only depends on where the block started, so 64 anchors are
 // tested at once and the first one that breaks the block is found with a ballot.  Block statistics (count, min / max y of
@@ -1669,6 +1814,8 @@ __device__ __forceinline__ void job_replay(const JobArgs &A, u32 j, u32 n1, u32 
 struct DpShare { const u32 *xs, *ys; Rec rec; i32 *jlo; u32 m; int score_type; int abort; };
 struct RadixShare { u64 *a, *alt; u32 n; };
 #define RADIX_BLOCK_MIN 2048
+struct SortShare { u64 *a; u32 *L, *R; u64 *tasks, *stg; u32 stg_cap, n; };
+#define SORT_BLOCK_MIN 2048
 // PHASE: 0 = the whole job; 1 = up to the filled x / y arrays (state -> A.jstate); 2 = from the traceback on (the DP ran
 // in k_job_dp).  Phases 1 and 2 are launched with arena_lds = 0: every array then lives in the job's global scratch and
 // the allocation sequence, replayed from the two counts in jstate, yields the same pointers in all three kernels.
@@ -1685,6 +1832,9 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
     __shared__ RadixShare s_rs;      // NW > 1: ... and for the radix sort
     __shared__ u32 s_rhist[NW > 1 ? NW : 1][256];   // per-wave digit counts / cursors of the workgroup radix sort
     __shared__ u32 s_rtot[NW > 1 ? 256 : 1], s_rflag;
+    __shared__ SortShare s_so;       // NW > 1: ... and for the x-descending sort
+    __shared__ SortStack s_sstk[NW > 1 ? NW : 1];
+    __shared__ SortDeferQ s_sq;
     int lane = lane_id();
     int wave = (int)(threadIdx.x >> 6);
     const bool lead = NW == 1 || wave == 0;
@@ -1722,6 +1872,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
 #endif
         u64 *ag = nullptr, *s_alt = nullptr;
         u32 n = 0, cap = 0;
+        u32 *so_L = nullptr, *so_R = nullptr; u64 *so_tasks = nullptr, *so_stg = nullptr; u32 so_stg_cap = 0;   // scratch of the x-descending sort
         if (lead && PHASE != 2) {
             ag = A.anchors + A.anc_off[j];
             n = A.n_anchors[j];
@@ -1764,17 +1915,26 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             if (NW == 1 && A.stop_after == 13) break;   // after the list filter
             if (m > 1) {
                 // scratch of the sort: position lists in the (dead) radix buffer, task list behind it
-                u32 *Lbuf = (u32 *)s_alt, *Rbuf = Lbuf + (m + 2);
-                u64 *tasks = slow.get<u64>((u64)m + 2);
+                so_L = (u32 *)s_alt; so_R = so_L + (m + 2);
+                so_tasks = slow.get<u64>((u64)m + 2);
                 // free LDS behind the arena's current mark can stage the final small sorts when `a` itself is in global memory
-                u64 *stg = nullptr; u32 stg_cap = 0;
                 {
                     bool a_in_lds = (char *)a >= (char *)dyn_lds && (char *)a < (char *)dyn_lds + A.arena_lds;
                     u64 used = (ar.off + 15) & ~15ULL;
-                    if (!a_in_lds && A.arena_lds > used + 4096) { stg = (u64 *)((char *)dyn_lds + used); stg_cap = (u32)((A.arena_lds - used) / 8); }
+                    if (!a_in_lds && A.arena_lds > used + 4096) { so_stg = (u64 *)((char *)dyn_lds + used); so_stg_cap = (u32)((A.arena_lds - used) / 8); }
                 }
-                introsort_xdesc_wave(a, m, Lbuf, Rbuf, tasks, &s_ls, stg, stg_cap);
+                if (NW == 1) introsort_xdesc_wave(a, m, so_L, so_R, so_tasks, &s_ls, so_stg, so_stg_cap);
             }
+        }
+        if (NW > 1 && PHASE != 2) {
+            // the x-descending sort of a multi-wave workgroup: wave 0 partitions from the top, all waves finish the sub-ranges
+            if (threadIdx.x == 0) { s_so.a = a; s_so.L = so_L; s_so.R = so_R; s_so.tasks = so_tasks; s_so.stg = so_stg; s_so.stg_cap = so_stg_cap; s_so.n = (m > 1 && m >= SORT_BLOCK_MIN) ? m : 0; }
+            __syncthreads();
+            SortShare so = s_so;
+            if (so.n) introsort_xdesc_block<NW>(so.a, so.n, so.L, so.R, so.tasks, s_sstk, &s_sq, so.stg, so.stg_cap);   // ends with a workgroup barrier
+            else if (lead && m > 1) introsort_xdesc_wave(a, m, so_L, so_R, so_tasks, &s_ls, so_stg, so_stg_cap);
+        }
+        if (lead && PHASE != 2) {
             LNR_TICK(prof, 15, tk_);
             if (NW == 1 && A.stop_after == 4) break;
             ok = job_carve(ar, m, S, &s_ovf) && !slow.ovf;
