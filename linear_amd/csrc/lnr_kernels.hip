@@ -1813,9 +1813,13 @@ __device__ __forceinline__ void job_replay(const JobArgs &A, u32 j, u32 n1, u32 
 //             join for the chaining DP (best_chains_block) and otherwise wait at the two workgroup barriers per job.
 struct DpShare { const u32 *xs, *ys; Rec rec; i32 *jlo; u32 m; int score_type; int abort; };
 struct RadixShare { u64 *a, *alt; u32 n; };
-#define RADIX_BLOCK_MIN 2048
+#ifndef RADIX_BLOCK_MIN
+#define RADIX_BLOCK_MIN 2048   // shortest array the workgroup forms are used for (tools/stress_parity.py runs a build with 64)
+#endif
 struct SortShare { u64 *a; u32 *L, *R; u64 *tasks, *stg; u32 stg_cap, n; };
+#ifndef SORT_BLOCK_MIN
 #define SORT_BLOCK_MIN 2048
+#endif
 // PHASE: 0 = the whole job; 1 = up to the filled x / y arrays (state -> A.jstate); 2 = from the traceback on (the DP ran
 // in k_job_dp).  Phases 1 and 2 are launched with arena_lds = 0: every array then lives in the job's global scratch and
 // the allocation sequence, replayed from the two counts in jstate, yields the same pointers in all three kernels.
