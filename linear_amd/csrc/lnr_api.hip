@@ -92,7 +92,7 @@ struct lnr_ctx {
     lnr_index_info info{};
     std::vector<u64> seq_len, seq_off, f2_off;
     u32 nbins = 0;
-    size_t job_lds_bytes = 5 * 1024;    // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning)
+    size_t job_lds_bytes = 6 * 1024;    // LDS half of k_job's two-level arena (LNR_JOB_LDS_KB overrides, for tuning): 2.6 KB static + 6 KB x 16 workgroups fit a CU's 160 KB (measured: 5 KB +2 %, 7 KB +1 %)
     size_t job_stage_bytes = 0;         // LDS stage of the blocked DP's predecessor window in the fused k_job (LNR_JOB_STAGE_KB; measured slower, off)
     u32 heavy_lds_kb = 48;              // LDS arena of k_job_heavy (LNR_HEAVY_LDS_KB)
     u32 mid_cap = 6144, mid_lds_kb = 24;   // reads with at least this many anchors run on 4 waves (k_job_mid: the DP is dealt over the waves); LNR_MID_CAP, LNR_MID_LDS_KB

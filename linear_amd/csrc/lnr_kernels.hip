@@ -1825,12 +1825,15 @@ struct SortShare { u64 *a; u32 *L, *R; u64 *tasks, *stg; u32 stg_cap, n; };
 // the allocation sequence, replayed from the two counts in jstate, yields the same pointers in all three kernels.
 template <int NW, int PHASE = 0>
 __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
-    __shared__ u32 hist[256];
     __shared__ u32 s_m;
     __shared__ int s_ovf, s_flag[4];
     __shared__ u64 *s_H;
     __shared__ u32 s_nH, s_nhits;
     __shared__ LeaderScratch s_ls;   // introsort stack + tree table: one per workgroup, in LDS
+    // the 256 digit counters of the wave radix sort live in the four 64-entry tree tables (used by the traceback only): every
+    // static LDS byte of the single-wave kernel is one byte less for its arena at 16 workgroups per CU
+    static_assert(sizeof(s_ls.l_root) + sizeof(s_ls.l_score) + sizeof(s_ls.l_len) + sizeof(s_ls.l_leaf) == 256 * sizeof(u32), "tree tables = 256 words");
+    u32 *hist = (u32 *)s_ls.l_root;
     __shared__ DpTile<NW> s_tile;    // tiled chaining DP: leaf flags (+ the per-wave candidates of a multi-wave workgroup)
     __shared__ DpShare s_dp;         // NW > 1: what the helper waves need for the DP
     __shared__ RadixShare s_rs;      // NW > 1: ... and for the radix sort

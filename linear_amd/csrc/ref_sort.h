@@ -103,7 +103,7 @@ LNR_HD inline void rs_heap_sort(T *a, long first, long last, Comp comp) {
 
 // Explicit stack of the introsort loop.  Depth <= 2*lg(n) + 1 entries; callers on the GPU place it in LDS
 // (one per wave) instead of per-lane private memory, which would cost occupancy.
-struct SortStack { int first[96], last[96], depth[96]; };
+struct SortStack { int first[64], last[64], depth[64]; };   // 2 lg n + 1 entries: enough below 2^31 elements
 
 // std::sort(a, a+n, comp)
 template <class T, class Comp>
