@@ -191,3 +191,36 @@ def test_gpu_traceback_of_long_score_arrays_with_rejected_chains(oracle_lib):
     o = oracle_lib.Checker("oracle", refs, 3)
     ooff, ocs, oce, _ = o.map_batch(reads, off, threads=8)
     assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
+
+
+def test_gpu_reads_that_begin_inside_an_n_run(oracle_lib):
+    """hashInit's N-skip at the read start is found by a whole wave from the N bits (k_prep): reads whose first bases are N
+    for 1 .. 4000 positions -- around the 21-base window, the 16-position groups and the 992-position steps of the search --
+    reads that are N throughout, N runs further inside, and a short read that takes the literal walk."""
+    from linear_amd import Filter, synth
+    ref = synth.random_ref(300_000, 4711)
+    refs = [ref]
+    L = 6000
+    lead = [0, 1, 5, 15, 16, 17, 20, 21, 22, 31, 32, 33, 63, 64, 65, 500, 991, 992, 993, 1008, 1500, 1983, 1984, 1985, 4000, 5979, 5980, 5999, L]
+    rng = np.random.default_rng(99)
+    parts, off = [], [0]
+    for k, n_lead in enumerate(lead):
+        p = int(rng.integers(1000, 290_000 - L))
+        r = ref[p:p + L].copy()
+        r[:n_lead] = 4
+        if k % 3 == 1 and n_lead + 40 < L:          # a second run a little further in: the first window of 21 clean bases may lie between them
+            r[n_lead + 25:n_lead + 40] = 4
+        if k % 3 == 2 and n_lead + 20 < L:          # ... or only 20 clean bases between two runs
+            r[n_lead + 20:n_lead + 30] = 4
+        parts.append(r); off.append(off[-1] + L)
+    short = ref[5000:5300].copy(); short[:37] = 4   # 2 * packed groups < 64: the literal walk
+    parts.append(short); off.append(off[-1] + short.size)
+    reads = np.concatenate(parts); off = np.asarray(off, dtype=np.uint64)
+    f = Filter(device=0)
+    f.build_index(refs, 1)
+    coff, cs, ce = f.filter_batch(reads, off)
+    f.close()
+    o = oracle_lib.Checker("oracle", refs, 1)
+    ooff, ocs, oce, _ = o.map_batch(reads, off, threads=2)
+    assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
+    assert cs.size > 0
