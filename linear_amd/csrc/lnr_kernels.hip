@@ -9,8 +9,8 @@
 //   features     [a6]   : k_f2 (genome), k_f1 (reads, both strands)
 //   read prep    [a1,a2]: k_prep (2-bit packing of both strands + N bitmaps + hashInit N-skip)
 //   seed lookup  [a3,a4,a7]: k_seed_fused (+ k_ix_bitmap at index time)
-//   per-read job [a8-a16]: k_job (1 wave per read) / k_job_heavy (16 waves per heavy read): binning, radix sort, filter,
-//                         introsort, blocked chaining DP, traceback, blocks, windows
+//   per-read job [a8-a16]: k_job (1 wave per read) / k_job_mid (4 waves) / k_job_heavy (16 waves per heavy read): binning,
+//                         radix sort, filter, introsort, blocked chaining DP, traceback, blocks, windows
 //   tails        [a17-a20]: k_tail_a, k_tail_b, k_gather_out
 #pragma once
 #include <hip/hip_runtime.h>
@@ -1809,8 +1809,9 @@ __device__ __forceinline__ void job_replay(const JobArgs &A, u32 j, u32 n1, u32 
 // One workgroup per read: runs the read's jobs in order (round 0: the whole read; remap round: its gaps), appending
 // cords to the read's cord list exactly like consecutive apxMap_ calls do.
 //   NW == 1 : one wave does everything (the bulk of the reads).
-//   NW == 16: heavy reads.  Wave 0 runs every serial / wave-parallel phase with a large LDS arena; the other waves only
-//             join for the chaining DP (best_chains_block) and otherwise wait at the two workgroup barriers per job.
+//   NW == 4 / 16: reads with many anchors.  Wave 0 runs the serial / wave-parallel phases with a large LDS arena; the other
+//             waves join for the radix sort (radix_sort_block), the x-descending sort (introsort_xdesc_block) and the chaining
+//             DP (best_chains_block) and otherwise wait at the workgroup barriers that frame those three phases.
 struct DpShare { const u32 *xs, *ys; Rec rec; i32 *jlo; u32 m; int score_type; int abort; };
 struct RadixShare { u64 *a, *alt; u32 n; };
 #ifndef RADIX_BLOCK_MIN
