@@ -530,27 +530,36 @@ struct DpPair { i32 dy; u32 da, M; };
 template <int ST, bool SORTED = false>
 LNR_HD inline bool dp_pair_cand(u32 px, u32 py, u32 xi, u32 yi, DpPair &p) {
     i32 dy = (i32)py - (i32)yi, dx = (i32)px - (i32)xi;
-    i32 t = dx - dy;
-    u32 da = (u32)(t < 0 ? -t : t);
-    u32 M;
-    if (SORTED) { i32 m = dy > dx ? dy : dx; M = (u32)(m < 50 ? 50 : m); }      // dx >= 0: a negative dy never wins
-    else {
+    u32 da, M;
+    i32 m3;                                              // max(dy, dx) when dx >= 0
+    if (SORTED) {
+        // dx >= 0; every use of da and M below sits behind a test that dy is positive, and for non-negative dx, dy the
+        // distance from the diagonal is one unsigned absolute difference (v_sad_u32); a negative dy never wins the maximum
+        u32 udx = (u32)dx, udy = (u32)dy;
+        da = udx > udy ? udx - udy : udy - udx;
+        m3 = dy > dx ? dy : dx;
+        M = (u32)(m3 < 50 ? 50 : m3);
+    } else {
+        i32 t = dx - dy;
+        da = (u32)(t < 0 ? -t : t);
         u32 adx = (u32)(dx < 0 ? -dx : dx);
         M = (u32)(dy < 0 ? 0 : dy); M = M > adx ? M : adx; M = M < 50 ? 50 : M;
+        m3 = (i32)M;
     }
     p.dy = dy; p.da = da; p.M = M;
     if (ST) return dy >= 5 && dy < 100 && da < 100 && da < M;
-    // dy in [10, 2250) && da < M && (da < 10 || 7 da < M), without the 64-bit product and without a branch: da < 10 passes
-    // (M >= 50); otherwise 7 da < M forces da < 375 -- M = max(dy, 50) < 2250 gives da < 322, M = |dx| > dy needs dx > 0 (else
-    // da = dy + |dx| > M) and 7 (dx - dy) < dx, i.e. dx < 2625 -- so da >= 512 is rejected outright and 7 da only has to be
-    // right for da < 512 (a 24-bit multiply on the GPU)
-    u32 e = da < 10 ? 0u : da;
+    // dy in [10, 2250) && da < M && (da < 10 || 7 da < M), without the 64-bit product and without a branch.  7 da < M forces
+    // da < 375 -- M = max(dy, 50) < 2250 gives da < 322, M = |dx| > dy needs dx > 0 (else da = dy + |dx| > M) and
+    // 7 (dx - dy) < dx, i.e. dx < 2625 -- so da >= 512 is rejected outright and 7 da only has to be right for da < 512 (a
+    // 24-bit multiply on the GPU).  The case da < 10 needs no test of its own against max(M, 70): 7 da <= 63 < 70 then, and for
+    // da >= 10 (7 da >= 70) the larger bound changes nothing when M < 70.
+    u32 M70 = (u32)(m3 < 70 ? 70 : m3);
 #if defined(__HIP_DEVICE_COMPILE__)
-    u32 e7 = (u32)__umul24(e, 7u);
+    u32 e7 = (u32)__umul24(da, 7u);
 #else
-    u32 e7 = (e & 0xffffffu) * 7u;
+    u32 e7 = (da & 0xffffffu) * 7u;
 #endif
-    return (u32)(dy - 10) < 2240u && e < 512u && e7 < M;
+    return (u32)(dy - 10) < 2240u && da < 512u && e7 < M70;
 }
 // score_derr of getApxChainScore for a candidate pair (0 when da < 10): floor(100 da / M) by float estimate + exact correction
 LNR_HD inline u32 dp_pair_sderr(const DpPair &p) {

@@ -345,7 +345,8 @@ u64 hs_chain_score_fuzz(u64 seed, u64 n) {
             if (x1 >= x2) {   // the form for x-sorted predecessors (dx >= 0) must agree with the general one
                 DpPair q0, q1;
                 bool d0 = dp_pair_cand<0, true>(x1, y1, x2, y2, q0), d1 = dp_pair_cand<1, true>(x1, y1, x2, y2, q1);
-                if (d0 != c0 || d1 != c1 || q0.M != p0.M || q0.da != p0.da || q0.dy != p0.dy || q1.M != p1.M) bad++;
+                // (da of the sorted form is only meaningful for dy >= 0: every use sits behind a test that dy is positive)
+                if (d0 != c0 || d1 != c1 || q0.M != p0.M || q0.dy != p0.dy || q1.M != p1.M || (p0.dy >= 0 && (q0.da != p0.da || q1.da != p1.da))) bad++;
             }
         }
     }
