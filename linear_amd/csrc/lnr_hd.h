@@ -536,7 +536,11 @@ LNR_HD inline bool dp_pair_cand(u32 px, u32 py, u32 xi, u32 yi, DpPair &p) {
         // dx >= 0; every use of da and M below sits behind a test that dy is positive, and for non-negative dx, dy the
         // distance from the diagonal is one unsigned absolute difference (v_sad_u32); a negative dy never wins the maximum
         u32 udx = (u32)dx, udy = (u32)dy;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("v_sad_u32 %0, %1, %2, 0" : "=v"(da) : "v"(udx), "v"(udy));   // the compiler emits min / max / sub for the select form here
+#else
         da = udx > udy ? udx - udy : udy - udx;
+#endif
         m3 = dy > dx ? dy : dx;
         M = (u32)(m3 < 50 ? 50 : m3);
     } else {
