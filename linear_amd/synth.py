@@ -221,3 +221,73 @@ def chr22_like(seed: int = 2022, length: int = 50_818_468, lead_n: int = 10_510_
         pos = int(rng.integers(body0, length - n))
         ref[pos:pos + n] = 4
     return ref
+
+
+def plant_repeats(ref: np.ndarray, rng: np.random.Generator, fams, frac: float, lo: int = 0, hi: int | None = None) -> None:
+    """Overwrite ~frac of ref[lo:hi) with diverged copies of the (consensus, divergence) families, in place."""
+    hi = ref.size if hi is None else hi
+    target, filled = frac * (hi - lo), 0
+    while filled < target:
+        f, div = fams[int(rng.integers(0, len(fams)))]
+        a = int(rng.integers(0, max(1, f.size - 300)))
+        b = int(rng.integers(min(a + 280, f.size), f.size + 1))
+        cp = f[a:b].copy()
+        mut = rng.random(cp.size) < div
+        cp[mut] = (cp[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+        if rng.random() < 0.5:
+            cp = revcomp(cp)
+        pos = int(rng.integers(lo, hi - cp.size))
+        ref[pos:pos + cp.size] = cp
+        filled += cp.size
+
+
+def scale_refs(seed: int = 38, big: int = 262_500_000, n_small: int = 23) -> list[np.ndarray]:
+    """Scale-pinning reference set: 24 sequences, the first longer than any human chromosome
+    (262.5 Mb > chr1's 248 Mb: x + 2^20 crosses 2^28, the binning histogram has 8 800 bins), the others 0.4-6 Mb
+    (ids up to 23), repeat families shared between the sequences, a telomere-like leading N run and
+    assembly gaps in the big one.  ~320 Mb in all: small enough for the reference itself to index here."""
+    rng = np.random.default_rng(seed)
+    fams = [(rng.integers(0, 4, size=int(rng.integers(280, 6500)), dtype=np.uint8), float(rng.choice([0.02, 0.05, 0.10, 0.15, 0.20])))
+            for _ in range(60)]
+    lens = [big] + [int(rng.integers(400_000, 6_000_000)) for _ in range(n_small)]
+    refs = []
+    for k, L in enumerate(lens):
+        r = rng.integers(0, 4, size=L, dtype=np.uint8)
+        if k == 0:
+            # repeats only where the reads come from (both ends and the middle): planting 45 % of 262 Mb would take minutes
+            for lo, hi in ((10_000, 6_000_000), (128_000_000, 132_000_000), (L - 8_000_000, L)):
+                plant_repeats(r, rng, fams, 0.35, lo, hi)
+            r[:10_000] = 4
+            for _ in range(5):
+                n = int(rng.integers(1000, 60_000))
+                p = int(rng.integers(20_000_000, L - 20_000_000))
+                r[p:p + n] = 4
+        else:
+            plant_repeats(r, rng, fams, 0.35)
+        refs.append(r)
+    return refs
+
+
+def scale_reads(refs: list[np.ndarray], seed: int = 39, n_per: int = 40, read_len: int = 8000, err: float = 0.10):
+    """Reads for scale_refs: from the start, the middle and the last megabases of the big sequence (x beyond 2^28),
+    from the highest sequence ids, plus chimeras that join the far end of the big sequence to sequence 23."""
+    rng = np.random.default_rng(seed)
+    big = refs[0]
+    out = []
+
+    def take(ref, lo, hi, L):
+        span = int(L * (1 + err)) + 64
+        p = int(rng.integers(lo, hi - span))
+        s = mutate(ref[p:p + span], err, rng)[:L]
+        return revcomp(s) if rng.random() < 0.5 else s
+    for lo, hi in ((10_000, 6_000_000), (128_000_000, 132_000_000), (big.size - 8_000_000, big.size)):
+        for _ in range(n_per):
+            out.append(take(big, lo, hi, int(read_len * (0.5 + rng.random()))))
+    for sid in (1, 12, 22, 23):
+        for _ in range(n_per // 4):
+            out.append(take(refs[sid], 0, refs[sid].size, read_len))
+    for _ in range(6):
+        out.append(np.concatenate([take(big, big.size - 3_000_000, big.size, 4000), take(refs[23], 0, refs[23].size, 4000)]))
+    out.append(big[big.size - 5000:].copy())                 # the very end of the big sequence
+    out.append(rng.integers(0, 4, size=7000, dtype=np.uint8))  # junk -> re-map round against the full table
+    return pack_reads(out)

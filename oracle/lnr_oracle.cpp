@@ -180,6 +180,12 @@ static void createDIndex(const std::vector<const uint8_t *> &seqs, const std::ve
     std::vector<int32_t> &dir = index.dir;
     std::vector<u64> &hs = index.hs;
     dir.assign(full, 0);
+    // The reference runs the `threads` chunks of a sequence as an OpenMP team and counts / fills with atomics
+    // (index_util.cpp:1667-1700, 1743-1786: atomicInc on dir, atomic_inc_cord_y on the slot head), so the order in which
+    // chunks run does not reach the result.  Here every (sequence, chunk) pair is one work item of a host-wide team
+    // (build_threads, independent of the layout parameter `threads`): same counts, same slots after the per-bucket sort.
+    struct Item { size_t seq; i64 t_str, t_end; };
+    std::vector<Item> items;
     for (size_t i = 0; i < seqs.size(); i++) {
         std::vector<i64> t_blocks;
         for (unsigned j = 0; j < threads; j++) t_blocks.push_back((i64)(lens[i] / threads * j));
@@ -188,21 +194,29 @@ static void createDIndex(const std::vector<const uint8_t *> &seqs, const std::ve
             i64 t_str = t_blocks[t_id] + t_shape.span;
             i64 t_end = t_blocks[t_id + 1] - t_shape.span;
             if (t_str >= t_end) continue;   // reference would still call hashInit; no effect
-            i64 last_j = t_str - 1, count = 0;
-            u64 preVal = ~0ULL;
-            Shape shape = t_shape;
-            hashInit(shape, seqs[i] + t_str);
-            for (i64 j = t_str; j < t_end; j++) {
-                hashNexth(shape, seqs[i] + j);
-                if (++count > thd_min_step) {
-                    hashNextX(shape, seqs[i] + j);
-                    if (preVal != shape.XValue || j - last_j > thd_max_step) {
-                        ++dir[shape.XValue];
-                        preVal = shape.XValue;
-                        last_j = j;
-                    }
-                    count = 0;
+            items.push_back({i, t_str, t_end});
+        }
+    }
+    std::sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.t_end - a.t_str > b.t_end - b.t_str; });   // longest first
+    const int build_threads = omp_get_max_threads();
+#pragma omp parallel for num_threads(build_threads) schedule(dynamic, 1)
+    for (size_t it = 0; it < items.size(); it++) {
+        const uint8_t *seq = seqs[items[it].seq];
+        i64 t_str = items[it].t_str, t_end = items[it].t_end;
+        i64 last_j = t_str - 1, count = 0;
+        u64 preVal = ~0ULL;
+        Shape shape = t_shape;
+        hashInit(shape, seq + t_str);
+        for (i64 j = t_str; j < t_end; j++) {
+            hashNexth(shape, seq + j);
+            if (++count > thd_min_step) {
+                hashNextX(shape, seq + j);
+                if (preVal != shape.XValue || j - last_j > thd_max_step) {
+                    __atomic_fetch_add(&dir[shape.XValue], 1, __ATOMIC_RELAXED);
+                    preVal = shape.XValue;
+                    last_j = j;
                 }
+                count = 0;
             }
         }
     }
@@ -214,44 +228,46 @@ static void createDIndex(const std::vector<const uint8_t *> &seqs, const std::ve
     }
     u64 EmptyVal = create_cord(seqs.size(), 0, 0, 0);
     hs.assign((size_t)sum, EmptyVal);
-    for (size_t i = 0; i < seqs.size(); i++) {
-        std::vector<i64> t_blocks;
-        for (unsigned j = 0; j < threads; j++) t_blocks.push_back((i64)(lens[i] / threads * j));
-        t_blocks.push_back((i64)lens[i] - (i64)t_shape.span);
-        for (unsigned t_id = 0; t_id < threads; t_id++) {
-            i64 t_str = t_blocks[t_id] + t_shape.span;
-            i64 t_end = t_blocks[t_id + 1] - t_shape.span;
-            if (t_str >= t_end) continue;
-            i64 last_j = t_str - 1, count = 0;
-            u64 preVal = ~0ULL;
-            Shape shape = t_shape;
-            hashInit(shape, seqs[i] + t_str);
-            for (i64 j = t_str; j < t_end; j++) {
-                hashNexth(shape, seqs[i] + j);
-                if (++count > thd_min_step) {
-                    hashNextX(shape, seqs[i] + j);
-                    if (preVal != shape.XValue || j - last_j > thd_max_step) {
-                        if (dir[shape.XValue + 1] - dir[shape.XValue]) {
-                            i64 slot_str = dir[shape.XValue];
-                            i64 slot_end = dir[shape.XValue + 1];
-                            u64 nv = ++hs[slot_str];                       // atomic_inc_cord_y
-                            i64 k = slot_end - (i64)(get_cord_y(nv) & ((1ULL << 15) - 1));
-                            hs[k] = create_cord(i, (u64)j + const_anchor_zero, shape.YValue, shape.strand);
-                            preVal = shape.XValue;
-                            last_j = j;
-                        }
+#pragma omp parallel for num_threads(build_threads) schedule(dynamic, 1)
+    for (size_t it = 0; it < items.size(); it++) {
+        size_t i = items[it].seq;
+        const uint8_t *seq = seqs[i];
+        i64 t_str = items[it].t_str, t_end = items[it].t_end;
+        i64 last_j = t_str - 1, count = 0;
+        u64 preVal = ~0ULL;
+        Shape shape = t_shape;
+        hashInit(shape, seq + t_str);
+        for (i64 j = t_str; j < t_end; j++) {
+            hashNexth(shape, seq + j);
+            if (++count > thd_min_step) {
+                hashNextX(shape, seq + j);
+                if (preVal != shape.XValue || j - last_j > thd_max_step) {
+                    if (dir[shape.XValue + 1] - dir[shape.XValue]) {
+                        i64 slot_str = dir[shape.XValue];
+                        i64 slot_end = dir[shape.XValue + 1];
+                        u64 nv = __atomic_add_fetch(&hs[slot_str], 1, __ATOMIC_RELAXED);   // atomic_inc_cord_y
+                        i64 k = slot_end - (i64)(get_cord_y(nv) & ((1ULL << 15) - 1));
+                        u64 val = create_cord(i, (u64)j + const_anchor_zero, shape.YValue, shape.strand);
+                        // the head slot doubles as the fill counter until its own (last) entry lands: that store must not tear
+                        // against another thread's increment, so it is an atomic exchange of the whole word
+                        if (k == slot_str) __atomic_store_n(&hs[k], val, __ATOMIC_RELAXED); else hs[k] = val;
+                        preVal = shape.XValue;
+                        last_j = j;
                     }
-                    count = 0;
                 }
+                count = 0;
             }
         }
     }
-    for (size_t i = 0; i + 1 < dir.size(); i++) {
+    u64 mism = 0;
+#pragma omp parallel for num_threads(build_threads) schedule(static, 1 << 16) reduction(+ : mism)
+    for (size_t i = 0; i < dir.size() - 1; i++) {
         if (dir[i + 1] > dir[i]) {
-            if (get_cord_id(hs[dir[i]]) >= seqs.size()) index.fill_mismatch++;
+            if (get_cord_id(hs[dir[i]]) >= seqs.size()) mism++;
             std::sort(hs.begin() + dir[i], hs.begin() + dir[i + 1]);
         }
     }
+    index.fill_mismatch = mism;
 }
 
 // ------------------------------------------------------------- features ----
@@ -1341,6 +1357,7 @@ void *orc_create(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq
     for (uint32_t i = 0; i < nseq; i++) ptrs.push_back(c->seqs[i].data());
     createDIndex(ptrs, c->lens, c->index, c->T);
     c->f2.resize(nseq);
+#pragma omp parallel for schedule(dynamic, 1)
     for (uint32_t i = 0; i < nseq; i++) createFeatures2_48_par(ptrs[i], (i64)lens[i], c->f2[i], c->T);
     return c;
 }

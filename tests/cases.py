@@ -51,13 +51,25 @@ def case_edge():
     return refs, reads, off
 
 
+def case_scale():
+    """Scale pin: 24 sequences, the first 262.5 Mb (longer than chr1: x + 2^20 beyond 2^28, 8 800 binning
+    bins, 37 M index entries), ids up to 23, reads from both ends of the big sequence, chimeras big-end + sequence 23."""
+    refs = synth.scale_refs()
+    reads, off = synth.scale_reads(refs)
+    return refs, reads, off
+
+
 CASES = {
     # name: (builder, [T layouts])
     "c1": (case_c1, [1]),
     "ont": (case_ont, [1, 4]),
     "rep": (case_rep, [1, 8]),
     "edge": (case_edge, [1, 3]),
+    "scale": (case_scale, [4]),
 }
+
+# reads whose per-stage outputs are stored (default: the first N_STAGE_READS mappable reads)
+STAGE_IDX = {"scale": [0, 45, 85, 100, 119, 125, 131, 160, 163, 166, 167]}
 
 N_STAGE_READS = 6   # reads per case whose per-stage outputs are stored
 

@@ -32,7 +32,10 @@ def main():
     assert pyorc.have_ref(), "oracle/_ref not built (no /root/reference?)"
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    only = sys.argv[1:]
     for name, (builder, layouts) in cases.CASES.items():
+        if only and name not in only:
+            continue
         refs, reads, off = builder()
         n = off.size - 1
         for T in layouts:
@@ -60,6 +63,8 @@ def main():
             # for the edge case take a spread of the edge reads as well
             if name == "edge":
                 idx = [i for i in range(n) if int(off[i + 1] - off[i]) > 200][:16]
+            if name in cases.STAGE_IDX:
+                idx = cases.STAGE_IDX[name]
             d["stage_reads"] = np.array(idx)
             for k, i in enumerate(idx):
                 rd = reads[int(off[i]):int(off[i + 1])]
