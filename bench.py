@@ -1,147 +1,271 @@
 #!/usr/bin/env python3
-"""bench.py -- reads/sec of the `linear filter` hot path on MI355X (BASELINE.json metric).
+"""bench.py -- reads/sec of the `linear filter` hot path on MI355X (BASELINE.json metric: "reads/sec (whole node) + HBM GB/s
+on seed lookup, 10 kb reads vs GRCh38").
 
-Workload (N = 1): BASELINE.json configs[1] -- 100 000 synthetic 10 kb ONT-error-profile reads (10 % errors,
-40/30/30 sub/del/ins, 50 % reverse-complemented) against chr22, `-f 2 -i 1`, `-g 0` (apxMap only; the gap
-re-mapper is next tier).  No genome file or network exists on the box, so chr22 is the seeded stand-in
-`synth.chr22_like` (same length, leading N arm, human-like repeat spectrum); `config.workload` says so.
+Workload (N = 1, the default): BASELINE.json configs[2] -- synthetic 10 kb ONT-error-profile reads (10 % errors, 40/30/30
+sub/del/ins, 50 % reverse-complemented) against the full GRCh38 primary assembly, `-f 2 -i 1`, `-g 0`.  No genome file or
+network exists on the box, so GRCh38 is the seeded stand-in `synth_torch.grch38_like_cuda` (24 sequences with the human
+chromosome lengths, 3.09 Gb, N runs, repeat families, tandem repeats, segmental duplications) generated in HBM;
+`config.workload` says so.  Every step filters a DIFFERENT batch of 100 000 reads (steps + warmup distinct batches, at most 16
+resident; 1 M reads = 10 steps).  `--workload chr22` is configs[1] (the round-1 line), `--workload small` a plumbing check.
 
-One step = one pass of the whole hot path (read prep + features + seed lookup + filter/chain/extend + block
-chaining -> cords) over one batch of reads that is already resident in HBM.  Index build (and, for N > 1, its RCCL
-broadcast) is done once before the timed region and reported in `config`.
+One step = one pass of the whole hot path (read prep + features + seed lookup + filter / chain / extend + block chaining ->
+cords) over one batch already resident in HBM.  Index build (and, for N > 1, its RCCL broadcast) happens once before the
+timed region and is reported in `config`.
 
-N > 1: one process per GPU (torch.distributed.run); rank 0 builds the packed index and broadcasts it over
-RCCL/xGMI; every rank then filters its own batch (weak scaling: per-GPU batch fixed, no data-path collective).
+N > 1: one process per GPU.  Launched either by the driver through torch.distributed.run, or by `python bench.py --gpus N`
+itself: with no WORLD_SIZE in the environment this script starts the N ranks as a child torch.distributed.run BEFORE any GPU
+call and relays rank 0's JSON line.  Rank 0 builds the packed index and broadcasts it over RCCL/xGMI; every rank then filters
+its own batches (weak scaling: per-GPU batch fixed, no data-path collective).
+
+CPU baseline (rank 0, N = 1): the REAL reference (oracle/_ref/libref_linear.so, the reference's own translation units compiled
+by oracle/Makefile; `kind: "reference"`) running its calculator loop on all host cores the process may use; where that library
+is absent the bit-exact restatement oracle/lnr_oracle.cpp (`kind: "port"`).  Test infrastructure, used here as the checker and
+as the timed CPU leg only.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_INT_PEAK_TOPS = 78.6    # same guide: 157.3 TFLOP/s fp32 vector = 2 x 78.6 T lane-operations/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
+DP_OPS_PER_PAIR = 31         # VALU instructions of one chaining-DP predecessor step without a candidate
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def recorded_traffic(args, launches_per_step):
-    """HBM-side bytes per k_seed_fused launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_seed_fused.json,
-    made by tools/pmc_summary.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  Counters cannot
-    be read from inside the process, so the figure is only reported when the workload is the one the passes were taken on."""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_seed_fused.json")
+def host_cores() -> tuple[int, str]:
+    """Cores this process may use: the affinity mask, cut by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"affinity mask {n} logical CPUs"
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            lim = max(1, int(int(q) / int(p)))
+            if lim < n:
+                n, note = lim, f"cgroup quota {lim} CPUs"
+    except Exception:
+        pass
+    return n, note
+
+
+def spawn_ranks(args) -> int:
+    """`bench.py --gpus N` without a launcher: start the N ranks (fresh processes, nothing here has touched the GPU) and relay
+    the one JSON line rank 0 prints."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for raw in p.stdout:
+        t = raw.decode(errors="replace").strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            log(t)
+    rc = p.wait()
+    if line:
+        print(line, flush=True)
+    return rc if rc else (0 if line else 1)
+
+
+def recorded_traffic(workload_key: dict, launches_per_step: float):
+    """HBM-side bytes per seed-lookup launch from the committed rocprofv3 PMC passes (profiles/r02/pmc_seed.json, made by
+    tools/pmc_summary.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  Counters cannot be read
+    from inside the process, so the figure is only reported when the workload is the one the passes were taken on."""
+    p = os.path.join(ROOT, "profiles", "r02", "pmc_seed.json")
     if not os.path.exists(p):
         return None
     rec = json.load(open(p))
-    key = {"reads": args.reads, "read_len": args.read_len, "err": args.err, "layout_threads": args.layout_threads,
-           "small": bool(args.small), "seed_only": bool(args.seed_only)}
-    if rec.get("workload") != key or abs(rec.get("launches_per_step", 0) - launches_per_step) > 1e-9:
+    if rec.get("workload") != workload_key or abs(rec.get("launches_per_step", 0) - launches_per_step) > 1e-9:
         return None
     return {"bytes_per_launch": rec["traffic_bytes_per_launch"], "source": rec["source"]}
+
+
+def padded_layout(seq_len):
+    """Start offsets of the sequences inside the library's genome blob (lnr_api.hip set_index_layout: each sequence is
+    followed by at least 64 zero bytes and starts 64-byte aligned)."""
+    starts, o = [], 0
+    for L in seq_len:
+        starts.append(o)
+        o += (int(L) + 64 + 63) // 64 * 64
+    return starts
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["grch38", "chr22", "small"], default="grch38")
+    ap.add_argument("--scale", type=float, default=1.0, help="grch38 only: scale of the chromosome lengths")
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--err", type=float, default=0.10)
-    ap.add_argument("--layout-threads", type=int, default=1, help="reference -t whose index layout is reproduced")
-    ap.add_argument("--cpu-sample", type=int, default=16_000, help="reads of the same workload timed on the host cores with the oracle")
+    ap.add_argument("--layout-threads", type=int, default=0, help="reference -t whose index layout is reproduced (0 = the host cores the CPU baseline runs on)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the timed CPU sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed-only", action="store_true", help="time only stage a7 (seed lookup) -- used for the roofline profile")
-    ap.add_argument("--small", action="store_true", help="tiny reference/batch (plumbing check)")
+    ap.add_argument("--small", action="store_true", help="alias of --workload small")
     args = ap.parse_args()
+    if args.small:
+        args.workload = "small"
+    if args.workload == "small":
+        args.reads = min(args.reads, 2000)
 
-    # stdout carries exactly one JSON line: everything else (RCCL prints a version banner to stdout at init) goes to stderr
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+
+    # stdout carries exactly one JSON line: everything else (RCCL's banner, the reference's progress lines) goes to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    double = bool(os.environ.get("LNR_BENCH_DOUBLE"))   # CPU rehearsal of the N > 1 plumbing (tests/test_bench_cli_cpu.py): gloo + a test double
+
+    import numpy as np
+    import torch
     import torch.distributed as dist
+    if double:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+    def sync():
+        if not double:
+            torch.cuda.synchronize()
+
     use_dist = world > 1 or bool(os.environ.get("LNR_BENCH_DIST_AT_1"))   # the env switch rehearses the N>1 plumbing on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if world == 1:
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if double:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    from linear_amd import build as lb
-    if local_rank == 0:
-        lb.build()
-    if use_dist:
-        dist.barrier()
-    from linear_amd import Filter, synth
+    cores, cores_note = host_cores()
+    if args.cpu_threads:
+        cores = args.cpu_threads
+    T = args.layout_threads or cores
+
     from linear_amd import dist as ldist
-    from linear_amd.synth_torch import sample_reads_cuda
-
-    # ---- reference + index (outside the timed region)
-    t0 = time.time()
-    if args.small:
-        ref = synth.repeat_ref(2_000_000, 99)
-        non_n = 0
-        ref_name = "synthetic 2 Mb repeat-rich reference (--small)"
+    if double:
+        from tests.bench_double import FilterDouble as Filter, make_genome, sample_reads
     else:
-        ref = synth.chr22_like()
-        non_n = 10_510_000
-        ref_name = "chr22 stand-in synth.chr22_like(seed 2022): 50 818 468 bp, 10.5 Mb leading N, human-like repeat spectrum"
-    t_ref = time.time() - t0
+        from linear_amd import build as lb
+        if local_rank == 0:
+            lb.build()
+        if use_dist:
+            dist.barrier()
+        from linear_amd import Filter
+        from linear_amd.synth_torch import grch38_like_cuda, sample_reads_multi_cuda
+
+    # ---- reference + index (outside the timed region); rank 0 owns the build
     flt = Filter(device=local_rank)
-    index_s, bcast = 0.0, None
+    index_s, bcast, t_ref, ref_name, info = 0.0, None, 0.0, "", None
+    host_genome = None     # [numpy per sequence] for the CPU baseline (rank 0, N = 1)
+    if args.workload == "grch38":
+        ref_name = (f"GRCh38 stand-in synth_torch.grch38_like_cuda(seed 38, scale {args.scale:g}): 24 sequences with the human chromosome lengths, "
+                    "N runs (telomeres, centromeres, acrocentric arms), 1500 repeat families over ~45 %, tandem repeats, segmental duplications")
+    elif args.workload == "chr22":
+        ref_name = "chr22 stand-in synth.chr22_like(seed 2022): 50 818 468 bp, 10.5 Mb leading N, human-like repeat spectrum"
+    else:
+        ref_name = "synthetic 2 Mb repeat-rich reference (--workload small)"
     if rank == 0:
         t0 = time.time()
-        info = flt.build_index([ref], args.layout_threads)
-        index_s = time.time() - t0
-        log(f"[bench] reference generated in {t_ref:.1f}s; index built in {index_s:.2f}s wall ({info.build_ms:.1f} ms device): hs {info.hs_len}, samples {info.n_samples}, f2 {info.f2_len}")
-    if use_dist:
-        bcast = ldist.broadcast_index(flt, 0, dev)
-        if rank == 0:
-            log(f"[bench] index broadcast: {bcast['bytes'] / 1e9:.2f} GB in {bcast['seconds'] * 1e3:.1f} ms ({bcast['bytes'] / 1e9 / max(bcast['seconds'], 1e-9):.1f} GB/s)")
-
-    # ---- reads of this rank, generated in HBM
-    d_ref = torch.from_numpy(ref).to(dev)
-    t0 = time.time()
-    d_reads, d_off = sample_reads_cuda(d_ref, args.reads, args.read_len, args.err, 777 + rank, non_n_start=non_n)
-    torch.cuda.synchronize()
-    log(f"[bench] rank {rank}: {args.reads} reads x {args.read_len} bp generated on device in {time.time() - t0:.1f}s")
-    del d_ref
-
-    def step():
-        if args.seed_only:
-            flt.seed_lookup_batch_dev(d_reads.data_ptr(), d_off.data_ptr(), args.reads)
+        if double:
+            seqs = make_genome()
+            t_ref = time.time() - t0
+            t0 = time.time()
+            info = flt.build_index(seqs, T)
+        elif args.workload == "grch38":
+            gen, offs = grch38_like_cuda(dev, seed=38, scale=args.scale)
+            sync()
+            t_ref = time.time() - t0
+            t0 = time.time()
+            info = flt.build_index_ptrs([gen.data_ptr() + o for o in offs[:-1]], [offs[i + 1] - offs[i] for i in range(len(offs) - 1)], T)
+            if world == 1 and not args.no_cpu_baseline and not args.seed_only:
+                h = gen.cpu().numpy()
+                host_genome = [h[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+            del gen
         else:
-            flt.filter_batch_dev(d_reads.data_ptr(), d_off.data_ptr(), args.reads)
+            from linear_amd import synth
+            seqs = [synth.chr22_like()] if args.workload == "chr22" else [synth.repeat_ref(2_000_000, 99)]
+            t_ref = time.time() - t0
+            t0 = time.time()
+            info = flt.build_index(seqs, T)
+            host_genome = seqs
+        index_s = time.time() - t0
+        log(f"[bench] reference generated in {t_ref:.1f}s; index built in {index_s:.2f}s wall ({info.build_ms:.1f} ms device): "
+            f"{info.nseq} sequences, hs {info.hs_len}, samples {info.n_samples}, f2 {info.f2_len}, layout -t {T}")
+    if use_dist:
+        bcast = ldist.broadcast_index(flt, 0, "cpu" if double else dev)
+        if rank == 0:
+            log(f"[bench] index broadcast to {dist.get_world_size()} ranks: {bcast['bytes'] / 1e9:.2f} GB in {bcast['seconds'] * 1e3:.1f} ms "
+                f"({bcast['bytes'] / 1e9 / max(bcast['seconds'], 1e-9):.1f} GB/s)")
+    info = flt.index_info()
+    index_bytes = int(sum(b for _, b in flt.index_blobs()))
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    # ---- this rank's read batches, generated in HBM from the library's own copy of the genome (every rank has it after the broadcast)
+    nb = max(1, min(args.steps + args.warmup, 16))
+    seq_len = [int(v) for v in flt.seq_len()]
+    t0 = time.time()
+    if double:
+        batches = [sample_reads(args.reads, 1000 * rank + b) for b in range(nb)]
+    else:
+        starts = padded_layout(seq_len)
+        gp, gb = flt.index_blobs()[0]
+        gview = ldist.blob_tensor(gp, gb, dev)
+        non_n = [starts[0] + 10_510_000] + starts[1:] if args.workload == "chr22" else starts
+        batches = [sample_reads_multi_cuda(gview, non_n, args.reads, args.read_len, args.err, 777 + 1000 * rank + b,
+                                           ends=[s + L for s, L in zip(starts, seq_len)]) for b in range(nb)]
+        sync()
+    log(f"[bench] rank {rank}: {nb} distinct batches of {args.reads} reads x {args.read_len} bp generated on device in {time.time() - t0:.1f}s")
+
+    def step(k):
+        r, o = batches[k % nb]
+        if args.seed_only:
+            flt.seed_lookup_batch_dev(r.data_ptr(), o.data_ptr(), args.reads)
+        else:
+            flt.filter_batch_dev(r.data_ptr(), o.data_ptr(), args.reads)
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     acc = {}
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(args.warmup + k)
         st = flt.stats()
-        for k, v in st.items():
-            acc[k] = acc.get(k, 0) + v
-    torch.cuda.synchronize()
+        for key, v in st.items():
+            acc[key] = acc.get(key, 0) + v
+    sync()
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -150,19 +274,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    st = flt.stats()
     K = max(args.steps, 1)
-    # k_seed_fused: one launch per round (round 0 = whole reads, round 1 = the re-mapped gaps); timed by the library with
-    # HIP events recorded on the stream the kernel is launched on (lnr_api.hip run_jobs, Timer t_sc)
+    total_reads = args.reads * K
+    # seed lookup: one launch per round (round 0 = whole reads, round 1 = the re-mapped gaps); timed by the library with HIP
+    # events recorded on the stream the kernels are launched on (lnr_api.hip seed_jobs, Timer t_seed)
     launches = max(int(acc["seed_count_launches"]), 1)
     seed_ms = acc["seed_count_ms"] / launches
     seed_bytes = acc["seed_bytes"] / launches
     achieved = seed_bytes / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
-    traffic = recorded_traffic(args, launches / K)
+    wl_key = {"workload": args.workload, "scale": args.scale, "reads": args.reads, "read_len": args.read_len, "err": args.err,
+              "layout_threads": T, "seed_only": bool(args.seed_only)}
+    traffic = recorded_traffic(wl_key, launches / K)
+    dev_rate = args.reads * world * args.steps / dt
 
     out = {
         "metric": "reads/sec (whole node) + HBM GB/s on seed lookup, 10 kb reads vs GRCh38",
-        "value": args.reads * world * args.steps / dt,
+        "value": dev_rate,
         "unit": "reads/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -174,22 +301,30 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.reads} synthetic {args.read_len} bp ONT-profile reads per GPU per step ({args.err:.0%} errors 40/30/30 sub/del/ins, 50% revcomp) vs {ref_name}; "
-                        f"linear filter -f 2 -i 1 -g 0 -p 1, index layout -t {args.layout_threads}" + ("; SEED LOOKUP STAGE ONLY" if args.seed_only else ""),
+            "workload": f"{args.reads} synthetic {args.read_len} bp ONT-profile reads per GPU per step, a different batch every step ({args.err:.0%} errors 40/30/30 sub/del/ins, "
+                        f"50% revcomp) vs {ref_name}; linear filter -f 2 -i 1 -g 0 -p 1, index layout -t {T}" + ("; SEED LOOKUP STAGE ONLY" if args.seed_only else ""),
+            "baseline_config": {"grch38": "configs[2] (10 kb ONT reads vs full GRCh38; 1 M reads = 10 steps of 100 k)", "chr22": "configs[1]", "small": "plumbing"}[args.workload],
             "reads_per_gpu_per_step": args.reads,
+            "distinct_batches": nb,
             "read_len": args.read_len,
             "parallelism": f"read-sharded x{world}, index built on rank 0" + (" + RCCL broadcast" if world > 1 else ""),
+            "ranks_reported_by_backend": dist.get_world_size() if use_dist else 1,
+            "reference_generation_s": round(t_ref, 2),
             "index_build_s": round(index_s, 3),
+            "index_build_device_ms": round(float(info.build_ms), 1),
             "index_broadcast_s": round(bcast["seconds"], 4) if bcast else None,
-            "index_bytes": bcast["bytes"] if bcast else None,
-            "per_read": {"samples": st["samples"] / args.reads, "lookups": st["lookups"] / args.reads, "bucket_entries": st["bucket_entries"] / args.reads,
-                         "anchors": st["anchors"] / args.reads, "cords": st["cords"] / args.reads, "remap_reads": st["remap_reads"]},
+            "index_bytes": index_bytes,
+            "index": {"nseq": int(info.nseq), "genome_bytes": int(info.genome_bytes), "hs_len": int(info.hs_len), "dir_len": int(info.dir_len),
+                      "f2_len": int(info.f2_len), "samples": int(info.n_samples), "layout_threads": int(T)},
+            "per_read": {"samples": acc["samples"] / total_reads, "lookups": acc["lookups"] / total_reads, "bucket_entries": acc["bucket_entries"] / total_reads,
+                         "anchors": acc["anchors"] / total_reads, "cords": acc["cords"] / total_reads, "remap_reads_per_step": acc["remap_reads"] / K},
             "stage_ms_per_step": {"prep": acc["prep_ms"] / K, "seed": acc["seed_count_ms"] / K,
                                   "job": acc["job_ms"] / K, "tail": acc["tail_ms"] / K, "total_device": acc["total_ms"] / K},
+            "device_resident_reads_per_s": dev_rate,
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_seed_fused (minimizers of the 2-bit packed read -> bucket bitmap -> dir -> hs -> Y filter -> anchors), "
+            "kernel": "seed lookup stage a3/a4/a7 (minimizers of the 2-bit packed read -> bucket lookup -> Y filter -> anchors), "
                       f"{launches / K:g} launches per step, averages per launch",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -202,42 +337,79 @@ def main():
         },
     }
 
-    # ---- CPU baseline + parity of the sample (rank 0, N = 1 only)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.seed_only:
+    parity_ok = True
+    if rank == 0 and world == 1 and not double and not args.seed_only:
+        # ---- the drop-in entry point as the caller sees it: host reads in -> host cords out (PCIe both ways); never `value`
+        hb = [(batches[k][0].cpu().numpy(), batches[k][1].cpu().numpy().astype(np.uint64)) for k in range(min(2, nb))]
+        flt.filter_batch(*hb[0])
+        t0 = time.perf_counter()
+        for r_, o_ in hb:
+            flt.filter_batch(r_, o_)
+        host_rate = args.reads * len(hb) / (time.perf_counter() - t0)
+        out["config"]["host_path_reads_per_s"] = host_rate
+        log(f"[bench] host-buffer entry point lnr_filter_batch (pageable reads in, cords out, PCIe both ways): {host_rate:.0f} reads/s")
+
+    if rank == 0 and world == 1 and not double and not args.no_cpu_baseline and not args.seed_only and host_genome is not None:
+        # ---- CPU baseline + parity on a bounded sample of batch 0
         from oracle import pyorc
         pyorc.build(ref=False)
-        ns = min(args.cpu_sample, args.reads)
-        cores = min(os.cpu_count() or 1, 16)
-        h_reads = d_reads[: ns * args.read_len].cpu().numpy()
-        h_off = d_off[: ns + 1].cpu().numpy().astype(np.uint64)
+        kind = "ref" if pyorc.have_ref() else "oracle"
         t0 = time.time()
-        orc = pyorc.Checker("oracle", [ref], args.layout_threads)
-        t_oidx = time.time() - t0
-        orc.map_batch(h_reads[: 64 * args.read_len], h_off[:65], threads=cores)   # warm the thread pool
-        t0 = time.time()
-        ooff, ocs, oce, ost = orc.map_batch(h_reads, h_off, threads=cores)
-        t_cpu = time.time() - t0
-        coff, cs, ce = flt.filter_batch(h_reads, h_off)
-        same = bool(np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce))
-        out["cpu_baseline"] = {"value": ns / t_cpu, "unit": "reads/s", "cores": cores, "kind": "port",
-                               "sample": f"first {ns} reads of the same batch, oracle/lnr_oracle.cpp (bit-exact restatement of the reference) with {cores} OpenMP threads; "
-                                         f"{t_cpu:.2f} s wall; its index build ({t_oidx:.1f} s, 1 thread) not included",
-                               "pair_evals_per_read": float(ost[4]) / ns}
-        out["parity"] = {"checked_reads": ns, "bit_exact_vs_oracle": same}
-        log(f"[bench] cpu baseline {ns / t_cpu:.0f} reads/s on {cores} cores; GPU/oracle parity on the sample: {same}")
-        if not same:
+        chk = pyorc.Checker(kind, host_genome, T)
+        t_cidx = time.time() - t0
+        h_reads = batches[0][0].cpu().numpy()
+        h_off = batches[0][1].cpu().numpy().astype(np.uint64)
+
+        def cpu_run(n0, n1):
+            rr = h_reads[int(h_off[n0]):int(h_off[n1])]
+            oo = h_off[n0:n1 + 1] - h_off[n0]
+            t0 = time.time()
+            res = chk.map_batch(rr, oo, threads=cores)
+            return time.time() - t0, res, rr, oo
+        pilot = min(args.reads, max(4 * cores, 256))
+        tp, _, _, _ = cpu_run(0, pilot)
+        ns = int(min(args.reads, max(pilot, pilot * args.cpu_seconds / max(tp, 1e-3))))
+        t_cpu, (ooff, ocs, oce, ost), rr, oo = cpu_run(0, ns)
+        coff, cs, ce = flt.filter_batch(rr, oo)
+        parity_ok = bool(np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce))
+        label = ("the reference itself: oracle/_ref/libref_linear.so = the reference's own translation units (base, cords, shape_extend, index_util, "
+                 "cluster_util, pmpfinder) compiled by oracle/Makefile, calculator loop of Mapper::p_calRecords with -g 0") if kind == "ref" else \
+                "oracle/lnr_oracle.cpp (bit-exact restatement of the reference)"
+        out["cpu_baseline"] = {"value": ns / t_cpu, "unit": "reads/s", "cores": cores, "kind": "reference" if kind == "ref" else "port",
+                               "sample": f"first {ns} reads of batch 0, {label}, {cores} OpenMP threads ({cores_note}); {t_cpu:.2f} s wall; "
+                                         f"its index + genome features build ({t_cidx:.1f} s, -t {T}) not included"}
+        out["parity"] = {"checked_reads": ns, "bit_exact": parity_ok, "against": out["cpu_baseline"]["kind"]}
+        log(f"[bench] cpu baseline ({kind}) {ns / t_cpu:.0f} reads/s on {cores} threads; GPU parity on the sample: {parity_ok}")
+        # secondary roofline: chaining-DP predecessor pairs per second next to the VALU integer peak.  Pair counts
+        # come from the restatement's counter on a slice of the sample (the reference has no counter).
+        if kind == "ref":
+            orc = pyorc.Checker("oracle", host_genome, T)
+            n2 = min(ns, 2000)
+            _, _, _, ost = orc.map_batch(rr[: int(oo[n2])], oo[: n2 + 1], threads=cores)
+            pairs_per_read = float(ost[4]) / n2
+            orc.close()
+        else:
+            pairs_per_read = float(ost[4]) / ns
+        job_s = acc["job_ms"] / K * 1e-3
+        pair_rate = pairs_per_read * args.reads / job_s if job_s > 0 else 0.0
+        peak_pairs = VALU_INT_PEAK_TOPS * 1e12 / DP_OPS_PER_PAIR
+        out["roofline_secondary"] = {"bound": "valu-int", "kernel": "per-read job kernels (a8-a16; the chaining DP is ~40 % of their VALU work)",
+                                     "achieved": pair_rate / 1e9, "peak": peak_pairs / 1e9, "unit": "G predecessor pairs/s", "frac": pair_rate / peak_pairs,
+                                     "pairs_per_read": pairs_per_read,
+                                     "note": f"peak = {VALU_INT_PEAK_TOPS} T lane-ops/s / {DP_OPS_PER_PAIR} VALU instructions per pair; achieved = pairs of one step / job-kernel time of one step"}
+        if not parity_ok:
             log("[bench] PARITY FAILURE on the bench sample")
-        # PCIe-inclusive rate of the host-buffer entry point, for DESIGN.md (never `value`)
-        t0 = time.time()
-        flt.filter_batch(h_reads, h_off)
-        log(f"[bench] host-buffer entry point (PCIe in/out) on the {ns}-read sample: {ns / (time.time() - t0):.0f} reads/s")
+        chk.close()
 
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     flt.close()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if not parity_ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -56,7 +56,7 @@ typedef struct lnr_opts {
     uint32_t preset;           /* -p : 1 (reference default: chain stop ratio 0) */
     uint32_t gap_len;          /* -g : must be 0 here (apxMap only; gap re-mapper is next tier) */
     uint32_t reserved0;
-    uint64_t scratch_budget;   /* max bytes of per-read device scratch in flight (0 = default 24 GiB) */
+    uint64_t scratch_budget;   /* max bytes of per-read device scratch in flight (0 = default 64 GiB of the 288 GB) */
 } lnr_opts;
 
 typedef struct lnr_index_info {
@@ -112,8 +112,10 @@ void lnr_destroy(lnr_ctx *ctx);
 const char *lnr_strerror(lnr_status s);
 const char *lnr_last_error(const lnr_ctx *ctx);   /* detail of the last failure on this context */
 
-/* Index + genome features from host sequences.  layout_threads = the reference's -t whose
- * DIndex layout is to be reproduced (index content depends on it: index_util.cpp:1652-1700). */
+/* Index + genome features from the reference sequences.  seq[i] may point to host memory (`&genome[i][0]` of the
+ * StringSet<String<Dna5>>) or to device memory (a genome already resident in HBM); the pointer array itself is a host array.
+ * layout_threads = the reference's -t whose DIndex layout is to be reproduced (index content depends on it:
+ * index_util.cpp:1652-1700). */
 lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64_t *len, uint32_t nseq, uint32_t layout_threads);
 lnr_status lnr_index_info_get(const lnr_ctx *ctx, lnr_index_info *info);
 /* Copy the index to host arrays (any pointer may be NULL).  f2 is written as 3 x int32 per entry. */

@@ -125,6 +125,14 @@ class Filter:
         self._seq_len = lens
         return self.index_info()
 
+    def build_index_ptrs(self, ptrs: list[int], lens: list[int], layout_threads: int = 1) -> "LnrIndexInfo":
+        """Sequences given as raw addresses (host or device memory, e.g. slices of a torch tensor in HBM)."""
+        arr = (_u8p * len(ptrs))(*[C.cast(C.c_void_p(int(p)), _u8p) for p in ptrs])
+        lens = np.array(lens, dtype=np.uint64)
+        self._ck(self.lib.lnr_index_build(self.h, arr, _p(lens, _u64p), len(ptrs), layout_threads))
+        self._seq_len = lens
+        return self.index_info()
+
     def index_info(self) -> "LnrIndexInfo":
         info = LnrIndexInfo()
         self._ck(self.lib.lnr_index_info_get(self.h, C.byref(info)))

@@ -367,7 +367,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
     Laps laps;
     u32 nj = hj.size();
     hipStream_t sm = ctx->s_multi[lane], sb = ctx->s_bulk[lane];
-    u64 budget = ctx->opts.scratch_budget ? ctx->opts.scratch_budget : (24ULL << 30);
+    u64 budget = ctx->opts.scratch_budget ? ctx->opts.scratch_budget : (64ULL << 30);
     const std::vector<u32> &nanc = S.nanc;
     std::vector<u64> w(ngrp, 0);
     for (u32 k = 0; k < ngrp; k++) for (u32 j = hj.grp_beg[groups[k]]; j < hj.grp_beg[groups[k] + 1]; j++) w[k] += nanc[j];
@@ -433,9 +433,11 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         A.read_err = ctx->read_err.as<i32>();
         A.nbins = ctx->nbins; A.grp_lo = g0; A.grp_hi = g1;
         A.prof = nullptr; A.tl = nullptr; A.jstate = Lx.jstate.as<u32>(); A.stop_after = ctx->stop_after;
-        size_t lds_min = (((size_t)((ctx->nbins + 1) / 2) * 4) + 15) & ~(size_t)15;
+        // dynamic LDS = the job arena; the binning histogram borrows it first and sweeps the bin range in passes of that many
+        // bins, so the LDS per workgroup (hence the residency of the bulk kernel) does not depend on the reference's length
+        const size_t lds_min = 4096;                 // the split path's pre / post kernels keep every array in global scratch
         size_t arena = (ctx->job_lds_bytes + 15) & ~(size_t)15;
-        size_t lds = std::max<size_t>(lds_min, arena + ctx->job_stage_bytes);
+        size_t lds = arena + ctx->job_stage_bytes;
         A.lds_bytes = (u32)lds;
         A.arena_lds = (u32)arena;
         // size classes along the (weight-descending) slice: heavy = 16 waves per read, mid = 4 waves, rest = 1 wave
@@ -472,7 +474,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         if (fork_m || fork_b) HIPCK(hipEventRecord(ctx->ev_fork[lane], sm));    // before any launch: nobody waits for another kernel
         if (gh > g0) {
             JobArgs H = A;
-            size_t hl = std::max<size_t>(lds_min, (size_t)ctx->heavy_lds_kb * 1024);
+            size_t hl = (size_t)ctx->heavy_lds_kb * 1024;
             H.grp_lo = g0; H.grp_hi = gh; H.lds_bytes = (u32)hl; H.arena_lds = (u32)hl;
             hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, sm, H);
             KCHECK();
@@ -503,7 +505,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         }
         if (gm > gs) {
             JobArgs M = A;
-            size_t ml = std::max<size_t>(lds_min, (size_t)ctx->mid_lds_kb * 1024);
+            size_t ml = (size_t)ctx->mid_lds_kb * 1024;
             M.grp_lo = gs; M.grp_hi = gm; M.lds_bytes = (u32)ml; M.arena_lds = (u32)ml;
             hipLaunchKernelGGL(k_job_mid, dim3(gm - gs), dim3(256), ml, s4, M);
             KCHECK();
@@ -1047,7 +1049,7 @@ lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64
     ENSURE(ctx->g, ctx->info.genome_bytes + 64);
     HIPCK(hipMemsetAsync(ctx->g.p, 0, ctx->info.genome_bytes + 64, ctx->stream));
     for (u32 i = 0; i < nseq; i++)
-        if (len[i]) HIPCK(hipMemcpyAsync(ctx->g.as<u8>() + ctx->seq_off[i], seq[i], len[i], hipMemcpyHostToDevice, ctx->stream));
+        if (len[i]) HIPCK(hipMemcpyAsync(ctx->g.as<u8>() + ctx->seq_off[i], seq[i], len[i], hipMemcpyDefault, ctx->stream));   // host or device source
     Timer tm; tm.init();
     tm.start(ctx->stream);
     // chunks of the T-thread layout (index_util.cpp:1654-1666)

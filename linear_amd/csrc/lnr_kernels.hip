@@ -663,7 +663,7 @@ struct JobArgs {
     GenomeFeat g;
     u64 *cords; const u64 *cords_off; const u32 *cords_cap; u32 *ncords; i32 *read_err;
     u32 nbins; u32 grp_lo, grp_hi;
-    u32 lds_bytes;          // dynamic LDS per block: binning histogram first, then the fast half of the job arena
+    u32 lds_bytes;          // dynamic LDS per block: binning histogram (swept in passes of lds_bytes bins) first, then the fast half of the job arena
     u32 arena_lds;          // bytes of that LDS the job arena may use
     u32 stop_after;         // diagnostic (LNR_STOP_AFTER, single-wave kernel only): leave the job after phase stop_after - 1; 0 = run everything
     u32 *jstate;            // split path: per job {anchors after binning, anchors after the list filter | ok << 31} handed from the pre to the DP / post kernel
@@ -671,30 +671,55 @@ struct JobArgs {
     unsigned long long *tl;     // diagnostic build only: per launch position {start, end (100 MHz ticks), hw id, anchors in the DP}
 };
 
-// wave-parallel twin of binning_filter_serial: LDS histogram of anchor x-field / 30000 (saturating u16
-// halves of u32 words), order-preserving ballot compaction.
-__device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 nbins) {
+// wave-parallel twin of binning_filter_serial (binningFilter, pmpfinder.cpp:1979-2012): histogram of anchor x-field / 30000,
+// anchors in bins of more than 10 are kept, order preserved (ballot compaction).
+// The histogram lives in `hist_bytes` bytes of LDS, one saturating byte per bin.  A reference sequence of length G has
+// (G + 2^21) / 30000 bins -- 8 350 for chr1, up to 35 800 at the format limit -- so the bin range is swept in passes of
+// hist_bytes bins: the LDS a job workgroup needs does not depend on the reference (it did in round 1, and cut the
+// residency of the bulk kernel at human scale).  With more than one pass the anchors of a kept bin are marked in place
+// (bit 63, unused by the anchor format cords.cpp:319-322) and the compaction strips the mark.
+#define BIN_SAT 100u   /* counts saturate here: only "more than 10" is asked.  At most 64 adds are in flight beyond it (one
+                          wave instruction; its undo is issued before the next add), so a byte never carries into its neighbour */
+__device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 hist_bytes, u32 nbins) {
     int lane = lane_id();
-    u32 nw = (nbins + 1) >> 1;
-    for (u32 w = lane; w < nw; w += 64) binw[w] = 0;
-    WSYNC();
-    for (u32 i0 = 0; i0 < n; i0 += 256) {   // four independent loads in flight per lane
-        u64 v[4];
+    const u64 MARK = 1ULL << 63;
+    u32 per = hist_bytes & ~3u;                         // bins per pass
+    u32 npass = (nbins + per - 1) / per;
+    for (u32 p = 0; p < npass; p++) {
+        u32 b_lo = p * per, b_n = nbins - b_lo < per ? nbins - b_lo : per;
+        for (u32 w = lane; w < (b_n + 3) / 4; w += 64) binw[w] = 0;
+        WSYNC();
+        for (u32 i0 = 0; i0 < n; i0 += 256) {   // four independent loads in flight per lane
+            u64 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { u32 i = i0 + 64 * u + (u32)lane; v[u] = i < n ? a[i] : ~0ULL; }
+            for (int u = 0; u < 4; u++) { u32 i = i0 + 64 * u + (u32)lane; v[u] = i < n ? a[i] : ~0ULL; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            u32 i = i0 + 64 * u + (u32)lane;
-            u32 b = (u32)(cord_x(v[u]) / 30000);
-            if (i < n && b < nbins) {
-                u32 inc = (b & 1) ? 0x10000u : 1u;
-                u32 old = atomicAdd(&binw[b >> 1], inc);
-                u32 half = (b & 1) ? (old >> 16) : (old & 0xffffu);
-                if (half >= 0x8000u) atomicSub(&binw[b >> 1], inc);   // saturate well below carry into the neighbour half
+            for (int u = 0; u < 4; u++) {
+                u32 i = i0 + 64 * u + (u32)lane;
+                u32 b = (u32)(cord_x(v[u]) / 30000) - b_lo;
+                if (i < n && b < b_n) {
+                    u32 sh = 8 * (b & 3), inc = 1u << sh;
+                    u32 old = atomicAdd(&binw[b >> 2], inc);
+                    if (((old >> sh) & 0xffu) >= BIN_SAT) atomicSub(&binw[b >> 2], inc);
+                }
+                WLDS();                         // this chunk's undo is issued before the next chunk's add
             }
         }
+        WSYNC();
+        if (npass == 1) break;
+        for (u32 i0 = 0; i0 < n; i0 += 256) {   // mark the anchors of this pass's kept bins
+            u64 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { u32 i = i0 + 64 * u + (u32)lane; v[u] = i < n ? a[i] : ~0ULL; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                u32 i = i0 + 64 * u + (u32)lane;
+                u32 b = (u32)(cord_x(v[u]) / 30000) - b_lo;
+                if (i < n && b < b_n && ((binw[b >> 2] >> (8 * (b & 3))) & 0xffu) > 10) a[i] = v[u] | MARK;
+            }
+        }
+        WSYNC();
     }
-    WSYNC();
     u32 ii = 0;
     // software pipeline: the next 256 anchors are in flight while this group of four chunks is compacted (in place: a
     // store lands at or below the chunk being compacted, i.e. below everything that is still to be read)
@@ -714,11 +739,13 @@ __device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 nbins) {
             u64 v = vc[u];
             bool keep = false;
             if (i < n) {
-                u32 b = (u32)(cord_x(v) / 30000);
-                if (b < nbins) { u32 w = binw[b >> 1]; keep = ((b & 1) ? (w >> 16) : (w & 0xffffu)) > 10; }
+                if (npass == 1) {
+                    u32 b = (u32)(cord_x(v) / 30000);
+                    if (b < nbins) keep = ((binw[b >> 2] >> (8 * (b & 3))) & 0xffu) > 10;
+                } else keep = (v & MARK) != 0;
             }
             u64 mask = __ballot(keep);
-            if (keep) a[ii + __popcll(mask & lanemask_lt())] = v;
+            if (keep) a[ii + __popcll(mask & lanemask_lt())] = v & ~MARK;
             ii += (u32)__popcll(mask);
         }
     }
@@ -1886,7 +1913,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             n = A.n_anchors[j];
             cap = n + 2;   // scratch is sized by the anchors that passed the Y filter (known before the launch), not by the bucket entries
             LNR_TICK(prof, 0, tk_);
-            n = binning_wave(ag, n, dyn_lds, A.nbins);   // uses the dynamic LDS as its histogram
+            n = binning_wave(ag, n, dyn_lds, A.lds_bytes, A.nbins);   // uses the dynamic LDS as its histogram
             LNR_TICK(prof, 1, tk_);
             if (NW == 1 && A.stop_after == 2) break;
             // two-level arena: dynamic LDS first (re-used once binning is done), the job's global scratch behind it

@@ -74,6 +74,8 @@ class Checker:
             L.orc_reset_stats.argtypes = [C.c_void_p]
             L.orc_get_stats.argtypes = [C.c_void_p, _u64p]
         else:
+            L.ref_map_batch.restype = C.c_uint64
+            L.ref_map_batch.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.c_int, _u64p, _u64p, _u64p, C.c_uint64]
             L.ref_stage.restype = C.c_uint64
             L.ref_stage.argtypes = [C.c_void_p, _u8p, C.c_uint64, C.c_int, _u64p, C.c_uint64]
         self._seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
@@ -140,8 +142,8 @@ class Checker:
         return cs[:n], ce[:n]
 
     def map_batch(self, reads: np.ndarray, off: np.ndarray, threads: int = 1):
-        """oracle only: CSR cords for a batch; returns (cord_off, cords_str, cords_end, stats5)."""
-        assert self.kind == "oracle"
+        """CSR cords for a batch on `threads` host threads; returns (cord_off, cords_str, cords_end, stats5).  The reference
+        (kind "ref") runs its own per-thread scratch as Mapper::p_calRecords does and has no counters (stats5 = zeros)."""
         reads = np.ascontiguousarray(reads, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         n = off.size - 1
@@ -150,6 +152,11 @@ class Checker:
         cs = np.zeros(cap, np.uint64)
         ce = np.zeros(cap, np.uint64)
         st = np.zeros(5, np.uint64)
+        if self.kind == "ref":
+            assert int(off[0]) == 0
+            tot = self.lib.ref_map_batch(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap)
+            assert tot <= cap, "cord capacity"
+            return coff, cs[:tot], ce[:tot], st
         tot = self.lib.orc_map_batch(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap, _p(st, _u64p))
         assert tot <= cap, "cord capacity"
         return coff, cs[:tot], ce[:tot], st

@@ -133,6 +133,51 @@ void ref_get_cords(void *h, uint64_t *cords_str, uint64_t *cords_end) {
     if (n) { memcpy(cords_str, &c->cs[0], n * 8); memcpy(cords_end, &c->ce[0], n * 8); }
 }
 
+// The reference's calculator loop over a block of reads (Mapper::p_calRecords, mapper.cpp:404-473 with -g 0): an OpenMP team,
+// per-thread scratch exactly as mapper.cpp:423-433 declares it (anchors, crhit, f1, apx_gaps, comStr and a private parameter
+// copy, because toggle() mutates it: mapper.cpp:233-237,447).  Used as the CPU baseline of bench.py (`kind: "reference"`).
+// Returns the total number of cords; cord_off[n+1] always, cords only while they fit `cap`.
+uint64_t ref_map_batch(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
+                       uint64_t *cords_str, uint64_t *cords_end, uint64_t cap) {
+    RefCtx *c = (RefCtx *)h;
+    std::vector<String<uint64_t> > CS(n), CE(n);
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        Anchors anchors;
+        String<uint64_t> hit;
+        String<UPair> gaps;
+        String<Dna5> com, r;
+        StringSet<FeaturesDynamic> f1;
+        resize(f1, 2);
+        f1[0].init(2);
+        f1[1].init(2);
+        PMPParms pm = c->pm;
+        GlobalParms pg = c->pg;
+#pragma omp for schedule(dynamic, 16)
+        for (uint32_t i = 0; i < n; i++) {
+            uint64_t len = off[i + 1] - off[i];
+            if (len <= 200) continue;                         // mapper.cpp:430,440
+            assign_padded(r, reads + off[i], len);
+            String<CordInfo> ci;
+            _compltRvseStr(r, com);
+            { uint64_t m = length(com); resize(com, m + PAD, Dna5(0)); resize(com, m); }
+            createFeatures(begin(r), end(r), f1[0]);
+            createFeatures(begin(com), end(com), f1[1]);
+            apxMap(*c->idx, r, anchors, hit, f1, c->f2, gaps, CS[i], CE[i], ci, 1, pg, pm);
+        }
+    }
+    uint64_t tot = 0;
+    cord_off[0] = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t k = length(CS[i]);
+        if (k && tot + k <= cap) { memcpy(cords_str + tot, &CS[i][0], k * 8); memcpy(cords_end + tot, &CE[i][0], k * 8); }
+        tot += k;
+        cord_off[i + 1] = tot;
+    }
+    return tot;
+}
+
 // stage dumps reproduced by calling the reference's own stage functions in apxMap_'s order
 // (pmpfinder.cpp:2646-2652, 2520-2526): 0 raw anchors, 1 filtered anchors, 2 x-desc sorted anchors, 3 hits after anchor chaining
 uint64_t ref_stage(void *h, const uint8_t *read, uint64_t len, int stage, uint64_t *out, uint64_t cap) {
