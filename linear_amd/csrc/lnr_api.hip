@@ -101,6 +101,7 @@ struct lnr_ctx {
     u32 heavy_cap_r1 = 7000, mid_cap_r1 = 3000;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
     bool lane_bulk_first = true;         // two lanes: which lane goes through the re-map round first (LNR_LANE_ORDER=heavy|bulk)
     u32 stop_after = 0;                  // diagnostic: LNR_STOP_AFTER (see JobArgs)
+    int seed_bm = -1;                    // bucket bitmap in the seed kernel: -1 = by table density, 0 / 1 forced (LNR_SEED_BM)
     u32 prep_threads = 256;             // workgroup size of k_prep (LNR_PREP_THREADS: 64, 128 or 256)
     u32 prep_grid = 4096;               // workgroups of k_prep (LNR_PREP_GRID): they loop over the reads
     u32 bulk_delay_ticks = 10000;       // head start (100 MHz ticks) of the multi-wave kernels over the bulk kernel (LNR_BULK_DELAY_US)
@@ -315,7 +316,10 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
         O.anchors = S.anchors.as<u64>(); O.anc_off = S.j_anc_off.as<u64>(); O.job_cap = S.j_cap.as<u32>(); O.job_look = S.j_look.as<u32>();
         O.n_anchors = S.j_nanc.as<u32>();
         S.t_seed.start(st);
-        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->dir.as<i32>(), ctx->bm.as<u32>(), ctx->hs.as<u64>(), nj, O);
+        // the bucket bitmap answers lookups of empty buckets without touching `dir`; once most buckets hold entries (human scale:
+        // 328 M entries in 67 M buckets) it is one more dependent load in front of every lookup and is skipped
+        bool use_bm = ctx->seed_bm < 0 ? ctx->info.hs_len < (1ULL << 25) : ctx->seed_bm != 0;
+        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->dir.as<i32>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->hs.as<u64>(), nj, O);
         KCHECK();
         S.t_seed.stop(st);
         if (f1_reads && attempt == 0) { lnr_status fs = launch_f1(ctx, f1_reads); if (fs != LNR_OK) return fs; }
@@ -975,6 +979,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_MID_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->mid_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP")) { long v = atol(e); if (v >= 64) { ctx->dp_split_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->dp_split_cap_r1 = ctx->dp_split_cap; } }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->dp_split_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
+    if (const char *e = getenv("LNR_SEED_BM")) ctx->seed_bm = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LNR_STOP_AFTER")) { long v = atol(e); if (v >= 0 && v < 16) ctx->stop_after = (u32)v; }
     if (const char *e = getenv("LNR_PREP_GRID")) { long v = atol(e); if (v > 0) ctx->prep_grid = (u32)v; }
     if (const char *e = getenv("LNR_PREP_THREADS")) { long v = atol(e); if (v == 64 || v == 128 || v == 256) ctx->prep_threads = (u32)v; }

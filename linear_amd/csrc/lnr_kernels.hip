@@ -546,18 +546,33 @@ __global__ void __launch_bounds__(256) k_ix_bitmap(const i32 *dir, u64 nbuckets,
 
 // Seed lookup of one job per wave (getDIndexMatchAll, pmpfinder.cpp:1856-1913), one kernel:
 //   1. minimizer of every sample (2-bit packed path; byte path where an N or hashInit state intervenes), the
-//      "minimizer changed" lookup rule (xpre == previous sample's X), bitmap test, bucket bounds from dir -- the sample
-//      records stay in LDS (SEG samples per segment);
+//      "minimizer changed" lookup rule (xpre == previous sample's X), optional bitmap test, bucket bounds from dir -- one
+//      8-byte record per sample stays in LDS (SEED_SEG samples per segment: a 10 kb read is one segment);
 //   2. the job's anchor segment is allocated with one atomicAdd (capacity = sum of bucket lengths + dummy);
-//   3. (sample, bucket entry) pairs are flattened over the lanes, filtered on Y (pmpfinder.cpp:1890-1899) and written in
-//      the reference's order by ballot compaction.
+//   3. the (sample, bucket entry) pairs of 64 samples are flattened over the lanes, 64 entries per group and SEED_MLP groups
+//      loaded before the first is looked at; the Y filter (pmpfinder.cpp:1890-1899) runs on the loaded words and the
+//      entries that pass are compacted, in the reference's order, into a small ring in LDS; whenever 64 have gathered the
+//      wave turns them into anchors (val2Anchor, index_util.cpp:1509-1520) and stores 512 contiguous bytes.
+// What the round-1 form of step 3 cost on the GRCh38 stand-in (27 entries per lookup, 17.7 k entries per read): one load in
+// flight per wave (latency bound), and ~118 VALU instructions per group of 64 entries -- a six-step binary search per lane to
+// find the entry's sample, 64-bit address and anchor arithmetic for lanes that mostly fail the Y test -- 3.3 G wave
+// instructions per launch, the SIMDs' issue slots 95 % taken (SQ counters, profiles/r02).  Now the owner of an entry comes
+// from one LDS scatter of the bucket starts + a ballot + a count-leading-zeros, and the anchor arithmetic runs on full groups
+// of survivors only.
 // Jobs with more samples than one segment count first and recompute the segments for step 3.
-#define SEED_SEG 512
-__global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, const i32 *dir, const u32 *bm, const u64 *hs, u32 njobs, SeedOutArrays O) {
-    __shared__ u32 st_xs[SEED_SEG];    // X | strand << 26
-    __shared__ u32 st_ydl[SEED_SEG];   // Y | bucket length << 8
-    __shared__ i32 st_ds[SEED_SEG];    // bucket start
-    __shared__ u32 s_incl[64];
+#define SEED_SEG 768
+#define SEED_MLP 4
+#define SEED_STG 128
+LNR_HD inline bool y_match32(u32 hs_y, u32 Y) {   // y_match on the 20-bit y field (pmpfinder.cpp:1893-1894, ctz(0) pinned to "match")
+    u32 v = hs_y ^ Y;
+    u32 low = v & (0u - v);                        // lowest set bit (0 if none)
+    return v < 4u * low || v == 0;                 // (v >> ctz(v)) < 4
+}
+__global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, const i32 *dir, const u32 *bm /* null: table too dense to pay */, const u64 *hs, u32 njobs, SeedOutArrays O) {
+    __shared__ uint2 st_rec[SEED_SEG];         // .x = bucket start, .y = Y | strand << 8 | bucket length << 9
+    __shared__ u32 s_mk[SEED_MLP][64];         // per group: sample (lane + 1) whose bucket starts at this entry position
+    __shared__ u64 s_sent[SEED_STG];           // ring of index entries that passed the Y filter ...
+    __shared__ u32 s_sq[SEED_STG];             // ... and the sample (segment-relative) each belongs to
     u32 j = blockIdx.x;
     if (j >= njobs) return;
     int lane = lane_id();
@@ -589,13 +604,13 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
             bool look = valid && o.X != prev;
             i32 ds = 0; u32 dl = 0;
             u32 xg = o.X >> BM_GROUP_LOG2;
-            if (look && ((bm[xg >> 5] >> (xg & 31)) & 1)) { ds = dir[o.X]; dl = (u32)(dir[o.X + 1] - ds); }
-            if (valid) { st_xs[si - s_lo] = o.X | (o.strand << 26); st_ydl[si - s_lo] = o.Y | (dl << 8); st_ds[si - s_lo] = ds; }
+            if (look && (!bm || ((bm[xg >> 5] >> (xg & 31)) & 1))) { ds = dir[o.X]; dl = (u32)(dir[o.X + 1] - ds); }
+            if (valid) st_rec[si - s_lo] = make_uint2((u32)ds, (o.Y & 0xffu) | (o.strand << 8) | (dl << 9));
             cap_io += wave_sum(dl);
             looks_io += (u32)__popcll(__ballot(look));
             carry_io = __shfl(o.X, 63);
         }
-        __syncthreads();
+        WLDS();
     };
     for (u32 seg = 0; seg < nseg; seg++) fill_segment(seg, carry, cap, looks);
     // allocate the anchor segment (dummy + capacity, even-sized)
@@ -612,42 +627,79 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
     if (lane == 0) out[0] = 0;   // the dummy the reference keeps at anchors[0] (base.cpp:272-277)
     u32 nout = 1;
     u32 carry2 = 0, capx = 0, lookx = 0;
+    const u64 lane_le = (2ULL << lane) - 1ULL;     // lanes 0 .. lane
     for (u32 seg = 0; seg < nseg; seg++) {
         if (nseg > 1) fill_segment(seg, carry2, capx, lookx);
         u32 s_lo = seg * SEED_SEG, s_hi = s_lo + SEED_SEG < ns ? s_lo + SEED_SEG : ns;
+        u32 sh = 0, sc = 0;                        // ring head / fill (wave-uniform)
+        auto emit = [&](u32 cnt) {                 // the first cnt (<= 64) entries of the ring become anchors
+            WLDS();
+            u32 p = (sh + (u32)lane) & (SEED_STG - 1);
+            u64 ent = s_sent[p];
+            u32 q = s_sq[p];
+            if ((u32)lane < cnt) {
+                u32 rec_y = st_rec[q].y;
+                u64 k = k0 + alpha - 1 + (u64)alpha * (s_lo + q);
+                out[nout + (u32)lane] = val2anchor(ent, k, L, (rec_y >> 8) & 1);
+            }
+            nout += cnt; sh = (sh + cnt) & (SEED_STG - 1); sc -= cnt;
+            WLDS();
+        };
         for (u32 base = s_lo; base < s_hi; base += 64) {
-            u32 li = base - s_lo + lane;
+            u32 cb = base - s_lo;                   // segment-relative index of the chunk's first sample
             bool valid = base + lane < s_hi;
-            u32 dl = valid ? st_ydl[li] >> 8 : 0;
+            u32 dl = valid ? st_rec[cb + lane].y >> 9 : 0;
             u32 incl = wave_incl_scan(dl);
-            u32 total = __shfl(incl, 63);
+            u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
             if (total == 0) continue;
-            __syncthreads();
-            s_incl[lane] = incl;
-            __syncthreads();
-            for (u32 e0 = 0; e0 < total; e0 += 64) {
-                u32 e = e0 + lane;
-                bool match = false;
-                u64 av = 0;
-                if (e < total) {
-                    int lo = 0, hi = 63;   // first sample of the chunk whose inclusive count exceeds e
-                    while (lo < hi) { int mid = (lo + hi) >> 1; if (s_incl[mid] > e) hi = mid; else lo = mid + 1; }
-                    u32 q = base - s_lo + (u32)lo;
-                    u32 ydl = st_ydl[q], xsv = st_xs[q];
-                    u32 excl = s_incl[lo] - (ydl >> 8);
-                    u64 ent = hs[st_ds[q] + (i32)(e - excl)];
-                    if (y_match(cord_y(ent), ydl & 0xff)) {
-                        match = true;
-                        u64 k = k0 + alpha - 1 + (u64)alpha * (base + (u32)lo);
-                        av = val2anchor(ent, k, L, (xsv >> 26) & 1);
+            u32 excl = incl - dl;
+            bool has = dl > 0;
+            for (u32 e0 = 0; e0 < total; e0 += 64 * SEED_MLP) {
+                u64 ent[SEED_MLP]; u32 qy[SEED_MLP];   // qy = sample | Y << 16
+#pragma unroll
+                for (int u = 0; u < SEED_MLP; u++) {
+                    u32 g0 = e0 + 64 * u;
+                    ent[u] = 0; qy[u] = 0;
+                    if (g0 >= total) continue;       // uniform
+                    // owner of entry g0 + lane: the last sample whose bucket starts at or before it
+                    s_mk[u][lane] = 0;
+                    WLDS();
+                    u32 rel = excl - g0;             // (wraps for buckets that start before the group)
+                    if (has && rel < 64) s_mk[u][rel] = (u32)lane + 1;
+                    WLDS();
+                    u32 m = s_mk[u][lane];
+                    u64 S = __ballot(m != 0);
+                    u64 cm = __ballot(has && excl < g0);                    // buckets that start before the group: the last one runs into it
+                    int cq = cm ? 63 - __builtin_clzll(cm) : 0;
+                    u32 cexcl = (u32)__builtin_amdgcn_readlane((int)excl, cq);
+                    u64 below = S & lane_le;
+                    int pp = below ? 63 - __builtin_clzll(below) : 0;
+                    u32 mq = s_mk[u][pp];
+                    u32 q = below ? mq - 1 : (u32)cq;
+                    u32 idx = below ? (u32)lane - (u32)pp : g0 + (u32)lane - cexcl;
+                    if (g0 + (u32)lane < total) {
+                        uint2 rec = st_rec[cb + q];
+                        ent[u] = hs[(i64)(i32)rec.x + (i64)idx];
+                        qy[u] = (cb + q) | ((rec.y & 0xffu) << 16);
                     }
                 }
-                u64 mask = __ballot(match);
-                if (match) out[nout + __popcll(mask & lanemask_lt())] = av;
-                nout += (u32)__popcll(mask);
+#pragma unroll
+                for (int u = 0; u < SEED_MLP; u++) {
+                    u32 g0 = e0 + 64 * u;
+                    if (g0 >= total) break;          // uniform
+                    bool match = g0 + (u32)lane < total && y_match32((u32)cord_y(ent[u]), qy[u] >> 16);
+                    u64 mask = __ballot(match);
+                    if (mask == 0) continue;
+                    if (match) {
+                        u32 p = (sh + sc + (u32)__popcll(mask & lanemask_lt())) & (SEED_STG - 1);
+                        s_sent[p] = ent[u]; s_sq[p] = qy[u] & 0xffffu;
+                    }
+                    sc += (u32)__popcll(mask);
+                    if (sc >= 64) emit(64);
+                }
             }
         }
-        __syncthreads();
+        while (sc) emit(sc < 64 ? sc : 64);         // the segment's records are overwritten next
     }
     if (lane == 0) O.n_anchors[j] = nout;
 }
