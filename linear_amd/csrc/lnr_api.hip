@@ -111,7 +111,7 @@ struct lnr_ctx {
     // lane's seed / tail launches), s_bulk the single-wave kernel of the same launch.
     hipStream_t s_multi[2] = {nullptr, nullptr}, s_bulk[2] = {nullptr, nullptr}, s_tail = nullptr;   // s_tail: early tail B of the reads that skip the re-map round
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_start = nullptr, ev_lane[2] = {nullptr, nullptr}, ev_prep = nullptr, ev_f1 = nullptr;
-    DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm;   // bm: bucket-non-empty bitmap (derived from dir)
+    DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines (k_ix_lines)
     // ---- batch inputs / per-read arrays
     DevBuf in_reads, in_off;                       // staging for the host-buffer entry points
     DevBuf rlen, rks, nf, f1_off, f1, pk, nm, pk_off;
@@ -124,7 +124,8 @@ struct lnr_ctx {
         DevBuf j_read, j_str, j_end, j_mode, j_cap, j_look, j_anc_off, j_nanc, grp_beg, anchors, seed_ctl;
         std::vector<u32> cap, look, nanc;
         std::vector<u64> anc_off;
-        u64 anc_slots_per_job = 1536;   // running estimate of anchor slots per job (grows on overflow)
+        u32 est_x16 = 64;               // anchors per sample x 16 the seed kernel sizes a job's first segment with (learned from the last batch)
+        u64 slots_hint = 0;             // anchor buffer of the last successful launch, per sample x 16
         Timer t_seed;
     } js[2];
     // (host vectors that feed asynchronous uploads live here, not on the stack: the launch functions return before the copy ran)
@@ -307,8 +308,12 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
     if (!S.t_seed.a) S.t_seed.init();
     JobArrays J = job_arrays(S);
     ReadArrays R = read_arrays(ctx);
-    u64 anc_slots = std::max<u64>(S.anc_slots_per_job * nj, 1024);
-    for (int attempt = 0; attempt < 2; attempt++) {
+    // anchor buffer: every job starts with a segment of est x samples slots and moves to one of twice the size when that fills
+    // up, so the buffer holds the first segments plus room for the moves; a launch that runs out is repeated with twice the room
+    u64 first_segs = ((hj.nsamp * S.est_x16) >> 4) + (u64)nj * 194;
+    u64 anc_slots = std::max<u64>(first_segs * 2 + (1u << 20), (hj.nsamp * S.slots_hint) >> 4);
+    bool use_bm = ctx->seed_bm < 0 ? ctx->info.hs_len < (1ULL << 25) : ctx->seed_bm != 0;
+    for (int attempt = 0; ; attempt++) {
         ENSURE(S.anchors, anc_slots * 8);
         HIPCK(hipMemsetAsync(S.seed_ctl.p, 0, 64, st));
         SeedOutArrays O;
@@ -316,10 +321,9 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
         O.anchors = S.anchors.as<u64>(); O.anc_off = S.j_anc_off.as<u64>(); O.job_cap = S.j_cap.as<u32>(); O.job_look = S.j_look.as<u32>();
         O.n_anchors = S.j_nanc.as<u32>();
         S.t_seed.start(st);
-        // the bucket bitmap answers lookups of empty buckets without touching `dir`; once most buckets hold entries (human scale:
-        // 328 M entries in 67 M buckets) it is one more dependent load in front of every lookup and is skipped
-        bool use_bm = ctx->seed_bm < 0 ? ctx->info.hs_len < (1ULL << 25) : ctx->seed_bm != 0;
-        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->dir.as<i32>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->hs.as<u64>(), nj, O);
+        // the bucket bitmap answers lookups of empty buckets without touching the bucket lines; once most buckets hold entries
+        // (human scale: 328 M entries in 67 M buckets) it is one more dependent load in front of every lookup and is skipped
+        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->bl.as<ulonglong2>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->hs.as<u64>(), nj, O, S.est_x16);
         KCHECK();
         S.t_seed.stop(st);
         if (f1_reads && attempt == 0) { lnr_status fs = launch_f1(ctx, f1_reads); if (fs != LNR_OK) return fs; }
@@ -330,14 +334,21 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
         HIPCK(hipMemcpyAsync(S.anc_off.data(), S.j_anc_off.p, (size_t)nj * 8, hipMemcpyDeviceToHost, st));
         HIPCK(hipMemcpyAsync(&ovf, S.seed_ctl.as<char>() + 16, 4, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
-        ctx->stats.seed_count_ms += S.t_seed.ms();
-        ctx->stats.seed_count_launches++;
-        if (!ovf) break;
-        if (attempt == 1) { ctx->err = "anchor buffer overflow after resize"; return LNR_ERR_INTERNAL; }
-        u64 need = 0;
-        for (u32 j = 0; j < nj; j++) need += ((u64)S.cap[j] + 1) & ~1ULL;   // cap already includes the dummy
-        anc_slots = need + 1024;
-        S.anc_slots_per_job = std::max<u64>(S.anc_slots_per_job, (need / nj) * 5 / 4 + 64);
+        if (!ovf) {                                   // only the successful launch is the stage's time
+            ctx->stats.seed_count_ms += S.t_seed.ms();
+            ctx->stats.seed_count_launches++;
+            break;
+        }
+        if (attempt == 5) { ctx->err = "anchor buffer overflow after five resizes"; return LNR_ERR_INTERNAL; }
+        anc_slots *= 2;
+    }
+    {   // learn the segment estimate for the next batch: 1.5 x the mean anchors per sample of this one
+        u64 tot = 0;
+        for (u32 j = 0; j < nj; j++) tot += S.nanc[j];
+        if (hj.nsamp) {
+            S.est_x16 = (u32)std::min<u64>(std::max<u64>((tot * 24) / hj.nsamp + 8, 32), 400 * 16);
+            S.slots_hint = (anc_slots << 4) / hj.nsamp + 1;
+        }
     }
     ctx->stats.jobs += nj;
     ctx->stats.samples += hj.nsamp;
@@ -1134,6 +1145,12 @@ lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64
         hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
         IXHIP(hipGetLastError());
     }
+    {   // bucket lines for the seed kernel
+        u64 nb = dir_len - 1;
+        ENSURE(ctx->bl, nb * 128);
+        hipLaunchKernelGGL(k_ix_lines, dim3((u32)((nb * 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), ctx->hs.as<u64>(), nb, ctx->bl.as<ulonglong2>());
+        IXHIP(hipGetLastError());
+    }
     // genome window features
     ENSURE(ctx->f2, std::max<u64>(ctx->info.f2_len * sizeof(F96), 16));
     if (ctx->info.f2_len) {
@@ -1211,6 +1228,9 @@ lnr_status lnr_index_adopt(lnr_ctx *ctx) {
     u64 nb = ctx->info.dir_len - 1, nwords = (((nb + (1u << BM_GROUP_LOG2) - 1) >> BM_GROUP_LOG2) + 31) / 32;   // derived structure: rebuilt from the received dir
     ENSURE(ctx->bm, nwords * 4 + 16);
     hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
+    KCHECK();
+    ENSURE(ctx->bl, nb * 128);
+    hipLaunchKernelGGL(k_ix_lines, dim3((u32)((nb * 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), ctx->hs.as<u64>(), nb, ctx->bl.as<ulonglong2>());
     KCHECK();
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->has_index = true;

@@ -544,35 +544,63 @@ __global__ void __launch_bounds__(256) k_ix_bitmap(const i32 *dir, u64 nbuckets,
     bm[w] = bits;
 }
 
-// Seed lookup of one job per wave (getDIndexMatchAll, pmpfinder.cpp:1856-1913), one kernel:
-//   1. minimizer of every sample (2-bit packed path; byte path where an N or hashInit state intervenes), the
-//      "minimizer changed" lookup rule (xpre == previous sample's X), optional bitmap test, bucket bounds from dir -- one
-//      8-byte record per sample stays in LDS (SEED_SEG samples per segment: a 10 kb read is one segment);
-//   2. the job's anchor segment is allocated with one atomicAdd (capacity = sum of bucket lengths + dummy);
-//   3. the (sample, bucket entry) pairs of 64 samples are flattened over the lanes, 64 entries per group and SEED_MLP groups
-//      loaded before the first is looked at; the Y filter (pmpfinder.cpp:1890-1899) runs on the loaded words and the
-//      entries that pass are compacted, in the reference's order, into a small ring in LDS; whenever 64 have gathered the
-//      wave turns them into anchors (val2Anchor, index_util.cpp:1509-1520) and stores 512 contiguous bytes.
-// What the round-1 form of step 3 cost on the GRCh38 stand-in (27 entries per lookup, 17.7 k entries per read): one load in
-// flight per wave (latency bound), and ~118 VALU instructions per group of 64 entries -- a six-step binary search per lane to
-// find the entry's sample, 64-bit address and anchor arithmetic for lanes that mostly fail the Y test -- 3.3 G wave
-// instructions per launch, the SIMDs' issue slots 95 % taken (SQ counters, profiles/r02).  Now the owner of an entry comes
-// from one LDS scatter of the bucket starts + a ballot + a count-leading-zeros, and the anchor arithmetic runs on full groups
-// of survivors only.
-// Jobs with more samples than one segment count first and recompute the segments for step 3.
-#define SEED_SEG 768
-#define SEED_MLP 4
-#define SEED_STG 128
-LNR_HD inline bool y_match32(u32 hs_y, u32 Y) {   // y_match on the 20-bit y field (pmpfinder.cpp:1893-1894, ctz(0) pinned to "match")
+// Bucket lines: the seed kernel's view of the DIndex.  Bucket X owns the 128-byte line X of `bl`: word 0 = bucket start in hs
+// (low 32 bits) | bucket length (bits 32..47), words 1..15 = its first 15 entries (zero behind the end).  One HBM line then
+// answers a lookup of a bucket of up to 15 entries completely -- dir line, hs line and the line fragments at both ends of the
+// bucket's run in hs were three or more -- and longer buckets continue in hs from entry 15.  A derived structure like the
+// bitmap: built on every GPU from dir / hs (8.6 GB of the 288), never broadcast.  dir and hs stay the parity surface.
+#define BL_INLINE 15
+__global__ void __launch_bounds__(256) k_ix_lines(const i32 *dir, const u64 *hs, u64 nbuckets, ulonglong2 *bl) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per 16-byte part of a line
+    u64 b = t >> 3;
+    if (b >= nbuckets) return;
+    u32 part = (u32)t & 7;
+    i32 ds = dir[b];
+    u32 dl = (u32)(dir[b + 1] - ds);
+    u64 w[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        u32 slot = 2 * part + (u32)k;
+        if (slot == 0) w[k] = (u64)(u32)ds | ((u64)dl << 32);
+        else w[k] = slot - 1 < dl ? hs[(i64)ds + (i64)(slot - 1)] : 0ULL;
+    }
+    bl[t] = make_ulonglong2(w[0], w[1]);
+}
+
+// Seed lookup of one job per wave (getDIndexMatchAll, pmpfinder.cpp:1856-1913), one kernel, one pass over the read in chunks
+// of 64 samples:
+//   1. lane = sample: minimizer (2-bit packed path; byte path where an N or hashInit state intervenes), the "minimizer
+//      changed" lookup rule (xpre == previous sample's X), optional bitmap test, then the header word of the bucket's line:
+//      start and length of the bucket (the fetch also brings the line on chip for step 2);
+//   2. lane = 128-byte line.  The lines a sample needs -- its bucket line, then the 128-byte-aligned lines of hs that hold its
+//      entries from the 16th on -- are numbered through the chunk in the reference's order; a lane takes one line (owner from
+//      one LDS scatter of the samples' first line numbers + a ballot + a count-leading-zeros), loads its 16 words with eight
+//      16-byte loads, runs the Y filter (pmpfinder.cpp:1890-1899) on the words in registers and keeps a 16-bit mask of the
+//      entries that pass and belong to the bucket;
+//   3. the survivors go, in lane order = the reference's order, into a ring in LDS; whenever 64 have gathered the wave turns
+//      them into anchors (val2Anchor, index_util.cpp:1509-1520) and stores 512 contiguous bytes.
+// The job's anchor segment is bump-allocated from an estimate (est_per_sample x samples, learned by the host from earlier
+// batches) and moved to a segment of twice the size when it fills up -- the round-1 kernel counted all bucket lengths first
+// and needed every bucket twice.
+// History on the GRCh38 stand-in (100 k reads per launch, 663 lookups and 17.7 k bucket entries per read, 16.3 GB algorithmic):
+//   round 1 kernel (lane = entry, one load in flight, per-lane binary search for the owner)    8.55 ms, 32 GB of HBM traffic
+//   four loads in flight, owner by scatter + ballot, anchors from full groups of survivors     5.75 ms, 32 GB (5.6 TB/s: HBM bound)
+//   bucket lines, lane = entry                                                                  7.1 ms, 24 GB (issue bound: 2.5 G VALU)
+//   bucket lines, lane = line (this form)                                                       see DESIGN.md
+#define SEED_RING 256
+LNR_HD inline u32 y_match32(u32 hs_y, u32 Y) {   // y_match on the 20-bit y field (pmpfinder.cpp:1893-1894, ctz(0) pinned to "match")
     u32 v = hs_y ^ Y;
     u32 low = v & (0u - v);                        // lowest set bit (0 if none)
-    return v < 4u * low || v == 0;                 // (v >> ctz(v)) < 4
+    return (v < 4u * low || v == 0) ? 1u : 0u;     // (v >> ctz(v)) < 4
 }
-__global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, const i32 *dir, const u32 *bm /* null: table too dense to pay */, const u64 *hs, u32 njobs, SeedOutArrays O) {
-    __shared__ uint2 st_rec[SEED_SEG];         // .x = bucket start, .y = Y | strand << 8 | bucket length << 9
-    __shared__ u32 s_mk[SEED_MLP][64];         // per group: sample (lane + 1) whose bucket starts at this entry position
-    __shared__ u64 s_sent[SEED_STG];           // ring of index entries that passed the Y filter ...
-    __shared__ u32 s_sq[SEED_STG];             // ... and the sample (segment-relative) each belongs to
+__global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, const ulonglong2 *bl, const u32 *bm /* null: table too dense to pay */, const u64 *hs, u32 njobs,
+                                                   SeedOutArrays O, u32 est_per_sample_x16) {
+    __shared__ uint4 s_rec[64];                // per sample: X, bucket start, bucket length, Y | strand << 8
+    __shared__ u32 s_mk[64];                   // sample (lane + 1) whose first line has this number within the round
+    __shared__ u64 s_src[64];                  // source address of the round's 64 lines (for the lanes that fetch them)
+    __shared__ ulonglong2 s_line[64][8];       // the round's lines, landed by LDS-DMA: [line][16-byte part]
+    __shared__ u64 s_sent[SEED_RING];          // ring of index entries that passed the Y filter ...
+    __shared__ u32 s_sq[SEED_RING];            // ... and the sample (read-relative) | strand << 31 each belongs to
     u32 j = blockIdx.x;
     if (j >= njobs) return;
     int lane = lane_id();
@@ -587,121 +615,174 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
     u64 k0 = rs + 21;
     int C = shape_const(s, 0, ks, k0);
     u32 ns = seed_num_samples(rs, re, alpha);
-    u32 nseg = (ns + SEED_SEG - 1) / SEED_SEG;
-    u32 cap = 0, looks = 0, carry = 0;
-    auto fill_segment = [&](u32 seg, u32 &carry_io, u32 &cap_io, u32 &looks_io) {
-        u32 s_lo = seg * SEED_SEG, s_hi = s_lo + SEED_SEG < ns ? s_lo + SEED_SEG : ns;
-        for (u32 base = s_lo; base < s_hi; base += 64) {
-            u32 si = base + lane;
-            bool valid = si < s_hi;
-            SeedOut o; o.X = 0; o.Y = 0; o.strand = 0;
-            if (valid) {
-                u64 k = k0 + alpha - 1 + (u64)alpha * si;
-                if (!seed_sample_packed(pk, nm, k, k0, C, o)) o = seed_sample(s, k, k0, 0, ks, C);
-            }
-            u32 prev = __shfl_up(o.X, 1);
-            if (lane == 0) prev = carry_io;
-            bool look = valid && o.X != prev;
-            i32 ds = 0; u32 dl = 0;
-            u32 xg = o.X >> BM_GROUP_LOG2;
-            if (look && (!bm || ((bm[xg >> 5] >> (xg & 31)) & 1))) { ds = dir[o.X]; dl = (u32)(dir[o.X + 1] - ds); }
-            if (valid) st_rec[si - s_lo] = make_uint2((u32)ds, (o.Y & 0xffu) | (o.strand << 8) | (dl << 9));
-            cap_io += wave_sum(dl);
-            looks_io += (u32)__popcll(__ballot(look));
-            carry_io = __shfl(o.X, 63);
-        }
-        WLDS();
-    };
-    for (u32 seg = 0; seg < nseg; seg++) fill_segment(seg, carry, cap, looks);
-    // allocate the anchor segment (dummy + capacity, even-sized)
-    u64 want = ((u64)cap + 1 + 1) & ~1ULL;
+    // anchor segment: estimate now, grow when it fills up
+    u64 seg_cap = ((((u64)ns * est_per_sample_x16) >> 4) + 192) & ~1ULL;
     unsigned long long off = 0;
-    if (lane == 0) off = atomicAdd(O.cursor, (unsigned long long)want);
+    if (lane == 0) off = atomicAdd(O.cursor, (unsigned long long)seg_cap);
     off = __shfl((long long)off, 0);
-    if (lane == 0) { O.job_cap[j] = cap + 1; O.job_look[j] = looks; O.anc_off[j] = off; }
-    if (off + want > O.capacity) {   // the host re-runs with the exact size (it now knows every job_cap)
-        if (lane == 0) { *O.overflow = 1; O.n_anchors[j] = 0; }
+    if (off + seg_cap > O.capacity) {            // the host re-runs with a larger buffer
+        if (lane == 0) { *O.overflow = 1; O.n_anchors[j] = 0; O.job_cap[j] = 1; O.job_look[j] = 0; O.anc_off[j] = 0; }
         return;
     }
     u64 *out = O.anchors + off;
     if (lane == 0) out[0] = 0;   // the dummy the reference keeps at anchors[0] (base.cpp:272-277)
     u32 nout = 1;
-    u32 carry2 = 0, capx = 0, lookx = 0;
+    u32 cap = 0, looks = 0, carry = 0;
+    u32 sh = 0, sc = 0;                            // ring head / fill (wave-uniform)
+    bool dead = false;
     const u64 lane_le = (2ULL << lane) - 1ULL;     // lanes 0 .. lane
-    for (u32 seg = 0; seg < nseg; seg++) {
-        if (nseg > 1) fill_segment(seg, carry2, capx, lookx);
-        u32 s_lo = seg * SEED_SEG, s_hi = s_lo + SEED_SEG < ns ? s_lo + SEED_SEG : ns;
-        u32 sh = 0, sc = 0;                        // ring head / fill (wave-uniform)
-        auto emit = [&](u32 cnt) {                 // the first cnt (<= 64) entries of the ring become anchors
-            WLDS();
-            u32 p = (sh + (u32)lane) & (SEED_STG - 1);
-            u64 ent = s_sent[p];
-            u32 q = s_sq[p];
-            if ((u32)lane < cnt) {
-                u32 rec_y = st_rec[q].y;
-                u64 k = k0 + alpha - 1 + (u64)alpha * (s_lo + q);
-                out[nout + (u32)lane] = val2anchor(ent, k, L, (rec_y >> 8) & 1);
-            }
-            nout += cnt; sh = (sh + cnt) & (SEED_STG - 1); sc -= cnt;
-            WLDS();
-        };
-        for (u32 base = s_lo; base < s_hi; base += 64) {
-            u32 cb = base - s_lo;                   // segment-relative index of the chunk's first sample
-            bool valid = base + lane < s_hi;
-            u32 dl = valid ? st_rec[cb + lane].y >> 9 : 0;
-            u32 incl = wave_incl_scan(dl);
-            u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-            if (total == 0) continue;
-            u32 excl = incl - dl;
-            bool has = dl > 0;
-            for (u32 e0 = 0; e0 < total; e0 += 64 * SEED_MLP) {
-                u64 ent[SEED_MLP]; u32 qy[SEED_MLP];   // qy = sample | Y << 16
-#pragma unroll
-                for (int u = 0; u < SEED_MLP; u++) {
-                    u32 g0 = e0 + 64 * u;
-                    ent[u] = 0; qy[u] = 0;
-                    if (g0 >= total) continue;       // uniform
-                    // owner of entry g0 + lane: the last sample whose bucket starts at or before it
-                    s_mk[u][lane] = 0;
-                    WLDS();
-                    u32 rel = excl - g0;             // (wraps for buckets that start before the group)
-                    if (has && rel < 64) s_mk[u][rel] = (u32)lane + 1;
-                    WLDS();
-                    u32 m = s_mk[u][lane];
-                    u64 S = __ballot(m != 0);
-                    u64 cm = __ballot(has && excl < g0);                    // buckets that start before the group: the last one runs into it
-                    int cq = cm ? 63 - __builtin_clzll(cm) : 0;
-                    u32 cexcl = (u32)__builtin_amdgcn_readlane((int)excl, cq);
-                    u64 below = S & lane_le;
-                    int pp = below ? 63 - __builtin_clzll(below) : 0;
-                    u32 mq = s_mk[u][pp];
-                    u32 q = below ? mq - 1 : (u32)cq;
-                    u32 idx = below ? (u32)lane - (u32)pp : g0 + (u32)lane - cexcl;
-                    if (g0 + (u32)lane < total) {
-                        uint2 rec = st_rec[cb + q];
-                        ent[u] = hs[(i64)(i32)rec.x + (i64)idx];
-                        qy[u] = (cb + q) | ((rec.y & 0xffu) << 16);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < SEED_MLP; u++) {
-                    u32 g0 = e0 + 64 * u;
-                    if (g0 >= total) break;          // uniform
-                    bool match = g0 + (u32)lane < total && y_match32((u32)cord_y(ent[u]), qy[u] >> 16);
-                    u64 mask = __ballot(match);
-                    if (mask == 0) continue;
-                    if (match) {
-                        u32 p = (sh + sc + (u32)__popcll(mask & lanemask_lt())) & (SEED_STG - 1);
-                        s_sent[p] = ent[u]; s_sq[p] = qy[u] & 0xffffu;
-                    }
-                    sc += (u32)__popcll(mask);
-                    if (sc >= 64) emit(64);
-                }
-            }
+    auto emit = [&](u32 cnt) {                     // the first cnt (<= 64) entries of the ring become anchors
+        if ((u64)nout + cnt > seg_cap) {           // segment full: move to one of twice the size (uniform branch)
+            u64 ncap = (2 * seg_cap + 128) & ~1ULL;
+            unsigned long long noff = 0;
+            if (lane == 0) noff = atomicAdd(O.cursor, (unsigned long long)ncap);
+            noff = __shfl((long long)noff, 0);
+            if (noff + ncap > O.capacity) { if (lane == 0) *O.overflow = 1; dead = true; sc = 0; return; }
+            u64 *nw = O.anchors + noff;
+            WSYNC();                               // the wave's own earlier stores to the old segment have landed
+            for (u32 i = (u32)lane; i < nout; i += 64) nw[i] = out[i];
+            out = nw; off = noff; seg_cap = ncap;
         }
-        while (sc) emit(sc < 64 ? sc : 64);         // the segment's records are overwritten next
+        WLDS();
+        u32 p = (sh + (u32)lane) & (SEED_RING - 1);
+        u64 ent = s_sent[p];
+        u32 sq = s_sq[p];                          // sample | strand << 31
+        if ((u32)lane < cnt) {
+            u64 k = k0 + alpha - 1 + (u64)alpha * (sq & 0x7fffffffu);
+            out[nout + (u32)lane] = val2anchor(ent, k, L, sq >> 31);
+        }
+        nout += cnt; sh = (sh + cnt) & (SEED_RING - 1); sc -= cnt;
+        WLDS();
+    };
+    // ---- 1. minimizers of a chunk and the header words of its buckets: issued one chunk ahead, so the headers of chunk c + 1
+    // travel while the lines of chunk c are fetched and filtered (a job is a chain of dependent memory round trips -- one for
+    // the headers and three for the lines of every chunk -- and its latency, not the chip's bandwidth, set the kernel's time)
+    auto sample_chunk = [&](u32 base, SeedOut &o, u64 &hdr) {
+        u32 si = base + lane;
+        bool valid = si < ns;
+        o.X = 0; o.Y = 0; o.strand = 0;
+        if (valid) {
+            u64 k = k0 + alpha - 1 + (u64)alpha * si;
+            if (!seed_sample_packed(pk, nm, k, k0, C, o)) o = seed_sample(s, k, k0, 0, ks, C);
+        }
+        u32 prev = __shfl_up(o.X, 1);
+        if (lane == 0) prev = carry;
+        carry = __shfl(o.X, 63);
+        bool look = valid && o.X != prev;
+        looks += (u32)__popcll(__ballot(look));
+        u32 xg = o.X >> BM_GROUP_LOG2;
+        bool fetch = look && (!bm || ((bm[xg >> 5] >> (xg & 31)) & 1));
+        hdr = fetch ? bl[(u64)o.X * 8].x : 0ULL;
+    };
+#ifndef SEED_PREFETCH
+#define SEED_PREFETCH 1
+#endif
+    SeedOut o_n; u64 hdr_n = 0;
+    if (SEED_PREFETCH && ns) sample_chunk(0, o_n, hdr_n);
+    for (u32 base = 0; base < ns && !dead; base += 64) {
+        SeedOut o = o_n; u64 hdr = hdr_n;
+        if (!SEED_PREFETCH) sample_chunk(base, o, hdr);
+        else if (base + 64 < ns) sample_chunk(base + 64, o_n, hdr_n);
+        u32 ds = (u32)hdr, dl = (u32)(hdr >> 32) & 0xffffu;
+        // lines of this sample: its bucket line + the aligned 16-entry lines of hs that hold entries 15 .. dl - 1
+        u32 nl = dl ? 1u + (dl > BL_INLINE ? ((ds + dl - 1) >> 4) - ((ds + BL_INLINE) >> 4) + 1u : 0u) : 0u;
+        u32 lincl = wave_incl_scan(nl);
+        u32 totalL = (u32)__builtin_amdgcn_readlane((int)lincl, 63);
+        if (totalL == 0) continue;
+        cap += wave_sum(dl);
+        s_rec[lane] = make_uint4(o.X, ds, dl, (o.Y & 0xffu) | (o.strand << 8));
+        u32 lexcl = lincl - nl;
+        bool has = nl > 0;
+        // ---- 2. the chunk's lines, 64 per round, one per lane
+        for (u32 g0 = 0; g0 < totalL && !dead; g0 += 64) {
+            s_mk[lane] = 0;
+            WLDS();
+            u32 rel = lexcl - g0;                 // (wraps for samples whose first line lies before the round)
+            if (has && rel < 64) s_mk[rel] = (u32)lane + 1;
+            WLDS();
+            u32 m = s_mk[lane];
+            u64 S = __ballot(m != 0);
+            u64 cm = __ballot(has && lexcl < g0);                           // samples that start before the round: the last one runs into it
+            int cq = cm ? 63 - __builtin_clzll(cm) : 0;
+            u32 cexcl = (u32)__builtin_amdgcn_readlane((int)lexcl, cq);
+            u64 below = S & lane_le;
+            int pp = below ? 63 - __builtin_clzll(below) : 0;
+            u32 mq = s_mk[pp];
+            u32 q = below ? mq - 1 : (u32)cq;
+            u32 li = below ? (u32)lane - (u32)pp : g0 + (u32)lane - cexcl;  // line of the sample: 0 = bucket line
+            bool act = g0 + (u32)lane < totalL;
+            uint4 rec = s_rec[q];
+            const ulonglong2 *src = bl + (u64)rec.x * 8;
+            u32 vm;                                                         // words of the line that are entries of this bucket
+            {
+                u32 n0 = rec.z < BL_INLINE ? rec.z : BL_INLINE;
+                vm = ((1u << n0) - 1u) << 1;                                // bucket line: words 1 .. n0
+                if (li) {
+                    u32 lb = ((rec.y + BL_INLINE) >> 4) + li - 1;           // line number in hs (16 entries per line)
+                    src = (const ulonglong2 *)(hs + (u64)lb * 16);
+                    i32 lo = (i32)(rec.y + BL_INLINE) - (i32)(lb * 16), hi = (i32)(rec.y + rec.z) - (i32)(lb * 16);
+                    lo = lo < 0 ? 0 : lo; hi = hi > 16 ? 16 : hi;
+                    vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                }
+                if (!act) { vm = 0; src = bl; }
+            }
+            // the 64 lines go from HBM to LDS without passing through registers: instruction t fetches lines 8 t .. 8 t + 7, eight
+            // lanes per line (coalesced: a lane that loaded its own line made 64 requests per instruction and the kernel ran
+            // at the rate of the address path)
+            s_src[lane] = (u64)src;
+            WLDS();
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const char *gp = (const char *)s_src[8 * t + (lane >> 3)] + 16 * (lane & 7);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp, (__attribute__((address_space(3))) void *)&s_line[8 * t][0], 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WLDS();
+            u32 Y = rec.w & 0xffu;
+            u32 mm = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                u32 pt = ((u32)t + (u32)lane) & 7;                          // parts in rotated order: 2-way instead of 8-way bank conflicts
+                ulonglong2 w = s_line[lane][pt];
+                mm |= y_match32((u32)w.x & 0xfffffu, Y) << (2 * pt);
+                mm |= y_match32((u32)w.y & 0xfffffu, Y) << (2 * pt + 1);
+            }
+            mm &= vm;
+            u32 cnt = (u32)__popc(mm);
+            u32 incl = wave_incl_scan(cnt);
+            u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            if (tot == 0) continue;
+            u32 pos = incl - cnt;
+            u32 sqv = (base + q) | ((rec.w >> 8) << 31);
+            // ---- 3. survivors -> ring (all lanes at once when they fit, else eight lanes at a time), anchors out.
+            // A line has about one survivor: the k-th survivor of every lane is read from the staged line and placed at pos + k.
+            const u64 *srcw = (const u64 *)&s_line[lane][0];
+            u32 nq = sc + tot <= SEED_RING ? 1u : 8u;                       // (8 lanes hold at most 128 survivors; sc < 64 here)
+            for (u32 qt = 0; qt < nq; qt++) {
+                u32 qb = 0, qn = tot;
+                if (nq > 1) {
+                    qb = qt ? (u32)__builtin_amdgcn_readlane((int)incl, (int)(8 * qt - 1)) : 0u;
+                    qn = (u32)__builtin_amdgcn_readlane((int)incl, (int)(8 * qt + 7)) - qb;
+                }
+                bool mine = nq == 1 || (u32)(lane >> 3) == qt;
+                u32 pr = sh + sc + pos - qb;
+                u32 mk = mine ? mm : 0u;
+                while (__ballot(mk != 0)) {
+                    if (mk) {
+                        u32 kbit = (u32)__builtin_ctz(mk);
+                        mk &= mk - 1;
+                        u32 p = pr & (SEED_RING - 1);
+                        s_sent[p] = srcw[kbit]; s_sq[p] = sqv; pr++;
+                    }
+                }
+                sc += qn;
+                while (sc >= 64 && !dead) emit(64);
+            }
+            WLDS();                                                         // the ring pushes read s_line: done before the next round lands
+        }
     }
-    if (lane == 0) O.n_anchors[j] = nout;
+    while (sc && !dead) emit(sc < 64 ? sc : 64);
+    if (lane == 0) { O.job_cap[j] = cap + 1; O.job_look[j] = looks; O.anc_off[j] = off; O.n_anchors[j] = dead ? 0 : nout; }
 }
 
 // =================================================================== job =====

@@ -1416,6 +1416,28 @@ void orc_get_cords(void *h, uint64_t *cords_str, uint64_t *cords_end) {
         memcpy(cords_end, c->cords_end.data(), c->cords_end.size() * 8);
     }
 }
+// diagnostic: histogram of the bucket length of every lookup getDIndexMatchAll makes for this read (hist[0..400])
+void orc_lookup_hist(void *h, const uint8_t *read, uint64_t len, uint64_t *hist401) {
+    Ctx *c = (Ctx *)h;
+    std::vector<uint8_t> buf(len + SEQ_PAD, 0);
+    memcpy(buf.data(), read, len);
+    Shape shape;
+    u64 dt = 0, xpre = ~0ULL;
+    if (len < 2 * shape.span) return;
+    hashInit(shape, buf.data());
+    for (u64 k = shape.span; k < len - shape.span; k++) {   // pmpfinder.cpp:1870-1907 with thd_alpha 15
+        hashNexth(shape, buf.data() + k);
+        if (++dt == 15) {
+            hashNextX(shape, buf.data() + k);
+            if (shape.XValue != xpre) {
+                u64 n = (u64)(c->index.dir[shape.XValue + 1] - c->index.dir[shape.XValue]);
+                hist401[n > 400 ? 400 : n]++;
+                xpre = shape.XValue;
+            }
+            dt = 0;
+        }
+    }
+}
 void orc_reset_stats(void *h) { Work *c = &((Ctx *)h)->w; c->stats = Stats(); c->pair_evals = 0; }
 void orc_get_stats(void *h, uint64_t *out5) {
     Work *c = &((Ctx *)h)->w;

@@ -6,7 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from linear_amd import Filter
+from linear_amd import Filter, api
+if os.environ.get("LNR_PROBE_LIB"):
+    api.SO = os.path.abspath(os.environ["LNR_PROBE_LIB"])   # A/B runs of several builds on one box
 from linear_amd.synth_torch import grch38_like_cuda, sample_reads_multi_cuda
 
 ap = argparse.ArgumentParser()
