@@ -101,6 +101,7 @@ struct lnr_ctx {
     u32 heavy_cap_r1 = 7000, mid_cap_r1 = 3000;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
     bool lane_bulk_first = true;         // two lanes: which lane goes through the re-map round first (LNR_LANE_ORDER=heavy|bulk)
     u32 stop_after = 0;                  // diagnostic: LNR_STOP_AFTER (see JobArgs)
+    bool post_split = false;             // a11-a16 in k_post, one lane per read (LNR_POST_SPLIT=0: fused job kernels)
     int seed_bm = -1;                    // bucket bitmap in the seed kernel: -1 = by table density, 0 / 1 forced (LNR_SEED_BM)
     u32 prep_threads = 256;             // workgroup size of k_prep (LNR_PREP_THREADS: 64, 128 or 256)
     u32 prep_grid = 4096;               // workgroups of k_prep (LNR_PREP_GRID): they loop over the reads
@@ -402,7 +403,10 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         for (u32 k = 0; k < ngrp; k++) order[cnt[gc[k]]++] = k;
         u32 nh = 0;
         while (nh < ngrp && w[order[nh]] >= std::min<u64>(std::min(std::min(ctx->heavy_cap, ctx->mid_cap), std::min(ctx->heavy_cap_r1, ctx->mid_cap_r1)), std::min(ctx->dp_split_cap, ctx->dp_split_cap_r1)) / 2) nh++;
-        std::stable_sort(order.begin(), order.begin() + nh, [&w](u32 a, u32 b) { return w[a] > w[b]; });
+        // (exact order only for a short prefix: at human scale every read carries > 1500 mostly random anchors, the prefix was
+        // 60 % of the batch and its sort 2.3 ms of host time per step with the GPU idle; without it the class cuts are exact
+        // to the 1/8 octave, which only moves a few reads between kernels)
+        if (nh <= 4096) std::stable_sort(order.begin(), order.begin() + nh, [&w](u32 a, u32 b) { return w[a] > w[b]; });
     }
     std::vector<u32> &dev_order = Lx.h_order;
     dev_order.resize(ngrp);
@@ -448,6 +452,8 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         A.read_err = ctx->read_err.as<i32>();
         A.nbins = ctx->nbins; A.grp_lo = g0; A.grp_hi = g1;
         A.prof = nullptr; A.tl = nullptr; A.jstate = Lx.jstate.as<u32>(); A.stop_after = ctx->stop_after;
+        const bool split = ctx->post_split && ctx->stop_after == 0;
+        if (split) HIPCK(hipMemsetAsync(Lx.jstate.p, 0, (size_t)nj * 8, sm));   // a job the job kernel never reached reads as "not handed over"
         // dynamic LDS = the job arena; the binning histogram borrows it first and sweeps the bin range in passes of that many
         // bins, so the LDS per workgroup (hence the residency of the bulk kernel) does not depend on the reference's length
         const size_t lds_min = 4096;                 // the split path's pre / post kernels keep every array in global scratch
@@ -491,7 +497,11 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
             JobArgs H = A;
             size_t hl = (size_t)ctx->heavy_lds_kb * 1024;
             H.grp_lo = g0; H.grp_hi = gh; H.lds_bytes = (u32)hl; H.arena_lds = (u32)hl;
-            hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, sm, H);
+            if (split) {
+                hipLaunchKernelGGL(k_job_heavy_a, dim3(gh - g0), dim3(1024), hl, sm, H);
+                KCHECK();
+                hipLaunchKernelGGL(k_post, dim3((gh - g0 + 63) / 64), dim3(64), 0, sm, H);
+            } else hipLaunchKernelGGL(k_job_heavy, dim3(gh - g0), dim3(1024), hl, sm, H);
             KCHECK();
         }
         auto launch_bulk = [&]() -> lnr_status {
@@ -501,7 +511,11 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
             if (gm > g0 && bulk != sm && !after_bulk) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, bulk, ctx->bulk_delay_ticks); KCHECK(); }
             JobArgs K = A;
             K.grp_lo = gm; K.grp_hi = g1;
-            hipLaunchKernelGGL(k_job, dim3(g1 - gm), dim3(64), lds, bulk, K);
+            if (split) {
+                hipLaunchKernelGGL(k_job_a, dim3(g1 - gm), dim3(64), lds, bulk, K);
+                KCHECK();
+                hipLaunchKernelGGL(k_post, dim3((g1 - gm + 63) / 64), dim3(64), 0, bulk, K);
+            } else hipLaunchKernelGGL(k_job, dim3(g1 - gm), dim3(64), lds, bulk, K);
             KCHECK();
             return LNR_OK;
         };
@@ -522,7 +536,11 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
             JobArgs M = A;
             size_t ml = (size_t)ctx->mid_lds_kb * 1024;
             M.grp_lo = gs; M.grp_hi = gm; M.lds_bytes = (u32)ml; M.arena_lds = (u32)ml;
-            hipLaunchKernelGGL(k_job_mid, dim3(gm - gs), dim3(256), ml, s4, M);
+            if (split) {
+                hipLaunchKernelGGL(k_job_mid_a, dim3(gm - gs), dim3(256), ml, s4, M);
+                KCHECK();
+                hipLaunchKernelGGL(k_post, dim3((gm - gs + 63) / 64), dim3(64), 0, s4, M);
+            } else hipLaunchKernelGGL(k_job_mid, dim3(gm - gs), dim3(256), ml, s4, M);
             KCHECK();
         }
         if (fork_m && !after_bulk) HIPCK(hipEventRecord(ctx->ev_join[0], s4));
@@ -990,6 +1008,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_MID_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->mid_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP")) { long v = atol(e); if (v >= 64) { ctx->dp_split_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->dp_split_cap_r1 = ctx->dp_split_cap; } }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->dp_split_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
+    if (const char *e = getenv("LNR_POST_SPLIT")) ctx->post_split = atoi(e) != 0;
     if (const char *e = getenv("LNR_SEED_BM")) ctx->seed_bm = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LNR_STOP_AFTER")) { long v = atol(e); if (v >= 0 && v < 16) ctx->stop_after = (u32)v; }
     if (const char *e = getenv("LNR_PREP_GRID")) { long v = atol(e); if (v > 0) ctx->prep_grid = (u32)v; }

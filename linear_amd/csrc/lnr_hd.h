@@ -75,6 +75,11 @@ LNR_HD inline void lnr_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #endif
 }
+// Two ways the device runs the per-read stages: COOP = all 64 lanes of a wave execute the code together for ONE read (the leader
+// stores, the others track the counts; the job kernels), or one lane per read (k_post: every lane is its own leader and nothing
+// is shared between lanes).  The stage functions that differ take the mode as a template argument.
+template <bool COOP> LNR_HD inline bool lnr_leader() { return COOP ? lnr_is_leader() : true; }
+template <bool COOP> LNR_HD inline void lnr_sync() { if (COOP) lnr_wave_sync(); }
 // bounded vector view over caller-provided storage; overflow is recorded, never written past cap
 template <class T>
 struct Vec {
@@ -85,6 +90,10 @@ struct Vec {
     LNR_HD void push_u(const T &v) {
         if (n < cap) { if (lnr_is_leader()) p[n] = v; n++; }
         else if (lnr_is_leader()) *ovf = 1;
+    }
+    template <bool COOP> LNR_HD void push_m(const T &v) {
+        if (n < cap) { if (lnr_leader<COOP>()) p[n] = v; n++; }
+        else if (lnr_leader<COOP>()) *ovf = 1;
     }
     LNR_HD T &operator[](u32 i) { return p[i]; }
     LNR_HD T &back() { return p[n - 1]; }
@@ -927,8 +936,14 @@ LNR_HD inline u32 filter_blocks_hits(const BlockSink &ch, const u64 *hits, u64 *
 // best of the three candidate x-cells [x0, x0+3) against read cell y: minimal distance, first minimum wins.
 // Device: called by all 64 lanes with identical arguments; lanes 0..2 evaluate one candidate each, the result is
 // made uniform with shuffles (one memory round trip instead of twelve dependent ones).  Host: plain loop.
+template <bool COOP = true>
 LNR_HD inline u32 window_best3(FeatView f1, FeatView f2, u64 y, u64 x0, u64 &x_min) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (!COOP) {
+        u32 mn1 = ~0u;
+        for (u64 x = x0; x < x0 + 3; x++) { u32 t = wdist_raw(f1, f2, y, x); if (t < mn1) { mn1 = t; x_min = x; } }
+        return mn1;
+    }
     int lane = (int)(threadIdx.x & 63);
     u32 t = lane < 3 ? wdist_raw(f1, f2, y, x0 + (u64)lane) : 0xffffffffu;
     u32 t0 = __shfl(t, 0), t1 = __shfl(t, 1), t2 = __shfl(t, 2);
@@ -942,46 +957,49 @@ LNR_HD inline u32 window_best3(FeatView f1, FeatView f2, u64 y, u64 x0, u64 &x_m
     return mn;
 #endif
 }
+template <bool COOP = true>
 LNR_HD inline u64 previous_window(FeatView f1, FeatView f2, u64 cord) {   // pmpfinder.cpp:883-945
     u64 gid = cord_id(cord), strand = cord_strand(cord);
     u64 x_suf = cord_x(cord) >> 4, y_suf = cord_y(cord) >> 4, x_min = 0;
     if (y_suf < 5 || x_suf < 6) return 0;
     u64 y = y_suf - 5;
-    u32 mn = window_best3(f1, f2, y, x_suf - 6, x_min);
+    u32 mn = window_best3<COOP>(f1, f2, y, x_suf - 6, x_min);
     if (mn > 36) return 0;
     if (x_suf - x_min > 5) return mk_cord((gid << 30) + ((x_suf - 5) << 4), (x_suf - x_min - 5 + y) << 4, strand);
     return mk_cord((gid << 30) + (x_min << 4), y << 4, strand);
 }
+template <bool COOP = true>
 LNR_HD inline u64 next_window(FeatView f1, FeatView f2, u64 cord) {   // pmpfinder.cpp:1079-1150
     u64 gid = cord_id(cord), strand = cord_strand(cord);
     u64 x_pre = cord_x(cord) >> 4, y_pre = cord_y(cord) >> 4, x_min = 0;
     if (y_pre + 12 > f1.n || x_pre + 12 > f2.n) return 0;
     u64 y = y_pre + 5;
-    u32 mn = window_best3(f1, f2, y, x_pre + 3, x_min);
+    u32 mn = window_best3<COOP>(f1, f2, y, x_pre + 3, x_min);
     if (mn > 36) return 0;
     if (x_min - x_pre > 5) return mk_cord((gid << 30) + ((x_pre + 5) << 4), (x_pre + 5 - x_min + y) << 4, strand);
     return mk_cord((gid << 30) + (x_min << 4), y << 4, strand);
 }
 // SIMT-uniform: on the device every lane of the wave executes this with the same arguments (see window_best3);
 // `tail` is the value of cords.back(), carried in a register so that no lane has to re-read the leader's store.
+template <bool COOP = true>
 LNR_HD inline bool extend_window_serial(FeatView f1, FeatView f2, Vec<u64> &cords, u64 &tail, u64 cordy_str, u64 cordy_end) {   // pmpfinder.cpp:1152-1178
     u32 p_str = cords.n - 1;
     u64 nc;
-    while ((nc = previous_window(f1, f2, tail)) && cord_y(nc) >= cordy_str) {
-        if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return false; }
-        cords.push_u(nc); tail = nc;
+    while ((nc = previous_window<COOP>(f1, f2, tail)) && cord_y(nc) >= cordy_str) {
+        if (cords.n >= cords.cap) { if (lnr_leader<COOP>()) *cords.ovf = 1; return false; }
+        cords.template push_m<COOP>(nc); tail = nc;
     }
     u32 p_end = cords.n;
     if (p_end - p_str > 1) {
-        lnr_wave_sync();
-        if (lnr_is_leader())
+        lnr_sync<COOP>();
+        if (lnr_leader<COOP>())
             for (u32 k = p_str; k < (p_str + p_end) / 2; k++) rs_swap(cords[k], cords[cords.n - k + p_str - 1]);
-        lnr_wave_sync();
+        lnr_sync<COOP>();
         tail = cords[cords.n - 1];
     }
-    while ((nc = next_window(f1, f2, tail)) && cord_y(nc) + 96 < cordy_end) {
-        if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return false; }
-        cords.push_u(nc); tail = nc;
+    while ((nc = next_window<COOP>(f1, f2, tail)) && cord_y(nc) + 96 < cordy_end) {
+        if (cords.n >= cords.cap) { if (lnr_leader<COOP>()) *cords.ovf = 1; return false; }
+        cords.template push_m<COOP>(nc); tail = nc;
     }
     return true;
 }
@@ -1095,11 +1113,12 @@ LNR_HD inline u32 filter_hits_apply(u64 *hits, u32 nhits, const i32 *keep) {
     return nhits - mv;
 }
 // SIMT-uniform (all lanes execute it together on the device; hits are read-only, cords are written by the leader).
+template <bool COOP = true>
 LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], GenomeFeat g, Vec<u64> &cords, u64 read_str, u64 read_end, u64 L) {   // pmpfinder.cpp:1309-1410
     i64 hitBegin = 1, hitEnd = (i64)nhits;
     if (hitBegin >= hitEnd - 1) return;
     u64 tail;
-    if (cords.n == 0) { cords.push_u(F_END); tail = F_END; }   // initCords
+    if (cords.n == 0) { cords.template push_m<COOP>(F_END); tail = F_END; }   // initCords
     else tail = cords[cords.n - 1];
     u64 ready_str, ready_end, cordy_str = 0, cordy_end = 0;
     bool f_sp_l, f_sp_r = false, f_block_end = false, f_append;
@@ -1123,8 +1142,8 @@ LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], 
         if (!f_sp_r && !f_block_end) {
             cordy_str = f_sp_l ? hi : (first_i ? ready_str : cord_y(tail));
             cordy_end = cord_y(hits[itt_next]);
-            if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return; }
-            cords.push_u(hi & ~F_END); tail = hi & ~F_END;
+            if (cords.n >= cords.cap) { if (lnr_leader<COOP>()) *cords.ovf = 1; return; }
+            cords.template push_m<COOP>(hi & ~F_END); tail = hi & ~F_END;
             f_append = true;
         } else {
             u64 hl = hits[itt_next - 1];
@@ -1132,14 +1151,15 @@ LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], 
                 u64 nc = shift_cord(hl, -96, -96);
                 cordy_str = first_i ? read_str : cord_y(nc);
                 cordy_end = cord_y(hl);
-                if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return; }
-                cords.push_u(nc & ~F_END); tail = nc & ~F_END;
+                if (cords.n >= cords.cap) { if (lnr_leader<COOP>()) *cords.ovf = 1; return; }
+                cords.template push_m<COOP>(nc & ~F_END); tail = nc & ~F_END;
                 f_append = true;
             }
         }
         if (is_end(hi) || f_block_end) { f_block_end = true; cordy_end = ready_end; }
-        if (f_append && !extend_window(f1[cord_strand(hi)], f2_view(g, cord_id(hi)), cords, tail, cordy_str, cordy_end)) return;
-        if (f_block_end) { tail |= F_END; if (lnr_is_leader()) cords[cords.n - 1] = tail; }
+        if (f_append && !(COOP ? extend_window(f1[cord_strand(hi)], f2_view(g, cord_id(hi)), cords, tail, cordy_str, cordy_end)
+                               : extend_window_serial<false>(f1[cord_strand(hi)], f2_view(g, cord_id(hi)), cords, tail, cordy_str, cordy_end))) return;
+        if (f_block_end) { tail |= F_END; if (lnr_leader<COOP>()) cords[cords.n - 1] = tail; }
         itt_next = f_block_end ? itt_first : itt_next;
         f_sp_r = false; f_block_end = false;
     }

@@ -1955,6 +1955,19 @@ __device__ void best_chains_block(const u32 *xs, const u32 *ys, u32 m, Rec r, in
     }
 }
 
+// Where a job's chained hits wait for k_post: the last 12 x cap bytes (16-byte aligned) of its global scratch region.  The
+// region holds 160 x cap + 1 KB (job_scratch_bytes); the job kernel's own carving stays below 140 x cap and k_post's below
+// 124 x cap, both from the front.
+#ifndef POST_MAX_HITS
+#define POST_MAX_HITS 128
+#endif
+struct PostIn { u64 *hits; i32 *hscore; };
+__device__ __forceinline__ PostIn post_in_of(char *region, u32 cap) {
+    u64 bytes = (job_scratch_bytes(cap) + 255) & ~255ULL;
+    u64 need = ((u64)cap * 12 + 15) & ~15ULL;
+    PostIn p; p.hits = (u64 *)(region + bytes - need); p.hscore = (i32 *)(p.hits + cap);
+    return p;
+}
 // Replays the allocation sequence of the pre phase (global scratch only) from the two counts it left in jstate: n1 = anchors
 // after binning, m = anchors after the list filter.  Same calls in the same order -> same pointers.
 __device__ __forceinline__ void job_replay(const JobArgs &A, u32 j, u32 n1, u32 m, u32 *dyn_lds, Arena &slow, Arena &ar, u64 *&a, JobScratch &S, int *ovf) {
@@ -2010,7 +2023,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
     if (jb >= je) return;
     u32 r = A.J.read[jb];
     u64 L = A.read_len[r];
-    if (threadIdx.x == 0) s_ovf = 0;
+    if (threadIdx.x == 0) { s_ovf = 0; s_flag[3] = 0; }
     if (NW == 1) WSYNC(); else __syncthreads();
     Vec<u64> cords;
     cords.init(A.cords + A.cords_off[r], A.cords_cap[r], &s_ovf);
@@ -2137,7 +2150,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
         // ---------------- chaining DP
         if (NW == 1) {
             if (!ok) break;
-            if (PHASE == 0 && m >= 2) {
+            if ((PHASE == 0 || PHASE == 3) && m >= 2) {
                 best_chains_wave(S.xs, S.ys, m, S.rec, job_parm(mode).score_type, S.cnt, s_tile.tleaf);
             }
         } else {
@@ -2160,6 +2173,22 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             if (m >= 2) traceback_anchor_wave(S.rec, m, sink, S.chain, S.chain_sc, S.cnt, s_flag, &s_ls);
             LNR_TICK(prof, 5, tk_);
             if (NW == 1 && A.stop_after == 6) break;
+            bool handed = false;
+            if (PHASE == 3 && je - jb == 1) {
+                // hand-off to k_post (one lane per read runs the stages a11-a16, which are chains of dependent steps per read).
+                // Only reads with few chained hits go: the block pre-filter is quadratic in the number of hit blocks, fine on one lane
+                // for a typical read and hopeless for a repeat-rich one (those keep the wave-parallel forms below).  Groups of
+                // several jobs (re-map round) stay here too: their jobs append to one cord list in order.
+                u32 nh = S.hits.n;
+                handed = nh <= POST_MAX_HITS && !s_ovf;
+                if (handed) {
+                    WSYNC();
+                    PostIn pi = post_in_of(A.scratch + A.scr_off[j], A.n_anchors[j] + 2);
+                    for (u32 i = (u32)lane; i < nh; i += 64) { pi.hits[i] = S.hits.p[i]; pi.hscore[i] = S.hscore.p[i]; }
+                    if (lane == 0) { A.jstate[2 * j] = m; A.jstate[2 * j + 1] = nh | 0x80000000u; s_flag[3] = 1; }
+                }
+            }
+            if (!handed) {
             JobCtx c;
             c.traceback_done = 1;
             c.L = L; c.read_str = A.J.str[j]; c.read_end = A.J.end[j]; c.mode = mode;
@@ -2212,6 +2241,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
                     LNR_TICK(prof, 9, tk_);
                 }
             }
+            }   // !handed
             WSYNC();
 #ifdef LNR_PROF
             if (A.prof && lane == 0) {   // phase cycles of the job with the most anchors in the DP (per launch class of 4: A.prof + 128 + 16 * class)
@@ -2228,7 +2258,7 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             if (s_ovf) break;             // uniform
         }
     }
-    if (lead && lane == 0) { if (PHASE != 1) A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
+    if (lead && lane == 0) { if (PHASE != 1 && !(PHASE == 3 && s_flag[3])) A.ncords[r] = cords.n; if (s_ovf) A.read_err[r] = 1; }
 #ifdef LNR_PROF
     if (tl) tl[1] = wall_clock64();
 #endif
@@ -2281,6 +2311,74 @@ __global__ void __launch_bounds__(256, 4) k_job_mid(JobArgs A) {
     extern __shared__ u32 dyn_lds[];
     if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
     job_group_run<4>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
+
+// ---- split form (default): the wave-parallel stages a8-a10 (binning .. chaining DP .. traceback) per read in k_job*_a, then
+// k_post with ONE LANE PER READ for the stages that are chains of dependent steps per read (a11-a16: block gathering, block
+// pre-filter, block chaining, window filter, window extension).  In the fused kernels those ran one lane of 64 for 70-80 % of a
+// read's time (phase stamps: extension 37 %, block chaining 19 %, gather + pre-filter 16 % at human scale) while the wave's
+// other lanes idled; here 64 reads share a wave, every read of the batch is resident at once, and the stage is over when its
+// longest chain is.
+__global__ void __launch_bounds__(64, 4) k_job_a(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    job_group_run<1, 3>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
+__global__ void __launch_bounds__(256, 4) k_job_mid_a(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    job_group_run<4, 3>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
+__global__ void __launch_bounds__(1024) k_job_heavy_a(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    job_group_run<16, 3>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
+__global__ void __launch_bounds__(64) k_post(JobArgs A) {
+    u32 pos = A.grp_lo + blockIdx.x * 64 + threadIdx.x;
+    if (pos >= A.grp_hi) return;
+    u32 grp = A.grp_order[pos];
+    u32 jb = A.grp_beg[grp], je = A.grp_beg[grp + 1];
+    if (jb >= je) return;
+    u32 r = A.J.read[jb];
+    if (A.read_err[r]) return;
+    u64 L = A.read_len[r];
+    int ovf = 0;
+    Vec<u64> cords;
+    cords.init(A.cords + A.cords_off[r], A.cords_cap[r], &ovf);
+    cords.n = A.ncords[r];
+    LeaderScratch ls;
+    for (u32 j = jb; j < je && !ovf; j++) {
+        u32 m = A.jstate[2 * j], st = A.jstate[2 * j + 1];
+        if (!(st >> 31)) return;                        // not handed over: the job kernel ran these stages itself (or flagged the read)
+        u32 nh = st & 0x7fffffffu;
+        u32 cap = A.n_anchors[j] + 2;
+        char *region = A.scratch + A.scr_off[j];
+        PostIn pi = post_in_of(region, cap);
+        Arena ar; ar.init(region, (u64)((char *)pi.hits - region));
+        JobScratch S;
+        if (!job_carve(ar, m, S, &ovf)) { ovf = 1; break; }
+        u64 *a2 = ar.get<u64>((u64)m + 2);              // output of _filterBlocksHits (the fused kernel reuses the dead anchor array)
+        if (ar.ovf) { ovf = 1; break; }
+        S.hits.init(pi.hits, cap, &ovf); S.hits.n = nh;
+        S.hscore.init(pi.hscore, cap, &ovf); S.hscore.n = nh;
+        JobCtx c;
+        c.traceback_done = 1;
+        c.L = L; c.read_str = A.J.str[j]; c.read_end = A.J.end[j]; c.mode = (int)A.J.mode[j];
+        u32 nf = A.nf[r];
+        c.f1[0].p = A.f1 + A.f1_off[r]; c.f1[0].n = nf;
+        c.f1[1].p = A.f1 + A.f1_off[r] + nf; c.f1[1].n = nf;
+        c.g = A.g; c.bins = nullptr; c.nbins = 0; c.pair_evals = nullptr; c.prof = nullptr;
+        u64 *H = nullptr; u32 nH = 0;
+        if (job_phase3a(a2, m, S, c, nullptr, H, nH, ls)) { ovf = 1; break; }
+        if (nH >= 2) {
+            filter_hits_flags(H, nH, c.f1, c.g, S.cnt, 0, 1);
+            nH = filter_hits_apply(H, nH, S.cnt);
+            path_dst_2<false>(H, nH, c.f1, c.g, cords, c.read_str, c.read_end, L);
+        }
+    }
+    A.ncords[r] = cords.n;
+    if (ovf) A.read_err[r] = 1;
 }
 
 // Placed on the bulk stream ahead of k_job when multi-wave kernels were launched beside it: a 4- or 16-wave workgroup

@@ -13,10 +13,16 @@ subprocess.check_call([lb.hipcc_path()] + lb.FLAGS + ["-DLNR_PROF", "-o", so, os
 api.SO = so
 f = api.Filter(device=0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-ref = synth.chr22_like()
-f.build_index([ref], 1)
-d_ref = torch.from_numpy(ref).cuda()
-d_reads, d_off = sample_reads_cuda(d_ref, n, 10000, 0.10, 777, non_n_start=10_510_000)
+if len(sys.argv) > 2 and sys.argv[2] == "grch38":
+    from linear_amd.synth_torch import grch38_like_cuda, sample_reads_multi_cuda
+    gen, offs = grch38_like_cuda(torch.device("cuda", 0), seed=38, scale=float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
+    f.build_index_ptrs([gen.data_ptr() + o for o in offs[:-1]], [offs[i + 1] - offs[i] for i in range(24)], 16)
+    d_reads, d_off = sample_reads_multi_cuda(gen, offs, n, 10000, 0.10, 777)
+else:
+    ref = synth.chr22_like()
+    f.build_index([ref], 1)
+    d_ref = torch.from_numpy(ref).cuda()
+    d_reads, d_off = sample_reads_cuda(d_ref, n, 10000, 0.10, 777, non_n_start=10_510_000)
 f.filter_batch_dev(d_reads.data_ptr(), d_off.data_ptr(), n)
 out = (C.c_ulonglong * 192)()
 f.lib.lnr_prof_read.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
