@@ -339,15 +339,26 @@ def main():
 
     parity_ok = True
     if rank == 0 and world == 1 and not double and not args.seed_only:
-        # ---- the drop-in entry point as the caller sees it: host reads in -> host cords out (PCIe both ways); never `value`
-        hb = [(batches[k][0].cpu().numpy(), batches[k][1].cpu().numpy().astype(np.uint64)) for k in range(min(2, nb))]
+        # ---- the drop-in entry point as the caller sees it: host reads in -> host cords out (PCIe both ways); never `value`.
+        # Read blocks sit in pinned memory from lnr_host_alloc (where a front-end's reader would decode them), two batches are in
+        # flight: the upload of batch k + 1 runs under the kernels of batch k (lnr_filter_submit / lnr_filter_wait).
+        nhb = min(4, nb)
+        hb = []
+        for k in range(nhb):
+            buf = flt.host_alloc(int(batches[k][0].numel()))
+            buf[:] = batches[k][0].cpu().numpy()
+            hb.append((buf, batches[k][1].cpu().numpy().astype(np.uint64)))
         flt.filter_batch(*hb[0])
         t0 = time.perf_counter()
-        for r_, o_ in hb:
-            flt.filter_batch(r_, o_)
-        host_rate = args.reads * len(hb) / (time.perf_counter() - t0)
+        flt.filter_submit(*hb[0])
+        for k in range(nhb):
+            if k + 1 < nhb:
+                flt.filter_submit(*hb[k + 1])
+            flt.filter_wait(copy=False)
+        host_rate = args.reads * nhb / (time.perf_counter() - t0)
         out["config"]["host_path_reads_per_s"] = host_rate
-        log(f"[bench] host-buffer entry point lnr_filter_batch (pageable reads in, cords out, PCIe both ways): {host_rate:.0f} reads/s")
+        out["config"]["host_path"] = "lnr_filter_submit / lnr_filter_wait, pinned read blocks, 2 batches in flight; reads H2D + cords D2H included"
+        log(f"[bench] host entry point (pinned reads in, cords out, PCIe both ways, upload overlapped): {host_rate:.0f} reads/s = {host_rate / dev_rate:.0%} of the device-resident rate")
 
     if rank == 0 and world == 1 and not double and not args.no_cpu_baseline and not args.seed_only and host_genome is not None:
         # ---- CPU baseline + parity on a bounded sample of batch 0

@@ -28,6 +28,7 @@
 #ifndef LINEAR_AMD_H
 #define LINEAR_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -38,7 +39,8 @@ typedef struct lnr_ctx lnr_ctx;
 
 typedef enum lnr_status {
     LNR_OK = 0,
-    LNR_ERR_ARG = -1,         /* bad argument (null pointer, base value > 4, >= 1024 sequences, ...) */
+    LNR_ERR_ARG = -1,         /* bad argument (null pointer, offsets not monotone, >= 1024 sequences, ...).  Base ordinals above 4 are not an
+                                 error: they are read as N (4), in reads and in reference sequences alike */
     LNR_ERR_NO_DEVICE = -2,   /* no usable HIP device */
     LNR_ERR_HIP = -3,         /* a HIP runtime call failed; see lnr_last_error */
     LNR_ERR_NOMEM = -4,       /* device or host allocation failed */
@@ -134,7 +136,19 @@ lnr_status lnr_index_adopt(lnr_ctx *ctx);
 /* The hot path.  reads_concat = bases of all reads back to back, off[n+1] = start offsets.
  * Host-buffer form (copies in and out over PCIe): */
 lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads_concat, const uint64_t *off, uint32_t n, lnr_cords *out);
-/* Device-buffer form: d_reads_concat / d_off already in HBM; results stay in HBM. */
+/* The same in two halves, so that one context overlaps transfer and compute: lnr_filter_submit starts the upload of a batch on a
+ * copy stream and returns; lnr_filter_wait runs the oldest submitted batch and returns its cords.  Up to two batches may be in
+ * flight -- submit(k+1) before wait(k) puts the upload of batch k+1 under the kernels of batch k.  The read buffer must stay
+ * untouched until the matching lnr_filter_wait returns; results are valid until the next lnr_filter_wait / lnr_filter_batch.
+ * A read buffer in pinned host memory (lnr_host_alloc, or the caller's own hipHostMalloc / hipHostRegister) is uploaded by one
+ * DMA at link rate; a pageable one goes through the context's pinned staging buffers first. */
+lnr_status lnr_filter_submit(lnr_ctx *ctx, const uint8_t *reads_concat, const uint64_t *off, uint32_t n);
+lnr_status lnr_filter_wait(lnr_ctx *ctx, lnr_cords *out);
+void *lnr_host_alloc(size_t bytes);   /* pinned host memory for read blocks (NULL on failure) */
+void lnr_host_free(void *p);
+/* Device-buffer form: d_reads_concat / d_off already in HBM; results stay in HBM.  Streams: the library works on private
+ * streams.  The device inputs must be complete before the call (the caller synchronises the stream that produced them) and
+ * the results are complete when the call returns.  Every entry point leaves the caller's current HIP device as it found it. */
 lnr_status lnr_filter_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads_concat, const uint64_t *d_off, uint32_t n, lnr_cords_dev *out);
 /* Copy the last device result to the context's host arrays. */
 lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out);
@@ -144,6 +158,19 @@ lnr_status lnr_seed_lookup_batch(lnr_ctx *ctx, const uint8_t *reads_concat, cons
 lnr_status lnr_seed_lookup_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads_concat, const uint64_t *d_off, uint32_t n);
 
 lnr_status lnr_last_stats(const lnr_ctx *ctx, lnr_stats *st);
+
+/* Input side (host code; replaces, for this path, the fetcher's SeqAn readRecords of src/parallel_io.cpp:433-485): FASTA or
+ * FASTQ records, plain or gzip, decoded into the layout lnr_filter_batch / lnr_filter_submit take.  Characters convert as SeqAn's
+ * char -> Dna5 table does (A/a 0, C/c 1, G/g 2, T/t/U/u 3, anything else N = 4).  lnr_reader_next fills dst (e.g. a block from
+ * lnr_host_alloc) with up to max_reads records and at most dst_cap bases, writes off[0 .. *n_out]; *n_out == 0 at end of file.
+ * A record that no longer fits is delivered first by the next call.  lnr_reader_ids: header lines of the last block (without the
+ * '>' / '@'), '\0'-separated, id_off[k] = start of id k. */
+typedef struct lnr_reader lnr_reader;
+lnr_status lnr_reader_open(const char *path, lnr_reader **out);
+lnr_status lnr_reader_next(lnr_reader *r, uint8_t *dst, uint64_t dst_cap, uint64_t *off, uint32_t max_reads, uint32_t *n_out);
+lnr_status lnr_reader_ids(const lnr_reader *r, const char **ids, const uint64_t **id_off);
+const char *lnr_reader_error(const lnr_reader *r);
+void lnr_reader_close(lnr_reader *r);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,8 @@ class LnrError(RuntimeError):
 
 EXPORTS = ["lnr_opts_default", "lnr_create", "lnr_destroy", "lnr_strerror", "lnr_last_error", "lnr_index_build", "lnr_index_info_get",
            "lnr_index_export", "lnr_index_alloc", "lnr_index_blob", "lnr_index_adopt", "lnr_filter_batch", "lnr_filter_batch_dev",
-           "lnr_cords_to_host", "lnr_seed_lookup_batch", "lnr_seed_lookup_batch_dev", "lnr_last_stats"]
+           "lnr_cords_to_host", "lnr_seed_lookup_batch", "lnr_seed_lookup_batch_dev", "lnr_last_stats", "lnr_filter_submit", "lnr_filter_wait",
+           "lnr_host_alloc", "lnr_host_free", "lnr_reader_open", "lnr_reader_next", "lnr_reader_ids", "lnr_reader_error", "lnr_reader_close"]
 
 
 def load_library() -> C.CDLL:
@@ -78,6 +79,17 @@ def load_library() -> C.CDLL:
     lib.lnr_seed_lookup_batch.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.POINTER(LnrAnchors)]
     lib.lnr_seed_lookup_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.lnr_last_stats.argtypes = [C.c_void_p, C.POINTER(LnrStats)]
+    lib.lnr_filter_submit.argtypes = [C.c_void_p, C.c_void_p, _u64p, C.c_uint32]
+    lib.lnr_filter_wait.argtypes = [C.c_void_p, C.POINTER(LnrCords)]
+    lib.lnr_host_alloc.restype = C.c_void_p
+    lib.lnr_host_alloc.argtypes = [C.c_size_t]
+    lib.lnr_host_free.argtypes = [C.c_void_p]
+    lib.lnr_reader_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.lnr_reader_next.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.lnr_reader_ids.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(_u64p)]
+    lib.lnr_reader_error.restype = C.c_char_p
+    lib.lnr_reader_error.argtypes = [C.c_void_p]
+    lib.lnr_reader_close.argtypes = [C.c_void_p]
     return lib
 
 
@@ -109,6 +121,9 @@ class Filter:
         if getattr(self, "h", None):
             self.lib.lnr_destroy(self.h)
             self.h = None
+            for p in getattr(self, "_pinned", []):
+                self.lib.lnr_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -186,6 +201,29 @@ class Filter:
         self._ck(self.lib.lnr_filter_batch(self.h, _p(reads, _u8p), _p(off, _u64p), n, C.byref(out)))
         return self._cords_np(out)
 
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """uint8 array over pinned host memory from lnr_host_alloc (freed with host_free or at close)."""
+        p = self.lib.lnr_host_alloc(nbytes)
+        if not p:
+            raise LnrError(-4, "pinned host allocation failed")
+        a = np.ctypeslib.as_array(C.cast(C.c_void_p(p), _u8p), shape=(nbytes,))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return a
+
+    def filter_submit(self, reads: np.ndarray, off: np.ndarray):
+        """Starts the upload of a batch (at most two in flight); reads/off must stay alive and unchanged until filter_wait."""
+        assert reads.dtype == np.uint8 and reads.flags.c_contiguous and off.dtype == np.uint64 and off.flags.c_contiguous
+        self._inflight = getattr(self, "_inflight", [])
+        self._inflight.append((reads, off))
+        self._ck(self.lib.lnr_filter_submit(self.h, C.c_void_p(reads.ctypes.data), _p(off, _u64p), off.size - 1))
+
+    def filter_wait(self, copy: bool = True):
+        out = LnrCords()
+        self._ck(self.lib.lnr_filter_wait(self.h, C.byref(out)))
+        self._inflight.pop(0)
+        return self._cords_np(out) if copy else (out.n_reads, out.n_cords)
+
     @staticmethod
     def _cords_np(out: "LnrCords"):
         n = out.n_reads
@@ -224,3 +262,40 @@ class Filter:
         st = LnrStats()
         self._ck(self.lib.lnr_last_stats(self.h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in LnrStats._fields_}
+
+
+class Reader:
+    """FASTA / FASTQ (plain or gzip) -> blocks in the ABI's layout (host code; no GPU needed)."""
+
+    def __init__(self, path: str):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.lnr_reader_open(os.fsencode(path), C.byref(h))
+        if st != 0:
+            raise LnrError(st, self.lib.lnr_strerror(st).decode(), path)
+        self.h = h
+
+    def next(self, dst: np.ndarray, max_reads: int):
+        """Fills dst (uint8, e.g. Filter.host_alloc) -> (n, off[n+1], ids[n]); n == 0 at end of file."""
+        off = np.zeros(max_reads + 1, np.uint64)
+        n = C.c_uint32()
+        st = self.lib.lnr_reader_next(self.h, C.c_void_p(dst.ctypes.data), dst.size, _p(off, _u64p), max_reads, C.byref(n))
+        if st != 0:
+            raise LnrError(st, self.lib.lnr_strerror(st).decode(), self.lib.lnr_reader_error(self.h).decode())
+        ids_p, ido_p = C.c_char_p(), _u64p()
+        self.lib.lnr_reader_ids(self.h, C.byref(ids_p), C.byref(ido_p))
+        ido = np.ctypeslib.as_array(ido_p, shape=(n.value + 1,)) if n.value else np.zeros(1, np.uint64)
+        raw = C.string_at(C.cast(ids_p, C.c_void_p), int(ido[n.value])) if n.value else b""
+        ids = [raw[int(ido[k]):int(ido[k + 1]) - 1].decode(errors="replace") for k in range(n.value)]
+        return n.value, off[: n.value + 1].copy(), ids
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lnr_reader_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace lnr;
@@ -68,6 +69,24 @@ struct PinBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+// Device-to-host readbacks of the batch pipeline land in pinned memory and are copied out after the stream sync: a copy into
+// pageable memory is staged by the runtime, and while another stream uploads the next batch (lnr_filter_submit) such a copy was
+// measured to wait for the whole 1 GB upload.
+struct Readback {
+    struct Item { void *dst; size_t off, bytes; };
+    PinBuf *pin = nullptr;
+    std::vector<Item> items;
+    size_t used = 0;
+    bool begin(PinBuf &p, size_t total) { pin = &p; items.clear(); used = 0; return p.ensure(total + 64); }
+    hipError_t add(void *dst, const void *dsrc, size_t bytes, hipStream_t st) {
+        size_t o = (used + 15) & ~(size_t)15;
+        used = o + bytes;
+        items.push_back({dst, o, bytes});
+        return bytes ? hipMemcpyAsync((char *)pin->p + o, dsrc, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+    }
+    void finish() { for (auto &i : items) if (i.bytes) memcpy(i.dst, (char *)pin->p + i.off, i.bytes); }
+};
+
 static const u64 SEQ_PAD = 64;
 static inline u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
@@ -114,7 +133,14 @@ struct lnr_ctx {
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_start = nullptr, ev_lane[2] = {nullptr, nullptr}, ev_prep = nullptr, ev_f1 = nullptr;
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines (k_ix_lines)
     // ---- batch inputs / per-read arrays
-    DevBuf in_reads, in_off;                       // staging for the host-buffer entry points
+    // host-buffer entry points: two input slots, so that the upload of the next batch (copy stream) runs under the kernels of
+    // the current one (lnr_filter_submit / lnr_filter_wait)
+    DevBuf in_reads[2], in_off[2];
+    PinBuf h_off[2];
+    hipStream_t s_copy = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr};
+    u32 in_n[2] = {0, 0};
+    int in_head = 0, in_count = 0;
     DevBuf rlen, rks, nf, f1_off, f1, pk, nm, pk_off;
     DevBuf cords, out_str, out_end, cords_off, cords_cap, ncords, nout, read_err;
     DevBuf gaps, gaps_off, gaps_cap, ngaps, remap, gdense, gcursor, gpos;
@@ -128,10 +154,12 @@ struct lnr_ctx {
         u32 est_x16 = 64;               // anchors per sample x 16 the seed kernel sizes a job's first segment with (learned from the last batch)
         u64 slots_hint = 0;             // anchor buffer of the last successful launch, per sample x 16
         Timer t_seed;
+        PinBuf h_rb;
     } js[2];
     // (host vectors that feed asynchronous uploads live here, not on the stack: the launch functions return before the copy ran)
     struct Launch { DevBuf grp_order, j_scr_off, job_scr, jstate; std::vector<u32> h_order; std::vector<u64> h_scr_off; } ln[2];
     struct TailBuf { DevBuf off, cap, scr, list; std::vector<u64> h_off; std::vector<u32> h_cap, h_list; } tb[3];
+    PinBuf h_rb[4];                     // pinned landing zones of the small readbacks (per stream that reads back)
     DevBuf prof, tl; u32 tl_round = 0, tl_n[4] = {0, 0, 0, 0}; u32 tl_nh[4] = {0, 0, 0, 0};
     // ---- results
     DevBuf r_off, r_str, r_end;
@@ -329,12 +357,15 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
         S.t_seed.stop(st);
         if (f1_reads && attempt == 0) { lnr_status fs = launch_f1(ctx, f1_reads); if (fs != LNR_OK) return fs; }
         int ovf = 0;
-        HIPCK(hipMemcpyAsync(S.cap.data(), S.j_cap.p, (size_t)nj * 4, hipMemcpyDeviceToHost, st));
-        HIPCK(hipMemcpyAsync(S.look.data(), S.j_look.p, (size_t)nj * 4, hipMemcpyDeviceToHost, st));
-        HIPCK(hipMemcpyAsync(S.nanc.data(), S.j_nanc.p, (size_t)nj * 4, hipMemcpyDeviceToHost, st));
-        HIPCK(hipMemcpyAsync(S.anc_off.data(), S.j_anc_off.p, (size_t)nj * 8, hipMemcpyDeviceToHost, st));
-        HIPCK(hipMemcpyAsync(&ovf, S.seed_ctl.as<char>() + 16, 4, hipMemcpyDeviceToHost, st));
+        Readback rb;
+        if (!rb.begin(S.h_rb, (size_t)nj * 20 + 256)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+        HIPCK(rb.add(S.cap.data(), S.j_cap.p, (size_t)nj * 4, st));
+        HIPCK(rb.add(S.look.data(), S.j_look.p, (size_t)nj * 4, st));
+        HIPCK(rb.add(S.nanc.data(), S.j_nanc.p, (size_t)nj * 4, st));
+        HIPCK(rb.add(S.anc_off.data(), S.j_anc_off.p, (size_t)nj * 8, st));
+        HIPCK(rb.add(&ovf, S.seed_ctl.as<char>() + 16, 4, st));
         HIPCK(hipStreamSynchronize(st));
+        rb.finish();
         if (!ovf) {                                   // only the successful launch is the stage's time
             ctx->stats.seed_count_ms += S.t_seed.ms();
             ctx->stats.seed_count_launches++;
@@ -557,11 +588,17 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
 }
 
 // per-batch host tables + prep / feature kernels.  d_reads/d_off are device pointers.
-lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, BatchHost &B) {
+lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, BatchHost &B, const u64 *h_off = nullptr) {
     B.n = n;
     B.off.resize((size_t)n + 1);
-    HIPCK(hipMemcpyAsync(B.off.data(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCK(hipStreamSynchronize(ctx->stream));
+    if (h_off) memcpy(B.off.data(), h_off, ((size_t)n + 1) * 8);     // the host-buffer entry points know the offsets already
+    else {
+        Readback rb;
+        if (!rb.begin(ctx->h_rb[0], ((size_t)n + 1) * 8)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+        HIPCK(rb.add(B.off.data(), d_off, ((size_t)n + 1) * 8, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        rb.finish();
+    }
     B.len.resize(n); B.nf.resize(n); B.cords_cap.resize(n); B.gaps_cap.resize(n);
     B.f1_off.resize(n); B.cords_off.resize(n); B.gaps_off.resize(n); B.pk_off.resize(n);
     u64 fo = 0, co = 0, go = 0, po = 0;
@@ -619,8 +656,14 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
 lnr_status tail_prepare(lnr_ctx *ctx, const BatchHost &B, TailBuf &tb, const std::vector<u32> *list, hipStream_t st, TailArgs &T) {
     u32 n = B.n;
     std::vector<u32> ncords(n);
-    HIPCK(hipMemcpyAsync(ncords.data(), ctx->ncords.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));   // (counts of reads another lane is still working on are not used)
+    {
+        Readback rb;
+        PinBuf &pb = ctx->h_rb[st == ctx->s_tail ? 2 : (st == ctx->stream ? 1 : 3)];
+        if (!rb.begin(pb, (size_t)n * 4)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+        HIPCK(rb.add(ncords.data(), ctx->ncords.p, (size_t)n * 4, st));
+        HIPCK(hipStreamSynchronize(st));   // (counts of reads another lane is still working on are not used)
+        rb.finish();
+    }
     tb.h_off.assign(n, 0); tb.h_cap.assign(n, 0);
     u64 o = 0;
     u32 cnt = list ? (u32)list->size() : n;
@@ -716,7 +759,7 @@ lnr_status remap_round(lnr_ctx *ctx, const BatchHost &B, const std::vector<u32> 
     return s;
 }
 
-lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, lnr_cords_dev *out) {
+lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, lnr_cords_dev *out, const u64 *h_off = nullptr) {
     if (!ctx->has_index) { ctx->err = "no index: call lnr_index_build or lnr_index_adopt first"; return LNR_ERR_NO_INDEX; }
     reset_stats(ctx);
     ctx->last_n = n; ctx->last_ncords = 0;
@@ -731,7 +774,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     Laps laps;
     ctx->t_total.start(ctx->stream);
     BatchHost B;
-    lnr_status s = prepare_batch(ctx, d_reads, d_off, n, B);
+    lnr_status s = prepare_batch(ctx, d_reads, d_off, n, B, h_off);
     if (s != LNR_OK) return s;
     laps.lap("prepare");
     // round 0: one job per read longer than 200 bases (mapper.cpp:430,440), whole read, default parameters
@@ -813,9 +856,14 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     if (early) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
     std::vector<u32> nout(n);
     std::vector<i32> rerr(n);
-    HIPCK(hipMemcpyAsync(nout.data(), ctx->nout.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCK(hipMemcpyAsync(rerr.data(), ctx->read_err.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCK(hipStreamSynchronize(ctx->stream));
+    {
+        Readback rb;
+        if (!rb.begin(ctx->h_rb[0], (size_t)n * 8 + 64)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+        HIPCK(rb.add(nout.data(), ctx->nout.p, (size_t)n * 4, ctx->stream));
+        HIPCK(rb.add(rerr.data(), ctx->read_err.p, (size_t)n * 4, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        rb.finish();
+    }
     ctx->stats.tail_ms += ctx->t_tail.ms();
     for (u32 i = 0; i < n; i++)
         if (rerr[i]) {
@@ -897,66 +945,77 @@ lnr_status seed_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, bo
     return LNR_OK;
 }
 
-lnr_status stage_reads(lnr_ctx *ctx, const u8 *reads, const u64 *off, u32 n) {
+// memcpy of a large block by a few threads (a pageable source is first copied into pinned staging; one thread moves ~10 GB/s)
+void par_memcpy(void *dst, const void *src, size_t len) {
+    const size_t MIN = 4u << 20;
+    unsigned T = (unsigned)std::min<size_t>(4, len / MIN);
+    if (T < 2) { memcpy(dst, src, len); return; }
+    std::vector<std::thread> th;
+    size_t per = (len / T + 63) & ~(size_t)63;
+    for (unsigned t = 1; t < T; t++) {
+        size_t o = (size_t)t * per, l = o < len ? std::min(per, len - o) : 0;
+        if (l) th.emplace_back([=]() { memcpy((char *)dst + o, (const char *)src + o, l); });
+    }
+    memcpy(dst, src, std::min(per, len));
+    for (auto &t : th) t.join();
+}
+
+// Upload of one batch into input slot `slot`, asynchronously on the copy stream; ev_in[slot] marks its end.
+lnr_status submit_reads(lnr_ctx *ctx, int slot, const u8 *reads, const u64 *off, u32 n) {
     if (!off || (n && !reads)) { ctx->err = "null read buffer"; return LNR_ERR_ARG; }
+    for (u32 i = 0; i < n; i++)
+        if (off[i + 1] < off[i]) { ctx->err = "read offsets not monotone"; return LNR_ERR_ARG; }   // (before anything is sized by them)
     u64 base = off[0], total = off[n] - off[0];
-    ENSURE(ctx->in_reads, std::max<u64>(total, 16));
-    ENSURE(ctx->in_off, ((size_t)n + 1) * 8);
-    std::vector<u64> o((size_t)n + 1);
+    DevBuf &dr = ctx->in_reads[slot], &dof = ctx->in_off[slot];
+    ENSURE(dr, std::max<u64>(total, 16));
+    ENSURE(dof, ((size_t)n + 1) * 8);
+    if (!ctx->h_off[slot].ensure(((size_t)n + 1) * 8)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+    u64 *o = ctx->h_off[slot].as<u64>();
     for (u32 i = 0; i <= n; i++) o[i] = off[i] - base;
-    // the caller's buffer is pageable: copy it through two pinned staging buffers so that the host memcpy of one chunk
-    // overlaps the DMA of the previous one
-    const u64 CH = 32ULL << 20;
+    hipStream_t sc = ctx->s_copy;
     if (total) {
-        for (int k = 0; k < 2; k++) {
-            if (!ctx->h_up[k].ensure(CH)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
-            if (!ctx->ev_up[k]) HIPCK(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
-        }
-        int k = 0;
-        bool used[2] = {false, false};
-        for (u64 o2 = 0; o2 < total; o2 += CH, k ^= 1) {
-            u64 len = std::min<u64>(CH, total - o2);
-            if (used[k]) HIPCK(hipEventSynchronize(ctx->ev_up[k]));   // the DMA out of this staging buffer has finished
-            memcpy(ctx->h_up[k].p, reads + base + o2, len);
-            HIPCK(hipMemcpyAsync(ctx->in_reads.as<u8>() + o2, ctx->h_up[k].p, len, hipMemcpyHostToDevice, ctx->stream));
-            HIPCK(hipEventRecord(ctx->ev_up[k], ctx->stream));
-            used[k] = true;
+        hipPointerAttribute_t at;
+        bool pinned = hipPointerGetAttributes(&at, reads + base) == hipSuccess && at.type == hipMemoryTypeHost;
+        if (!pinned) (void)hipGetLastError();
+        if (pinned) {
+            // the caller filled memory from lnr_host_alloc (or registered its own): one DMA at link rate, no staging copy
+            HIPCK(hipMemcpyAsync(dr.p, reads + base, total, hipMemcpyHostToDevice, sc));
+        } else {
+            // pageable source: through two pinned staging buffers, so that the host copy of one chunk overlaps the DMA of the last
+            const u64 CH = 32ULL << 20;
+            for (int k = 0; k < 2; k++) {
+                if (!ctx->h_up[k].ensure(CH)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+                if (!ctx->ev_up[k]) HIPCK(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
+            }
+            int k = 0;
+            bool used[2] = {false, false};
+            for (u64 o2 = 0; o2 < total; o2 += CH, k ^= 1) {
+                u64 len = std::min<u64>(CH, total - o2);
+                if (used[k]) HIPCK(hipEventSynchronize(ctx->ev_up[k]));   // the DMA out of this staging buffer has finished
+                par_memcpy(ctx->h_up[k].p, reads + base + o2, len);
+                HIPCK(hipMemcpyAsync(dr.as<u8>() + o2, ctx->h_up[k].p, len, hipMemcpyHostToDevice, sc));
+                HIPCK(hipEventRecord(ctx->ev_up[k], sc));
+                used[k] = true;
+            }
         }
     }
-    HIPCK(hipMemcpyAsync(ctx->in_off.p, o.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCK(hipStreamSynchronize(ctx->stream));
+    HIPCK(hipMemcpyAsync(dof.p, o, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, sc));
+    HIPCK(hipEventRecord(ctx->ev_in[slot], sc));
+    ctx->in_n[slot] = n;
     return LNR_OK;
 }
+
+// restores the caller's current device when an entry point returns (a context may live on another device than the one the
+// caller's own HIP / torch code is using)
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 }  // namespace
 
 // ======================================================================= C ABI ====
-// diagnostic (LNR_PREP_DIAG): k_prep on private synthetic buffers, timed with events -- where in the life of the process does it slow down?
-static void prep_selftest(const char *tag, const void *src_override = nullptr, u32 n_override = 0) {
-    if (!getenv("LNR_PREP_DIAG")) return;
-    const u32 n = 100000, L = 10000;
-    static void *src = nullptr, *off = nullptr, *po = nullptr, *pk = nullptr, *nm = nullptr, *ks = nullptr;
-    if (!src) {
-        std::vector<u64> h_off(n + 1), h_po(n + 1); u64 p = 0;
-        for (u32 i = 0; i <= n; i++) { h_off[i] = (u64)i * L; h_po[i] = p; p += 2 * packed_words(L); }
-        (void)hipMalloc(&src, (size_t)n * L + 64); (void)hipMalloc(&off, (n + 1) * 8); (void)hipMalloc(&po, (n + 1) * 8); (void)hipMalloc(&pk, p * 8); (void)hipMalloc(&nm, p * 4); (void)hipMalloc(&ks, n * 4);
-        (void)hipMemset(src, 2, (size_t)n * L + 64);
-        (void)hipMemcpy(off, h_off.data(), (n + 1) * 8, hipMemcpyHostToDevice); (void)hipMemcpy(po, h_po.data(), (n + 1) * 8, hipMemcpyHostToDevice);
-    }
-    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    float best = 1e9f;
-    const void *use_src = src_override ? src_override : src;
-    u32 use_n = n_override ? (n_override < n ? n_override : n) : n;
-    for (int rep = 0; rep < 3; rep++) {
-        (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_prep, dim3(use_n), dim3(256), 0, 0, (const u8 *)use_src, (const u64 *)off, (const u64 *)po, use_n, (u64 *)pk, (u32 *)nm, (i32 *)ks);
-        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
-        float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
-    }
-    fprintf(stderr, "[lnr] k_prep selftest %-28s %.3f ms\n", tag, best);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-}
-
 extern "C" {
 
 void lnr_opts_default(lnr_opts *o) {
@@ -992,7 +1051,10 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     int dev = o.device;
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return LNR_ERR_NO_DEVICE; }
     if (dev >= ndev) return LNR_ERR_ARG;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     if (hipSetDevice(dev) != hipSuccess) return LNR_ERR_NO_DEVICE;
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore_{prev_dev == dev ? -1 : prev_dev};
     lnr_ctx *ctx = new (std::nothrow) lnr_ctx();
     if (!ctx) return LNR_ERR_NOMEM;
     ctx->opts = o;
@@ -1024,6 +1086,8 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
               hipEventCreateWithFlags(&ctx->ev_f1, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->s_multi[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ctx->s_bulk[1], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->s_tail, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) ok = hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming) == hipSuccess;
     ctx->s_bulk[0] = ctx->s_multi[0];
     if (getenv("LNR_LANE0_BULK_STREAM")) ok = ok && hipStreamCreateWithFlags(&ctx->s_bulk[0], hipStreamNonBlocking) == hipSuccess;   // experiment: own stream for lane 0's single-wave kernel
     ctx->s_multi[1] = ctx->stream;
@@ -1033,7 +1097,6 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (!ok) { lnr_destroy(ctx); return LNR_ERR_HIP; }
     ctx->t_prep.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();
     *out = ctx;
-    prep_selftest("end of lnr_create");
     return LNR_OK;
 }
 
@@ -1053,6 +1116,8 @@ void lnr_destroy(lnr_ctx *ctx) {
         if (ctx->ev_lane[l]) (void)hipEventDestroy(ctx->ev_lane[l]);
     }
     if (ctx->s_tail) { (void)hipStreamSynchronize(ctx->s_tail); (void)hipStreamDestroy(ctx->s_tail); }
+    if (ctx->s_copy) { (void)hipStreamSynchronize(ctx->s_copy); (void)hipStreamDestroy(ctx->s_copy); }
+    for (int k = 0; k < 2; k++) if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
     if (ctx->s_bulk[0] && ctx->s_bulk[0] != ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_bulk[0]);
     if (ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_multi[0]);
     if (ctx->s_bulk[1]) (void)hipStreamDestroy(ctx->s_bulk[1]);
@@ -1065,7 +1130,6 @@ void lnr_destroy(lnr_ctx *ctx) {
 }
 
 lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64_t *len, uint32_t nseq, uint32_t T) {
-    prep_selftest("start of lnr_index_build");
     if (!ctx) return LNR_ERR_ARG;
     if (!seq || !len || nseq == 0) { ctx->err = "null/empty sequence set"; return LNR_ERR_ARG; }
     if (nseq >= 1024) { ctx->err = "at most 1023 reference sequences (cord id field; linear.cpp:107)"; return LNR_ERR_LIMIT; }
@@ -1074,7 +1138,7 @@ lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64
         if (!seq[i]) { ctx->err = "null sequence pointer"; return LNR_ERR_ARG; }
         if (len[i] >= (1ULL << 30) - (1ULL << 20)) { ctx->err = "sequence too long for the 30-bit x field (cords.cpp:13-14)"; return LNR_ERR_LIMIT; }
     }
-    HIPCK(hipSetDevice(ctx->device));
+    DevGuard dg_(ctx->device);
     ctx->has_index = false;
     set_index_layout(ctx, len, nseq);
     ctx->info.layout_threads = T;
@@ -1087,6 +1151,10 @@ lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64
         if (len[i]) HIPCK(hipMemcpyAsync(ctx->g.as<u8>() + ctx->seq_off[i], seq[i], len[i], hipMemcpyDefault, ctx->stream));   // host or device source
     Timer tm; tm.init();
     tm.start(ctx->stream);
+    {   // ordinals above 4 -> N
+        u64 n16 = (ctx->info.genome_bytes + 64) / 16;
+        hipLaunchKernelGGL(k_clamp_bases, dim3((u32)((n16 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->g.as<u8>(), n16);
+    }
     // chunks of the T-thread layout (index_util.cpp:1654-1666)
     std::vector<ChunkDesc> chunks;
     u64 nsamp = 0;
@@ -1196,7 +1264,7 @@ lnr_status lnr_index_info_get(const lnr_ctx *ctx, lnr_index_info *info) {
 lnr_status lnr_index_export(lnr_ctx *ctx, int32_t *dir, uint64_t *hs, int32_t *f2, uint64_t *f2_off) {
     if (!ctx) return LNR_ERR_ARG;
     if (!ctx->has_index) return LNR_ERR_NO_INDEX;
-    HIPCK(hipSetDevice(ctx->device));
+    DevGuard dg_(ctx->device);
     HIPCK(hipStreamSynchronize(ctx->stream));
     if (dir) HIPCK(hipMemcpy(dir, ctx->dir.p, ctx->info.dir_len * 4, hipMemcpyDeviceToHost));
     if (hs && ctx->info.hs_len) HIPCK(hipMemcpy(hs, ctx->hs.p, ctx->info.hs_len * 8, hipMemcpyDeviceToHost));
@@ -1211,7 +1279,7 @@ lnr_status lnr_index_export(lnr_ctx *ctx, int32_t *dir, uint64_t *hs, int32_t *f
 
 lnr_status lnr_index_alloc(lnr_ctx *ctx, const lnr_index_info *info, const uint64_t *seq_len) {
     if (!ctx || !info || !seq_len || info->nseq == 0 || info->nseq >= 1024) return LNR_ERR_ARG;
-    HIPCK(hipSetDevice(ctx->device));
+    DevGuard dg_(ctx->device);
     ctx->has_index = false;
     set_index_layout(ctx, seq_len, info->nseq);
     if (ctx->info.genome_bytes != info->genome_bytes || ctx->info.f2_len != info->f2_len || ctx->info.dir_len != info->dir_len) {
@@ -1243,7 +1311,7 @@ lnr_status lnr_index_blob(lnr_ctx *ctx, uint32_t which, void **d_ptr, uint64_t *
 lnr_status lnr_index_adopt(lnr_ctx *ctx) {
     if (!ctx) return LNR_ERR_ARG;
     if (!ctx->g.p || !ctx->dir.p || !ctx->hs.p || !ctx->f2.p) return LNR_ERR_NO_INDEX;
-    HIPCK(hipSetDevice(ctx->device));
+    DevGuard dg_(ctx->device);
     u64 nb = ctx->info.dir_len - 1, nwords = (((nb + (1u << BM_GROUP_LOG2) - 1) >> BM_GROUP_LOG2) + 31) / 32;   // derived structure: rebuilt from the received dir
     ENSURE(ctx->bm, nwords * 4 + 16);
     hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
@@ -1258,15 +1326,13 @@ lnr_status lnr_index_adopt(lnr_ctx *ctx) {
 
 lnr_status lnr_filter_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_off, uint32_t n, lnr_cords_dev *out) {
     if (!ctx || !d_off || (n && !d_reads)) return LNR_ERR_ARG;
-    HIPCK(hipSetDevice(ctx->device));
-    prep_selftest("before filter_dev");
+    DevGuard dg_(ctx->device);
     lnr_status st_ = filter_dev(ctx, d_reads, d_off, n, out);
-    prep_selftest("after filter_dev");
     return st_;
 }
 lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out) {
     if (!ctx || !out) return LNR_ERR_ARG;
-    HIPCK(hipSetDevice(ctx->device));
+    DevGuard dg_(ctx->device);
     u64 tot = ctx->last_ncords;
     if (!ctx->h_cords_str.ensure(std::max<u64>(tot * 8, 16)) || !ctx->h_cords_end.ensure(std::max<u64>(tot * 8, 16))) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
     if (ctx->h_cord_off.size() != (size_t)ctx->last_n + 1) ctx->h_cord_off.assign((size_t)ctx->last_n + 1, 0);
@@ -1279,32 +1345,57 @@ lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out) {
     out->cord_off = ctx->h_cord_off.data(); out->cords_str = ctx->h_cords_str.as<u64>(); out->cords_end = ctx->h_cords_end.as<u64>();
     return LNR_OK;
 }
+void *lnr_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void lnr_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+lnr_status lnr_filter_submit(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *off, uint32_t n) {
+    if (!ctx) return LNR_ERR_ARG;
+    DevGuard dg_(ctx->device);
+    if (!ctx->has_index) { ctx->err = "no index"; return LNR_ERR_NO_INDEX; }
+    if (ctx->in_count >= 2) { ctx->err = "two batches already in flight: call lnr_filter_wait first"; return LNR_ERR_ARG; }
+    int slot = (ctx->in_head + ctx->in_count) & 1;
+    lnr_status s = submit_reads(ctx, slot, reads, off, n);
+    if (s != LNR_OK) return s;
+    ctx->in_count++;
+    return LNR_OK;
+}
+lnr_status lnr_filter_wait(lnr_ctx *ctx, lnr_cords *out) {
+    if (!ctx || !out) return LNR_ERR_ARG;
+    DevGuard dg_(ctx->device);
+    if (ctx->in_count == 0) { ctx->err = "no batch in flight"; return LNR_ERR_ARG; }
+    int slot = ctx->in_head;
+    ctx->in_head ^= 1; ctx->in_count--;
+    HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_in[slot], 0));
+    lnr_status s = filter_dev(ctx, ctx->in_reads[slot].as<u8>(), ctx->in_off[slot].as<u64>(), ctx->in_n[slot], nullptr, ctx->h_off[slot].as<u64>());
+    if (s != LNR_OK) return s;
+    return lnr_cords_to_host(ctx, out);
+}
 lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *off, uint32_t n, lnr_cords *out) {
     if (!ctx || !out) return LNR_ERR_ARG;
-    HIPCK(hipSetDevice(ctx->device));
-    if (!ctx->has_index) { ctx->err = "no index"; return LNR_ERR_NO_INDEX; }
-    lnr_status s = stage_reads(ctx, reads, off, n);
+    if (ctx->in_count) { ctx->err = "batches submitted with lnr_filter_submit are still in flight"; return LNR_ERR_ARG; }
+    lnr_status s = lnr_filter_submit(ctx, reads, off, n);
     if (s != LNR_OK) return s;
-    prep_selftest("before filter_dev (host entry)");
-    if ((s = filter_dev(ctx, ctx->in_reads.as<u8>(), ctx->in_off.as<u64>(), n, nullptr)) != LNR_OK) return s;
-    prep_selftest("after filter_dev (host entry)");
-    prep_selftest("same, synthetic, n reads", nullptr, n);
-    prep_selftest("same, the caller's reads", ctx->in_reads.p, n);
-    return lnr_cords_to_host(ctx, out);
+    return lnr_filter_wait(ctx, out);
 }
 
 lnr_status lnr_seed_lookup_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_off, uint32_t n) {
     if (!ctx || !d_off || (n && !d_reads)) return LNR_ERR_ARG;
-    HIPCK(hipSetDevice(ctx->device));
+    DevGuard dg_(ctx->device);
     return seed_dev(ctx, d_reads, d_off, n, false);
 }
 lnr_status lnr_seed_lookup_batch(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *off, uint32_t n, lnr_anchors *out) {
     if (!ctx || !out) return LNR_ERR_ARG;
-    HIPCK(hipSetDevice(ctx->device));
+    DevGuard dg_(ctx->device);
     if (!ctx->has_index) { ctx->err = "no index"; return LNR_ERR_NO_INDEX; }
-    lnr_status s = stage_reads(ctx, reads, off, n);
+    if (ctx->in_count) { ctx->err = "batches submitted with lnr_filter_submit are still in flight"; return LNR_ERR_ARG; }
+    lnr_status s = submit_reads(ctx, 0, reads, off, n);
     if (s != LNR_OK) return s;
-    if ((s = seed_dev(ctx, ctx->in_reads.as<u8>(), ctx->in_off.as<u64>(), n, true)) != LNR_OK) return s;
+    HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_in[0], 0));
+    if ((s = seed_dev(ctx, ctx->in_reads[0].as<u8>(), ctx->in_off[0].as<u64>(), n, true)) != LNR_OK) return s;
     out->n_reads = n; out->n_anchors = ctx->h_anchor_off[n];
     out->anchor_off = ctx->h_anchor_off.data(); out->anchors = ctx->h_anchors.data();
     return LNR_OK;

@@ -148,6 +148,22 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan_add(i32 *out, u64 n, const i3
 }
 
 // ============================================================== index build ====
+// base ordinals above 4 are read as N (the reference's Dna5 has no such value; an unvalidated byte would leave the 26-bit
+// minimizer range and corrupt the flag bits the build keeps beside it)
+__global__ void __launch_bounds__(256) k_clamp_bases(u8 *g, u64 n16) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16) return;
+    uint4 v = ((uint4 *)g)[i];
+    u32 w[4] = {v.x, v.y, v.z, v.w};
+    bool ch = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        u32 x = w[k], hi = x & 0xF8F8F8F8u, c5 = ((x & 0x07070707u) + 0x03030303u) & 0x08080808u;   // byte >= 8, or 5..7
+        u32 bad = ((hi | (hi >> 1) | (hi >> 2) | (hi >> 3) | (hi >> 4)) & 0x08080808u) | c5;
+        if (bad) { u32 m = (bad >> 3) * 0xFFu; w[k] = (x & ~m) | (0x04040404u & m); ch = true; }
+    }
+    if (ch) ((uint4 *)g)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
 struct ChunkDesc { u64 seq_off; i64 t_str; u64 samp_base; u32 nsamp; u32 seq_id; i32 ks; i32 C; };
 static const u32 X_MASK = (1u << 26) - 1, X_REC = 1u << 30, X_FIRST = 1u << 31;
 

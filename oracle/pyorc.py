@@ -177,3 +177,17 @@ class Checker:
         self.lib.orc_debug_get(self.h, stage, _p(out, _u64p), out.size)
         self.lib.orc_debug(self.h, 0)
         return out[:n]
+
+
+def ref_read_file(path: str):
+    """The reference's own reader (SeqAn readRecords) on a FASTA / FASTQ(.gz) file -> (bases, off, ids).  TEST-ONLY."""
+    lib = C.CDLL(os.path.join(HERE, "_ref", "libref_linear.so"))
+    lib.ref_read_file.restype = C.c_uint64
+    lib.ref_read_file.argtypes = [C.c_char_p, _u8p, C.c_uint64, _u64p, C.c_uint64, C.c_char_p, C.c_uint64]
+    cap = max(os.path.getsize(path) * 12, 1 << 16)
+    bases = np.zeros(cap, np.uint8)
+    off = np.zeros(1 << 16, np.uint64)
+    ids = C.create_string_buffer(1 << 22)
+    n = lib.ref_read_file(os.fsencode(path), _p(bases, _u8p), cap, _p(off, _u64p), off.size - 1, ids, len(ids))
+    assert n < (1 << 60), f"ref_read_file failed ({n:#x})"
+    return bases[: int(off[n])].copy(), off[: n + 1].copy(), ids.value.decode(errors="replace").split("\n")[:n]

@@ -14,6 +14,7 @@
 #include "index_util.h"
 #include "cluster_util.h"
 #include "pmpfinder.h"
+#include <seqan/seq_io.h>
 #include <omp.h>
 #include <vector>
 #include <cstring>
@@ -176,6 +177,36 @@ uint64_t ref_map_batch(void *h, const uint8_t *reads, const uint64_t *off, uint3
         cord_off[i + 1] = tot;
     }
     return tot;
+}
+
+// The reference's reader: SeqAn readRecords on a SeqFileIn, the call of its fetcher (src/parallel_io.cpp:433-485), into
+// StringSet<String<Dna5>>.  Pins the product's own FASTA / FASTQ reader (linear_amd/csrc/lnr_reader.cpp): same records, same
+// ordinals, same ids.  Returns the number of records; bases back to back, off[n+1]; ids '\n'-separated.
+uint64_t ref_read_file(const char *path, uint8_t *bases, uint64_t cap, uint64_t *off, uint64_t max_n, char *ids, uint64_t ids_cap) {
+    SeqFileIn fin;
+    if (!open(fin, path)) return ~0ULL;
+    StringSet<CharString> idset;
+    StringSet<String<Dna5> > seqs;
+    uint64_t n = 0, used = 0, iu = 0;
+    off[0] = 0;
+    try {
+        while (!atEnd(fin)) {
+            clear(idset); clear(seqs);
+            readRecords(idset, seqs, fin, 100);
+            for (unsigned i = 0; i < length(seqs) && n < max_n; i++) {
+                uint64_t L = length(seqs[i]);
+                if (used + L > cap) return ~1ULL;
+                for (uint64_t k = 0; k < L; k++) bases[used + k] = (uint8_t)ordValue(seqs[i][k]);
+                used += L;
+                off[++n] = used;
+                uint64_t il = length(idset[i]);
+                if (iu + il + 1 > ids_cap) return ~2ULL;
+                memcpy(ids + iu, toCString(idset[i]), il); iu += il; ids[iu++] = '\n';
+            }
+        }
+    } catch (...) { return ~3ULL; }
+    if (iu < ids_cap) ids[iu] = 0;
+    return n;
 }
 
 // stage dumps reproduced by calling the reference's own stage functions in apxMap_'s order

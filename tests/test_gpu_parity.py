@@ -101,10 +101,10 @@ def test_gpu_scratch_slicing(oracle_lib):
     f.close()
 
 
-@pytest.mark.parametrize("var,val", [("LNR_MID_CAP", "64"), ("LNR_DP_SPLIT_CAP", "64"), ("LNR_SPLIT_CAP", "300")])
+@pytest.mark.parametrize("var,val", [("LNR_MID_CAP", "64"), ("LNR_DP_SPLIT_CAP", "64"), ("LNR_SPLIT_CAP", "300"), ("LNR_POST_SPLIT", "1")])
 def test_gpu_other_size_class_paths(case_inputs, monkeypatch, var, val):
     """Force the reads through the 4-wave kernel, the split path (pre -> 16-wave DP kernel -> post) and the two-lane
-    orchestration: same cords as the reference."""
+    orchestration, and the k_post split (serial stages with one lane per read): same cords as the reference."""
     from linear_amd import Filter
     monkeypatch.setenv(var, val)
     f = Filter(device=0)
@@ -224,3 +224,61 @@ def test_gpu_reads_that_begin_inside_an_n_run(oracle_lib):
     ooff, ocs, oce, _ = o.map_batch(reads, off, threads=2)
     assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
     assert cs.size > 0
+
+
+def test_gpu_submit_wait_pipeline_and_pinned_input(case_inputs):
+    """lnr_filter_submit / lnr_filter_wait with two batches in flight, one from pinned memory (lnr_host_alloc: direct DMA) and one
+    from a pageable numpy array (staged): the cords of each batch equal the reference's, in submission order."""
+    from linear_amd import Filter, LnrError
+    refs, reads, off = case_inputs("ont")
+    g = np.load(os.path.join(GOLD, "ont_T4.npz"))
+    f = Filter(device=0)
+    f.build_index(refs, 4)
+    n = off.size - 1
+    h = n // 2
+    pin = f.host_alloc(int(off[h]))
+    pin[:] = reads[: int(off[h])]
+    o1 = np.ascontiguousarray(off[: h + 1])
+    r2 = np.ascontiguousarray(reads[int(off[h]):])
+    o2 = np.ascontiguousarray(off[h:] - off[h])
+    for _ in range(2):
+        f.filter_submit(pin, o1)
+        f.filter_submit(r2, o2)
+        with pytest.raises(LnrError):
+            f.filter_submit(r2, o2)          # a third batch in flight is refused
+        c1 = f.filter_wait()
+        c2 = f.filter_wait()
+        coff, cs, ce = g["cord_off"], g["cords_str"], g["cords_end"]
+        k = int(coff[h])
+        assert np.array_equal(c1[0], coff[: h + 1]) and np.array_equal(c1[1], cs[:k]) and np.array_equal(c1[2], ce[:k])
+        assert np.array_equal(c2[0], coff[h:] - coff[h]) and np.array_equal(c2[1], cs[k:]) and np.array_equal(c2[2], ce[k:])
+    with pytest.raises(LnrError):
+        f.filter_wait()
+    bad = np.array([0, 10, 5], dtype=np.uint64)
+    with pytest.raises(LnrError) as e:
+        f.filter_batch(reads[:10], bad)
+    assert e.value.status == -1               # offsets not monotone -> LNR_ERR_ARG, not an allocation failure
+    f.close()
+
+
+def test_gpu_base_values_above_4_read_as_n(oracle_lib):
+    """Bytes above 4 in the reference or in a read are taken as N (header contract), never fed raw into the hash arithmetic."""
+    from linear_amd import Filter, synth
+    ref = synth.random_ref(400_000, 31)
+    dirty = ref.copy()
+    rng = np.random.default_rng(32)
+    pos = rng.integers(1000, 399_000, size=40)
+    dirty[pos] = rng.integers(5, 256, size=40).astype(np.uint8)
+    clean = dirty.copy(); clean[clean > 4] = 4
+    reads, off, _ = synth.sample_reads([clean], 40, 5000, 0.05, 33, "random")
+    rd = reads.copy(); rd[::997] = 200
+    rc = rd.copy(); rc[rc > 4] = 4
+    f = Filter(device=0)
+    f.build_index([dirty], 2)
+    o = oracle_lib.Checker("oracle", [clean], 2)
+    dir_, hs, _, _ = f.index_export()
+    assert np.array_equal(dir_, o.dir()) and np.array_equal(hs, o.hs())
+    coff, cs, ce = f.filter_batch(rd, off)
+    ooff, ocs, oce, _ = o.map_batch(rc, off, threads=4)
+    assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
+    f.close()

@@ -33,6 +33,18 @@ def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     only = sys.argv[1:]
+    if not only or "reader" in only:
+        # input side: the reference's own SeqAn reader on the seeded FASTA / FASTQ fixtures
+        import tempfile
+        from tests import reader_cases
+        with tempfile.TemporaryDirectory() as td:
+            files, _ = reader_cases.write_cases(td)
+            d = {}
+            for name, path in files.items():
+                b, o, ids = pyorc.ref_read_file(path)
+                d[name + ":bases"], d[name + ":off"], d[name + ":ids"] = b, o, np.array(ids)
+            np.savez_compressed(os.path.join(outdir, "reader.npz"), **d)
+            print("reader.npz:", {k: int(v.size) for k, v in d.items() if k.endswith(":off")})
     for name, (builder, layouts) in cases.CASES.items():
         if only and name not in only:
             continue
