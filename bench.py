@@ -342,7 +342,7 @@ def main():
         # ---- the drop-in entry point as the caller sees it: host reads in -> host cords out (PCIe both ways); never `value`.
         # Read blocks sit in pinned memory from lnr_host_alloc (where a front-end's reader would decode them), two batches are in
         # flight: the upload of batch k + 1 runs under the kernels of batch k (lnr_filter_submit / lnr_filter_wait).
-        nhb = min(4, nb)
+        nhb = min(8, nb)
         hb = []
         for k in range(nhb):
             buf = flt.host_alloc(int(batches[k][0].numel()))

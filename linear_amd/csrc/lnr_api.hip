@@ -24,8 +24,9 @@ struct DevBuf {
     size_t cap = 0;
     bool ensure(size_t bytes) {
         if (bytes <= cap && p) return true;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t nc = bytes + bytes / 8 + 4096;
+        bool grown = p != nullptr;          // a buffer that had to grow once gets half as much again: batch-dependent sizes creep, and
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }   // re-allocating GBs in the middle of a run costs hundreds of ms
+        size_t nc = bytes + (grown ? bytes / 2 : bytes / 8) + 4096;
         if (hipMalloc(&p, nc) != hipSuccess) { p = nullptr; cap = 0; (void)hipGetLastError(); return false; }
         cap = nc;
         return true;
@@ -56,8 +57,9 @@ struct PinBuf {
     size_t cap = 0;
     bool ensure(size_t bytes) {
         if (bytes <= cap && p) return true;
+        bool grown = p != nullptr;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        size_t nc = bytes + bytes / 8 + 4096;
+        size_t nc = bytes + (grown ? bytes / 2 : bytes / 8) + 4096;
         if (hipHostMalloc(&p, nc, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; (void)hipGetLastError(); return false; }
         cap = nc;
         return true;
@@ -69,23 +71,36 @@ struct PinBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
-// Device-to-host readbacks of the batch pipeline land in pinned memory and are copied out after the stream sync: a copy into
-// pageable memory is staged by the runtime, and while another stream uploads the next batch (lnr_filter_submit) such a copy was
-// measured to wait for the whole 1 GB upload.
+// Device-to-host readbacks of the batch pipeline (counts, flags: a few MB per batch) land in pinned memory and are copied out
+// after the stream sync.  They are written there by a kernel's stores, not by a DMA copy: while the copy stream uploads the next
+// batch (lnr_filter_submit, 1 GB, 18 ms) a DMA readback on the compute stream was measured to queue behind that upload -- the
+// seed stage took 24 ms instead of 6.7 -- and a copy into pageable memory is staged by the runtime on top of that.
 struct Readback {
     struct Item { void *dst; size_t off, bytes; };
     PinBuf *pin = nullptr;
     std::vector<Item> items;
     size_t used = 0;
-    bool begin(PinBuf &p, size_t total) { pin = &p; items.clear(); used = 0; return p.ensure(total + 64); }
-    hipError_t add(void *dst, const void *dsrc, size_t bytes, hipStream_t st) {
+    bool begin(PinBuf &p, size_t total) { pin = &p; items.clear(); used = 0; return p.ensure(total + 64 * 8); }
+    hipError_t add(void *dst, const void *dsrc, size_t bytes, hipStream_t st) {   // bytes: a multiple of 4, dsrc 4-byte aligned
         size_t o = (used + 15) & ~(size_t)15;
         used = o + bytes;
         items.push_back({dst, o, bytes});
-        return bytes ? hipMemcpyAsync((char *)pin->p + o, dsrc, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+        if (!bytes) return hipSuccess;
+        u64 nw = bytes / 4;
+        hipLaunchKernelGGL(lnr::k_words_out, dim3((u32)std::min<u64>((nw + 255) / 256, 1024)), dim3(256), 0, st, (const u32 *)dsrc, (u32 *)((char *)pin->p + o), nw);
+        return hipGetLastError();
     }
     void finish() { for (auto &i : items) if (i.bytes) memcpy(i.dst, (char *)pin->p + i.off, i.bytes); }
 };
+
+// pinned host -> device for the small per-batch tables, as a kernel's loads (same reason as Readback: a DMA copy on the compute
+// stream queues behind the copy stream's upload of the next batch)
+static inline hipError_t words_in(void *d_dst, const void *h_pinned, size_t bytes, hipStream_t st) {
+    u64 nw = (bytes + 3) / 4;
+    if (!nw) return hipSuccess;
+    hipLaunchKernelGGL(lnr::k_words_out, dim3((u32)std::min<u64>((nw + 255) / 256, 1024)), dim3(256), 0, st, (const u32 *)h_pinned, (u32 *)d_dst, nw);
+    return hipGetLastError();
+}
 
 static const u64 SEQ_PAD = 64;
 static inline u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
@@ -152,7 +167,7 @@ struct lnr_ctx {
         std::vector<u32> cap, look, nanc;
         std::vector<u64> anc_off;
         u32 est_x16 = 64;               // anchors per sample x 16 the seed kernel sizes a job's first segment with (learned from the last batch)
-        u64 slots_hint = 0;             // anchor buffer of the last successful launch, per sample x 16
+        u64 cap_slots = 0;              // anchor buffer capacity (u64 slots), sticky
         Timer t_seed;
         PinBuf h_rb;
     } js[2];
@@ -204,7 +219,7 @@ lnr_status upload(lnr_ctx *ctx, DevBuf &b, const std::vector<T> &v) {
         void *h = b.host_stage(v.size() * sizeof(T));
         if (!h) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
         memcpy(h, v.data(), v.size() * sizeof(T));
-        HIPCK(hipMemcpyAsync(b.p, h, v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        HIPCK(words_in(b.p, h, v.size() * sizeof(T), ctx->stream));
     }
     return LNR_OK;
 }
@@ -299,7 +314,7 @@ lnr_status upload_on(lnr_ctx *ctx, DevBuf &b, const std::vector<T> &v, hipStream
         void *h = b.host_stage(v.size() * sizeof(T));
         if (!h) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
         memcpy(h, v.data(), v.size() * sizeof(T));
-        HIPCK(hipMemcpyAsync(b.p, h, v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCK(words_in(b.p, h, v.size() * sizeof(T), st));
     }
     return LNR_OK;
 }
@@ -339,8 +354,12 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
     ReadArrays R = read_arrays(ctx);
     // anchor buffer: every job starts with a segment of est x samples slots and moves to one of twice the size when that fills
     // up, so the buffer holds the first segments plus room for the moves; a launch that runs out is repeated with twice the room
+    // The capacity is sticky and generous (grown by half when a batch needs more, never shrunk): re-allocating a buffer of a few GB
+    // costs ~300 ms, which one step of a benchmark paid when the estimate crept over the old allocation's slack.
     u64 first_segs = ((hj.nsamp * S.est_x16) >> 4) + (u64)nj * 194;
-    u64 anc_slots = std::max<u64>(first_segs * 2 + (1u << 20), (hj.nsamp * S.slots_hint) >> 4);
+    u64 need_slots = first_segs * 2 + (1u << 20);
+    if (need_slots > S.cap_slots) S.cap_slots = need_slots + need_slots / 2;
+    u64 anc_slots = S.cap_slots;
     bool use_bm = ctx->seed_bm < 0 ? ctx->info.hs_len < (1ULL << 25) : ctx->seed_bm != 0;
     for (int attempt = 0; ; attempt++) {
         ENSURE(S.anchors, anc_slots * 8);
@@ -373,13 +392,13 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
         }
         if (attempt == 5) { ctx->err = "anchor buffer overflow after five resizes"; return LNR_ERR_INTERNAL; }
         anc_slots *= 2;
+        S.cap_slots = anc_slots;
     }
     {   // learn the segment estimate for the next batch: 1.5 x the mean anchors per sample of this one
         u64 tot = 0;
         for (u32 j = 0; j < nj; j++) tot += S.nanc[j];
         if (hj.nsamp) {
             S.est_x16 = (u32)std::min<u64>(std::max<u64>((tot * 24) / hj.nsamp + 8, 32), 400 * 16);
-            S.slots_hint = (anc_slots << 4) / hj.nsamp + 1;
         }
     }
     ctx->stats.jobs += nj;
@@ -470,7 +489,7 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
             void *h = Lx.j_scr_off.host_stage((size_t)nj * 8);
             if (!h) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
             memcpy(h, scr_off.data(), (size_t)nj * 8);
-            HIPCK(hipMemcpyAsync(Lx.j_scr_off.p, h, (size_t)nj * 8, hipMemcpyHostToDevice, sm));
+            HIPCK(words_in(Lx.j_scr_off.p, h, (size_t)nj * 8, sm));
         }
         laps.lap("upload-scr");
         JobArgs A;
@@ -714,17 +733,22 @@ lnr_status remap_round(lnr_ctx *ctx, const BatchHost &B, const std::vector<u32> 
     KCHECK();
     if (!ctx->h_flags.ensure((size_t)n * 12 + 16)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
     u32 *remap = ctx->h_flags.as<u32>(), *ngaps = remap + n, *gpos = ngaps + n, *gtot_p = gpos + n;
-    HIPCK(hipMemcpyAsync(remap, ctx->remap.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCK(hipMemcpyAsync(ngaps, ctx->ngaps.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCK(hipMemcpyAsync(gpos, ctx->gpos.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCK(hipMemcpyAsync(gtot_p, ctx->gcursor.p, 4, hipMemcpyDeviceToHost, st));
+    auto words_out = [&](void *h_dst, const void *d_src, u64 nw) -> hipError_t {   // (kernel stores into pinned memory: see Readback)
+        if (!nw) return hipSuccess;
+        hipLaunchKernelGGL(k_words_out, dim3((u32)std::min<u64>((nw + 255) / 256, 1024)), dim3(256), 0, st, (const u32 *)d_src, (u32 *)h_dst, nw);
+        return hipGetLastError();
+    };
+    HIPCK(words_out(remap, ctx->remap.p, n));
+    HIPCK(words_out(ngaps, ctx->ngaps.p, n));
+    HIPCK(words_out(gpos, ctx->gpos.p, n));
+    HIPCK(words_out(gtot_p, ctx->gcursor.p, 1));
     HIPCK(hipStreamSynchronize(st));
     laps.lap("tail_a+flags");
     u64 gtot = *gtot_p;
     if (gtot == 0) return LNR_OK;
     if (!ctx->h_gaps.ensure(gtot * sizeof(UP))) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
     UP *gaps = ctx->h_gaps.as<UP>();
-    HIPCK(hipMemcpyAsync(gaps, ctx->gdense.p, gtot * sizeof(UP), hipMemcpyDeviceToHost, st));
+    HIPCK(words_out(gaps, ctx->gdense.p, gtot * sizeof(UP) / 4));
     HIPCK(hipStreamSynchronize(st));
     for (u32 i : list) {
         if (!(remap[i] && ngaps[i])) continue;
@@ -881,7 +905,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         void *h = ctx->r_off.host_stage(((size_t)n + 1) * 8);
         if (!h) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
         memcpy(h, ctx->h_cord_off.data(), ((size_t)n + 1) * 8);
-        HIPCK(hipMemcpyAsync(ctx->r_off.p, h, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCK(words_in(ctx->r_off.p, h, ((size_t)n + 1) * 8, ctx->stream));
     }
     hipLaunchKernelGGL(k_gather_out, dim3(n), dim3(64), 0, ctx->stream, ctx->out_str.as<u64>(), ctx->out_end.as<u64>(), ctx->cords_off.as<u64>(), ctx->nout.as<u32>(),
                        ctx->r_off.as<u64>(), n, ctx->r_str.as<u64>(), ctx->r_end.as<u64>());

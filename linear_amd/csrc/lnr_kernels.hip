@@ -91,6 +91,11 @@ __device__ __forceinline__ i64 wave_max_i64(i64 v) {
     return (i64)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)v >> 32), 63) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)v, 63));
 }
 
+// small device -> pinned-host readbacks as a kernel's stores (see Readback in lnr_api.hip)
+__global__ void __launch_bounds__(256) k_words_out(const u32 *src, u32 *dst, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // ============================================================ generic scans ====
 #define SCAN_TPB 256
 #define SCAN_IPT 16
