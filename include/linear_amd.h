@@ -166,11 +166,25 @@ lnr_status lnr_last_stats(const lnr_ctx *ctx, lnr_stats *st);
  * A record that no longer fits is delivered first by the next call.  lnr_reader_ids: header lines of the last block (without the
  * '>' / '@'), '\0'-separated, id_off[k] = start of id k. */
 typedef struct lnr_reader lnr_reader;
+typedef struct lnr_writer lnr_writer;
 lnr_status lnr_reader_open(const char *path, lnr_reader **out);
 lnr_status lnr_reader_next(lnr_reader *r, uint8_t *dst, uint64_t dst_cap, uint64_t *off, uint32_t max_reads, uint32_t *n_out);
 lnr_status lnr_reader_ids(const lnr_reader *r, const char **ids, const uint64_t **id_off);
 const char *lnr_reader_error(const lnr_reader *r);
 void lnr_reader_close(lnr_reader *r);
+
+/* Output side (host threads; replaces, for this path, the calculator's tail cords2BamLink + fillBamRecords, src/mapper.cpp:463-470,
+ * src/f_io.cpp:758-1011, src/align_util.cpp:301-343,452-744, and the printer's writeSam / print_cords_apf, src/f_io.cpp:100-207,
+ * 313-412): the cords of a batch as SAM records (what = 1) or APF text (what = 2), byte for byte what the reference prints for
+ * the same cords with -g 0 (MAPQ 255, flag 16 / 2048, SA:Z of the read's other lines; APF: a blank line before every '@' record
+ * of a read that is not the first of the call, as the reference does per block).  read_ids = header lines, '\0'-separated,
+ * id_off[k] = start of id k (the layout lnr_reader_ids returns); read_len[k] = bases of read k.  The text is owned by the writer
+ * and valid until its next call.  lnr_writer_sam_header: @SQ per sequence, @RG ID: SM:, @PG ID:M1-3 PN:Linear CL:<command_line>. */
+lnr_status lnr_writer_create(const char *const *genome_ids, const uint64_t *genome_len, uint32_t nseq, lnr_writer **out);
+lnr_status lnr_writer_format(lnr_writer *w, const lnr_cords *cords, const uint64_t *read_len, const char *read_ids, const uint64_t *id_off,
+                             int what, uint32_t threads, const char **text, uint64_t *size);
+lnr_status lnr_writer_sam_header(lnr_writer *w, const char *command_line, const char **text, uint64_t *size);
+void lnr_writer_destroy(lnr_writer *w);
 
 #ifdef __cplusplus
 }

@@ -53,7 +53,8 @@ class LnrError(RuntimeError):
 EXPORTS = ["lnr_opts_default", "lnr_create", "lnr_destroy", "lnr_strerror", "lnr_last_error", "lnr_index_build", "lnr_index_info_get",
            "lnr_index_export", "lnr_index_alloc", "lnr_index_blob", "lnr_index_adopt", "lnr_filter_batch", "lnr_filter_batch_dev",
            "lnr_cords_to_host", "lnr_seed_lookup_batch", "lnr_seed_lookup_batch_dev", "lnr_last_stats", "lnr_filter_submit", "lnr_filter_wait",
-           "lnr_host_alloc", "lnr_host_free", "lnr_reader_open", "lnr_reader_next", "lnr_reader_ids", "lnr_reader_error", "lnr_reader_close"]
+           "lnr_host_alloc", "lnr_host_free", "lnr_reader_open", "lnr_reader_next", "lnr_reader_ids", "lnr_reader_error", "lnr_reader_close",
+           "lnr_writer_create", "lnr_writer_format", "lnr_writer_sam_header", "lnr_writer_destroy"]
 
 
 def load_library() -> C.CDLL:
@@ -90,6 +91,10 @@ def load_library() -> C.CDLL:
     lib.lnr_reader_error.restype = C.c_char_p
     lib.lnr_reader_error.argtypes = [C.c_void_p]
     lib.lnr_reader_close.argtypes = [C.c_void_p]
+    lib.lnr_writer_create.argtypes = [C.POINTER(C.c_char_p), _u64p, C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.lnr_writer_format.argtypes = [C.c_void_p, C.POINTER(LnrCords), _u64p, C.c_char_p, _u64p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), _u64p]
+    lib.lnr_writer_sam_header.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), _u64p]
+    lib.lnr_writer_destroy.argtypes = [C.c_void_p]
     return lib
 
 
@@ -292,6 +297,53 @@ class Reader:
     def close(self):
         if getattr(self, "h", None):
             self.lib.lnr_reader_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Writer:
+    """Cords of a batch -> SAM records / APF text (host code; no GPU needed)."""
+
+    def __init__(self, genome_ids: list[str], genome_len: list[int]):
+        self.lib = load_library()
+        arr = (C.c_char_p * len(genome_ids))(*[g.encode() for g in genome_ids])
+        lens = np.array(genome_len, dtype=np.uint64)
+        h = C.c_void_p()
+        st = self.lib.lnr_writer_create(arr, _p(lens, _u64p), len(genome_ids), C.byref(h))
+        if st != 0:
+            raise LnrError(st, self.lib.lnr_strerror(st).decode())
+        self.h = h
+
+    def format(self, cord_off: np.ndarray, cords_str: np.ndarray, cords_end: np.ndarray, read_len: np.ndarray, read_ids: list[str], what: str, threads: int = 4) -> bytes:
+        cord_off = np.ascontiguousarray(cord_off, dtype=np.uint64)
+        cs = np.ascontiguousarray(cords_str, dtype=np.uint64)
+        ce = np.ascontiguousarray(cords_end, dtype=np.uint64)
+        rl = np.ascontiguousarray(read_len, dtype=np.uint64)
+        c = LnrCords()
+        c.n_reads, c.n_cords = cord_off.size - 1, cs.size
+        c.cord_off, c.cords_str, c.cords_end = _p(cord_off, _u64p), _p(cs, _u64p), _p(ce, _u64p)
+        blob = b"".join(i.encode() + b"\0" for i in read_ids)
+        ido = np.zeros(len(read_ids) + 1, np.uint64)
+        ido[1:] = np.cumsum([len(i.encode()) + 1 for i in read_ids])
+        text, size = C.c_void_p(), C.c_uint64()
+        st = self.lib.lnr_writer_format(self.h, C.byref(c), _p(rl, _u64p), blob, _p(ido, _u64p), {"sam": 1, "apf": 2}[what], threads, C.byref(text), C.byref(size))
+        if st != 0:
+            raise LnrError(st, self.lib.lnr_strerror(st).decode())
+        return C.string_at(text, size.value)
+
+    def sam_header(self, command_line: str) -> bytes:
+        text, size = C.c_void_p(), C.c_uint64()
+        self.lib.lnr_writer_sam_header(self.h, command_line.encode(), C.byref(text), C.byref(size))
+        return C.string_at(text, size.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lnr_writer_destroy(self.h)
             self.h = None
 
     def __del__(self):

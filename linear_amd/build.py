@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "liblinear_amd.so")
-SOURCES = ["lnr_api.hip", "lnr_kernels.hip", "lnr_hd.h", "ref_sort.h", "lnr_reader.cpp"]
+SOURCES = ["lnr_api.hip", "lnr_kernels.hip", "lnr_hd.h", "ref_sort.h", "lnr_reader.cpp", "lnr_output.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
@@ -32,10 +32,13 @@ def needs_build() -> bool:
 
 def build(force: bool = False) -> str:
     if force or needs_build():
-        # host-only translation unit (FASTA / FASTQ reader) by the host compiler, device code + C ABI by hipcc, one library
-        obj = os.path.join(HERE, "lnr_reader.o")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-c", os.path.join(CSRC, "lnr_reader.cpp"), "-o", obj])
-        cmd = [hipcc_path()] + FLAGS + ["-o", SO, os.path.join(CSRC, "lnr_api.hip"), "-Wl," + obj, "-lz"]   # (-Wl: hipcc would compile a bare .o as HIP source)
+        # host-only translation units (FASTA / FASTQ reader, SAM / APF writer) by the host compiler, device code + C ABI by hipcc, one library
+        objs = []
+        for src in ("lnr_reader.cpp", "lnr_output.cpp"):
+            obj = os.path.join(HERE, src.replace(".cpp", ".o"))
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-c", os.path.join(CSRC, src), "-o", obj])
+            objs.append("-Wl," + obj)                         # (-Wl: hipcc would compile a bare .o as HIP source)
+        cmd = [hipcc_path()] + FLAGS + ["-o", SO, os.path.join(CSRC, "lnr_api.hip")] + objs + ["-lz", "-lpthread"]
         subprocess.check_call(cmd)
     return SO
 

@@ -161,6 +161,21 @@ class Checker:
         assert tot <= cap, "cord capacity"
         return coff, cs[:tot], ce[:tot], st
 
+    def format(self, reads: np.ndarray, off: np.ndarray, read_ids: list[str], genome_ids: list[str], cmd_line: str = "") -> tuple[bytes, bytes]:
+        """reference only: (SAM records, APF text) of a block, produced by the reference's own cords2BamLink / fillBamRecords /
+        printAlignSamBam / print_cords_apf."""
+        assert self.kind == "ref"
+        import tempfile
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        self.lib.ref_format.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
+        with tempfile.TemporaryDirectory() as td:
+            ps, pa = os.path.join(td, "o.sam"), os.path.join(td, "o.apf")
+            rc = self.lib.ref_format(self.h, _p(reads, _u8p), _p(off, _u64p), off.size - 1, "\n".join(read_ids).encode(), "\n".join(genome_ids).encode(),
+                                     cmd_line.encode(), ps.encode(), pa.encode())
+            assert rc == 0
+            return open(ps, "rb").read(), open(pa, "rb").read()
+
     def stage(self, read: np.ndarray, stage: int) -> np.ndarray:
         """Stage dump of the first apxMap_ pass: 0 raw anchors, 1 filtered, 2 x-desc sorted, 3 hits after anchor chaining
         (oracle additionally: 4 hits after block chaining, 5 after window filter, 6 cords after path_dst)."""

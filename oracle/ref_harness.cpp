@@ -15,6 +15,9 @@
 #include "cluster_util.h"
 #include "pmpfinder.h"
 #include <seqan/seq_io.h>
+#include "f_io.h"
+#include <fstream>
+#include <sstream>
 #include <omp.h>
 #include <vector>
 #include <cstring>
@@ -207,6 +210,54 @@ uint64_t ref_read_file(const char *path, uint8_t *bases, uint64_t cap, uint64_t 
     } catch (...) { return ~3ULL; }
     if (iu < ids_cap) ids[iu] = 0;
     return n;
+}
+
+// Output shaping by the reference's own functions: the calculator's tail (mapper.cpp:463-470: cords2BamLink with
+// thd_large_X 8000 and the preset-1 thd_DI 80 / thd_X 200, mapper.cpp:185-186, then fillBamRecords) and its printers
+// (printAlignSamBam -> writeSam, f_io.cpp:313-412,540-648; print_cords_apf, f_io.cpp:100-207).  SAM (header records built as
+// mapper.cpp:292-320 builds them, written by the reference's printAlignSamHeader) goes to sam_path, APF to apf_path.
+int ref_format(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, const char *read_ids_nl, const char *genome_ids_nl,
+               const char *cmd_line, const char *sam_path, const char *apf_path) {
+    RefCtx *c = (RefCtx *)h;
+    StringSet<String<Dna5> > rds;
+    StringSet<CharString> rids, gids;
+    StringSet<String<uint64_t> > cs, ce;
+    StringSet<String<CordInfo> > cinfo;
+    { std::stringstream ss(read_ids_nl); std::string l; while (std::getline(ss, l)) appendValue(rids, CharString(l.c_str())); }
+    { std::stringstream ss(genome_ids_nl); std::string l; while (std::getline(ss, l)) appendValue(gids, CharString(l.c_str())); }
+    if (length(rids) != n || length(gids) != length(c->g)) return -1;
+    resize(rds, n); resize(cs, n); resize(ce, n); resize(cinfo, n);
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t len = off[i + 1] - off[i];
+        assign_padded(rds[i], reads + off[i], len);
+        if (len <= 200) continue;                                 // mapper.cpp:430,440
+        _compltRvseStr(rds[i], c->com);
+        { uint64_t m = length(c->com); resize(c->com, m + PAD, Dna5(0)); resize(c->com, m); }
+        createFeatures(begin(rds[i]), end(rds[i]), c->f1[0]);
+        createFeatures(begin(c->com), end(c->com), c->f1[1]);
+        apxMap(*c->idx, rds[i], c->anchors, c->hit, c->f1, c->f2, c->gaps, cs[i], ce[i], cinfo[i], 1, c->pg, c->pm);
+    }
+    FIOParms fio;
+    fio.thd_DI = 80; fio.thd_X = 200;
+    fio.f_output_type = 0;
+    fp_handler_.setPrintSam(fio.f_output_type);
+    StringSet<String<BamAlignmentRecordLink> > bam;
+    cords2BamLink(cs, ce, cinfo, bam, rds, 96, 8000, fio.thd_DI, fio.thd_X);
+    fillBamRecords(c->g, rds, gids, rids, bam, fio);
+    {   // header records as Mapper's constructor assembles them (mapper.cpp:292-320; read group / sample name default to "")
+        BamHeaderRecord hr;
+        for (unsigned i = 0; i < length(c->g); i++) {
+            clear(hr); hr.type = seqan::BAM_HEADER_REFERENCE;
+            setTagValue("SN", gids[i], hr); setTagValue("LN", std::to_string(length(c->g[i])), hr);
+            appendValue(fio.bam_header, hr);
+        }
+        clear(hr); hr.type = seqan::BAM_HEADER_READ_GROUP; setTagValue("ID", "", hr); setTagValue("SM", "", hr); appendValue(fio.bam_header, hr);
+        clear(hr); hr.type = seqan::BAM_HEADER_PROGRAM; setTagValue("ID", "M1-3", hr); setTagValue("PN", "Linear", hr); setTagValue("CL", cmd_line, hr);
+        appendValue(fio.bam_header, hr);
+    }
+    { std::ofstream of(sam_path); printAlignSamBam(c->g, rds, gids, rids, bam, of, 1, fio); }
+    { std::ofstream of(apf_path); print_cords_apf(cs, c->g, rds, gids, rids, of); }
+    return 0;
 }
 
 // stage dumps reproduced by calling the reference's own stage functions in apxMap_'s order

@@ -85,3 +85,11 @@ def input_digest(refs, reads, off) -> str:
 
 def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def text_ids(n_reads: int, n_refs: int):
+    """Read / reference names used for the SAM and APF goldens (read ids keep blanks: the reference prints the whole header line)."""
+    return [f"read_{i} len extra={i * 3}" for i in range(n_reads)], [f"chr{k + 1}" for k in range(n_refs)]
+
+
+CMD_LINE = "linear filter reads.fa ref.fa -g 0"

@@ -282,3 +282,21 @@ def test_gpu_base_values_above_4_read_as_n(oracle_lib):
     ooff, ocs, oce, _ = o.map_batch(rc, off, threads=4)
     assert np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)
     f.close()
+
+
+@pytest.mark.parametrize("name,T", [("edge", 3), ("rep", 8), ("scale", 4)])
+def test_gpu_cords_to_sam_and_apf_text(flt, case_inputs, name, T):
+    """north_star's parity surface end to end: reads -> HIP path -> cords -> lnr_writer -> the SAM and APF bytes the reference's
+    own writer functions produced for its own cords (tests/golden, made by tools/make_golden.py through oracle/_ref)."""
+    from linear_amd.api import Writer
+    refs, reads, off = case_inputs(name)
+    g = np.load(os.path.join(GOLD, f"{name}_T{T}.npz"))
+    flt.build_index(refs, T)
+    coff, cs, ce = flt.filter_batch(reads, off)
+    n = off.size - 1
+    rid, gid = cases.text_ids(n, len(refs))
+    w = Writer(gid, [r.size for r in refs])
+    rl = np.diff(off.astype(np.int64)).astype(np.uint64)
+    assert w.sam_header(cases.CMD_LINE) + w.format(coff, cs, ce, rl, rid, "sam") == g["sam"].tobytes()
+    assert w.format(coff, cs, ce, rl, rid, "apf") == g["apf"].tobytes()
+    w.close()

@@ -86,6 +86,10 @@ def main():
                 d[f"st{k}_f1rev"] = r.read_features(rd, 1)
                 a7, _ = r.seed_lookup(rd, 100, rd.size - 50, 7)
                 d[f"st{k}_raw7"] = a7
+            # output shaping: SAM (header + records) and APF text of the whole block, by the reference's own writer functions
+            rid, gid = cases.text_ids(n, len(refs))
+            sam, apf = r.format(reads, off, rid, gid, cases.CMD_LINE)
+            d["sam"], d["apf"] = np.frombuffer(sam, np.uint8), np.frombuffer(apf, np.uint8)
             path = os.path.join(outdir, f"{name}_T{T}.npz")
             np.savez_compressed(path, **d)
             print(f"{path}: reads {n} cords {int(coff[-1])} hs {hs.size} size {os.path.getsize(path) / 1024:.0f} kB")
