@@ -11,7 +11,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "liblinear_amd.so")
-SOURCES = ["lnr_api.hip", "lnr_kernels.hip", "lnr_hd.h", "ref_sort.h", "lnr_reader.cpp", "lnr_output.cpp"]
+CLI = os.path.join(HERE, "linear_filter")
+SOURCES = ["lnr_api.hip", "lnr_kernels.hip", "lnr_hd.h", "ref_sort.h", "lnr_reader.cpp", "lnr_output.cpp", "linear_filter_main.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
@@ -23,7 +24,7 @@ def hipcc_path() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(SO):
+    if not os.path.exists(SO) or not os.path.exists(CLI):
         return True
     t = os.path.getmtime(SO)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "linear_amd.h")]
@@ -40,6 +41,9 @@ def build(force: bool = False) -> str:
             objs.append("-Wl," + obj)                         # (-Wl: hipcc would compile a bare .o as HIP source)
         cmd = [hipcc_path()] + FLAGS + ["-o", SO, os.path.join(CSRC, "lnr_api.hip")] + objs + ["-lz", "-lpthread"]
         subprocess.check_call(cmd)
+        # the `linear filter` front-end over the ABI (plain C++, links the library)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", os.path.join(CSRC, "linear_filter_main.cpp"), "-o", CLI, SO,
+                               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
     return SO
 
 

@@ -300,3 +300,36 @@ def test_gpu_cords_to_sam_and_apf_text(flt, case_inputs, name, T):
     assert w.sam_header(cases.CMD_LINE) + w.format(coff, cs, ce, rl, rid, "sam") == g["sam"].tobytes()
     assert w.format(coff, cs, ce, rl, rid, "apf") == g["apf"].tobytes()
     w.close()
+
+
+def test_gpu_linear_filter_cli_end_to_end(case_inputs, tmp_path):
+    """The front-end binary (linear_amd/linear_filter: reader -> submit / wait -> writer, all through the C ABI) on FASTA files,
+    two reads blocks in flight: its .sam and .apf equal what the reference's writer functions printed for the reference's cords
+    (the @PG line carries the command line and is compared apart; APF blank lines depend on the block size)."""
+    import subprocess
+    from linear_amd import build as lb
+    lb.build()
+    name, T = "edge", 3
+    refs, reads, off = case_inputs(name)
+    g = np.load(os.path.join(GOLD, f"{name}_T{T}.npz"))
+    n = off.size - 1
+    rid, gid = cases.text_ids(n, len(refs))
+    abc = np.frombuffer(b"ACGTN", np.uint8)
+    with open(tmp_path / "ref.fa", "wb") as f:
+        for k, r in enumerate(refs):
+            f.write(b">" + gid[k].encode() + b" some description\n")
+            t = abc[r].tobytes()
+            f.write(b"\n".join(t[i:i + 80] for i in range(0, len(t), 80)) + b"\n")
+    with open(tmp_path / "reads.fa", "wb") as f:
+        for i in range(n):
+            f.write(b">" + rid[i].encode() + b"\n" + abc[reads[int(off[i]):int(off[i + 1])]].tobytes() + b"\n")
+    for block in (1000, 17):
+        p = subprocess.run([lb.CLI, "filter", str(tmp_path / "reads.fa"), str(tmp_path / "ref.fa"), "-t", str(T), "-g", "0", "-o", str(tmp_path / "out"), "-ot", "3", "-b", str(block)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-1000:]
+        sam = open(tmp_path / "out.sam", "rb").read().split(b"\n")
+        want = g["sam"].tobytes().split(b"\n")
+        assert [l for l in sam if not l.startswith(b"@PG")] == [l for l in want if not l.startswith(b"@PG")]
+        assert [l for l in sam if l.startswith(b"@PG")][0].startswith(b"@PG\tID:M1-3\tPN:Linear\tCL:")
+        apf = [l for l in open(tmp_path / "out.apf", "rb").read().split(b"\n") if l]
+        assert apf == [l for l in g["apf"].tobytes().split(b"\n") if l]
