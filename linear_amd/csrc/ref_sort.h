@@ -12,7 +12,7 @@
 // libstdc++ 11 bits/stl_algo.h (std::__sort) and bits/stl_heap.h.
 //
 // Recursion is replaced by an explicit stack (sub-ranges are disjoint, so processing
-// order does not change the result).  tests/test_ref_sort.py fuzzes this against
+// order does not change the result).  tests/test_stage_logic_host.py::test_ref_sort_equals_libstdcxx_sort_with_ties fuzzes this against
 // std::sort with heavy ties on the CPU build.
 #pragma once
 #include <stdint.h>
