@@ -135,6 +135,7 @@ struct lnr_ctx {
     u32 heavy_cap_r1 = 7000, mid_cap_r1 = 3000;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
     bool lane_bulk_first = true;         // two lanes: which lane goes through the re-map round first (LNR_LANE_ORDER=heavy|bulk)
     u32 stop_after = 0;                  // diagnostic: LNR_STOP_AFTER (see JobArgs)
+    bool mid_cap_env = false;            // LNR_MID_CAP given: no density-dependent default
     bool post_split = false;             // a11-a16 in k_post, one lane per read (LNR_POST_SPLIT=0: fused job kernels)
     int seed_bm = -1;                    // bucket bitmap in the seed kernel: -1 = by table density, 0 / 1 forced (LNR_SEED_BM)
     u32 prep_threads = 256;             // workgroup size of k_prep (LNR_PREP_THREADS: 64, 128 or 256)
@@ -515,6 +516,9 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
         // (the re-map round leaves most of the chip idle, so it can afford wider workgroups for more of its reads)
         bool remap_round_ = nj && hj.mode[0] != 0;
         u64 hcap = remap_round_ ? ctx->heavy_cap_r1 : ctx->heavy_cap, mcap = remap_round_ ? ctx->mid_cap_r1 : ctx->mid_cap;
+        // a populated table (human scale) adds ~1 500 chance anchors to every read's weight, and the 4-wave kernel holds 14 of a CU's 16
+        // wave slots while it runs: fewer reads go there (measured on the GRCh38 stand-in: 6144 -> 40.0 ms, 9000 -> 38.6, 12000 -> 38.5, 20000 -> 45)
+        if (!remap_round_ && !ctx->mid_cap_env && ctx->info.hs_len >= (1ULL << 25)) mcap = 9000;
         u64 scap = remap_round_ ? ctx->dp_split_cap_r1 : ctx->dp_split_cap;
         u32 gh = g0;
         while (gh < g1 && w[order[gh]] >= hcap) gh++;
@@ -1088,7 +1092,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_JOB_STAGE_KB")) { long kb = atol(e); if (kb >= 0 && kb <= 60) ctx->job_stage_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_HEAVY_CAP")) { long v = atol(e); if (v >= 64) { ctx->heavy_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->heavy_cap_r1 = ctx->heavy_cap; } }
     if (const char *e = getenv("LNR_HEAVY_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->heavy_lds_kb = (u32)v; }
-    if (const char *e = getenv("LNR_MID_CAP")) { long v = atol(e); if (v >= 64) { ctx->mid_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->mid_cap_r1 = ctx->mid_cap; } }
+    if (const char *e = getenv("LNR_MID_CAP")) { long v = atol(e); if (v >= 64) { ctx->mid_cap_env = true; ctx->mid_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->mid_cap_r1 = ctx->mid_cap; } }
     if (const char *e = getenv("LNR_MID_LDS_KB")) { long v = atol(e); if (v >= 1 && v <= 56) ctx->mid_lds_kb = (u32)v; }
     if (const char *e = getenv("LNR_HEAVY_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->heavy_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_MID_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->mid_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }

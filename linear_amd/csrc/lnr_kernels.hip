@@ -834,7 +834,7 @@ struct JobArgs {
 // (bit 63, unused by the anchor format cords.cpp:319-322) and the compaction strips the mark.
 #define BIN_SAT 100u   /* counts saturate here: only "more than 10" is asked.  At most 64 adds are in flight beyond it (one
                           wave instruction; its undo is issued before the next add), so a byte never carries into its neighbour */
-__device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 hist_bytes, u32 nbins) {
+__device__ u32 binning_exact_wave(u64 *a, u32 n, u32 *binw, u32 hist_bytes, u32 nbins) {
     int lane = lane_id();
     const u64 MARK = 1ULL << 63;
     u32 per = hist_bytes & ~3u;                         // bins per pass
@@ -904,7 +904,76 @@ __device__ u32 binning_wave(u64 *a, u32 n, u32 *binw, u32 hist_bytes, u32 nbins)
         }
     }
     WSYNC();
-    return ii ? ii : n;   // nothing survives -> everything is kept (pmpfinder.cpp:2007-2010)
+    return ii;            // (0: nothing survives; the caller then keeps everything, pmpfinder.cpp:2007-2010)
+}
+
+// binningFilter at human scale.  A read carries ~1 700 anchors into this stage, all but a few hundred of them chance hits spread
+// over the genome, and the exact histogram sweeps the whole list five times (two passes of bins at 6 KB of LDS: count, mark, count,
+// mark, compact), and a reference at the format's length limit would need six passes of bins.  So first a conservative filter: one saturating byte per HASHED bin
+// (bin mod 4096, 4 KB of LDS).  A hashed count is at least the bin's true count, so an anchor whose hashed count is <= 10 is
+// dropped by the reference too; every anchor of a bin that the reference keeps survives.  The survivors (the true clusters plus
+// the few chance hits that share a hashed bin with one) go to `tmp` in order, and the exact histogram runs on them alone: for a
+// bin of more than 10 anchors all members survived, so its count among the survivors is its true count, and a smaller bin stays
+// at or below its true count.  `a` is untouched until the result is known (nothing survives -> everything is kept).
+// (Measured on the GRCh38 stand-in: no change of the kernel's time against the plain two-pass histogram -- the stage costs 1.3 ms of
+// 31 when the kernel has the chip to itself; what made it look like 7 ms was the 4-wave kernel holding 14 of 16 wave slots per CU.)
+#define BIN_HASH 4096u
+__device__ u32 binning_wave(u64 *a, u32 n, u64 *tmp, u32 *binw, u32 hist_bytes, u32 nbins) {
+    int lane = lane_id();
+    if (n <= 256 || hist_bytes < BIN_HASH || !tmp) {           // short lists: the exact histogram directly (in place)
+        u32 k = binning_exact_wave(a, n, binw, hist_bytes, nbins);
+        return k ? k : n;
+    }
+    for (u32 w = lane; w < BIN_HASH / 4; w += 64) binw[w] = 0;
+    WSYNC();
+    for (u32 i0 = 0; i0 < n; i0 += 256) {
+        u64 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { u32 i = i0 + 64 * u + (u32)lane; v[u] = i < n ? a[i] : ~0ULL; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            u32 i = i0 + 64 * u + (u32)lane;
+            u32 b = (u32)(cord_x(v[u]) / 30000);
+            if (i < n && b < nbins) {
+                u32 hb = b & (BIN_HASH - 1), sh = 8 * (hb & 3), inc = 1u << sh;
+                u32 old = atomicAdd(&binw[hb >> 2], inc);
+                if (((old >> sh) & 0xffu) >= BIN_SAT) atomicSub(&binw[hb >> 2], inc);
+            }
+            WLDS();
+        }
+    }
+    WSYNC();
+    u32 s = 0;
+    u64 vn[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { u32 i = 64 * u + (u32)lane; vn[u] = i < n ? a[i] : 0; }
+    for (u32 base = 0; base < n; base += 256) {
+        u64 vc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vc[u] = vn[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { u32 i = base + 256 + 64 * u + (u32)lane; vn[u] = i < n ? a[i] : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (base + 64 * u >= n) break;               // uniform
+            u32 i = base + 64 * u + (u32)lane;
+            bool keep = false;
+            if (i < n) {
+                u32 b = (u32)(cord_x(vc[u]) / 30000);
+                if (b < nbins) { u32 hb = b & (BIN_HASH - 1); keep = ((binw[hb >> 2] >> (8 * (hb & 3))) & 0xffu) > 10; }
+            }
+            u64 mask = __ballot(keep);
+            if (keep) tmp[s + __popcll(mask & lanemask_lt())] = vc[u];
+            s += (u32)__popcll(mask);
+        }
+    }
+    WSYNC();
+    if (s == 0) return n;
+    u32 k = binning_exact_wave(tmp, s, binw, hist_bytes, nbins);
+    if (k == 0) return n;
+    for (u32 i = (u32)lane; i < k; i += 64) a[i] = tmp[i];
+    WSYNC();
+    return k;
 }
 
 // wave-level LSD radix sort, ascending u64 (the reference's ska_sort, base.cpp:570; result unique).
@@ -1996,7 +2065,8 @@ __device__ __forceinline__ void job_replay(const JobArgs &A, u32 j, u32 n1, u32 
     slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
     ar.init((void *)dyn_lds, A.arena_lds); ar.next = &slow;
     a = A.anchors + A.anc_off[j];
-    if (n1 > 1) { (void)slow.get<u64>(cap); a = ar.get<u64>((u64)n1 + 2); }
+    (void)slow.get<u64>(cap);
+    if (n1 > 1) a = ar.get<u64>((u64)n1 + 2);
     if (m > 1) (void)slow.get<u64>((u64)m + 2);
     (void)job_carve(ar, m, S, ovf);
 }
@@ -2080,15 +2150,16 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             n = A.n_anchors[j];
             cap = n + 2;   // scratch is sized by the anchors that passed the Y filter (known before the launch), not by the bucket entries
             LNR_TICK(prof, 0, tk_);
-            n = binning_wave(ag, n, dyn_lds, A.lds_bytes, A.nbins);   // uses the dynamic LDS as its histogram
-            LNR_TICK(prof, 1, tk_);
-            if (NW == 1 && A.stop_after == 2) break;
             // two-level arena: dynamic LDS first (re-used once binning is done), the job's global scratch behind it
             slow.init(A.scratch + A.scr_off[j], job_scratch_bytes(cap));
+            u64 *alt = slow.get<u64>(cap);            // radix ping-pong buffer; before that, the survivors of the binning pre-filter
+            if (NW == 1 && A.stop_after == 1) break;   // (diagnostic: start-up only)
+            n = binning_wave(ag, n, alt, dyn_lds, A.lds_bytes, A.nbins);   // uses the dynamic LDS as its histogram
+            LNR_TICK(prof, 1, tk_);
+            if (NW == 1 && A.stop_after == 2) break;
             ar.init((void *)dyn_lds, A.arena_lds); ar.next = &slow;
             a = ag;
             if (n > 1) {
-                u64 *alt = slow.get<u64>(cap);
                 s_alt = alt;
                 a = ar.get<u64>((u64)n + 2);          // sorted anchors move next to the lanes (LDS when they fit)
                 if (lane == 0) ag[0] = 0;   // filterAnchorsList pmpfinder.cpp:2031
