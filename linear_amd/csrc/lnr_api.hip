@@ -135,6 +135,7 @@ struct lnr_ctx {
     u32 heavy_cap_r1 = 7000, mid_cap_r1 = 3000;   // the same cuts for the re-map round (LNR_HEAVY_CAP_R1, LNR_MID_CAP_R1)
     bool lane_bulk_first = true;         // two lanes: which lane goes through the re-map round first (LNR_LANE_ORDER=heavy|bulk)
     u32 stop_after = 0;                  // diagnostic: LNR_STOP_AFTER (see JobArgs)
+    u32 mid_waves = 0;                   // waves per read of the middle class (LNR_MID_WAVES=2|4; 0 = 2 in round 0 on a populated table, else 4)
     bool mid_cap_env = false;            // LNR_MID_CAP given: no density-dependent default
     bool post_split = false;             // a11-a16 in k_post, one lane per read (LNR_POST_SPLIT=0: fused job kernels)
     int seed_bm = -1;                    // bucket bitmap in the seed kernel: -1 = by table density, 0 / 1 forced (LNR_SEED_BM)
@@ -375,7 +376,7 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
         hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->bl.as<ulonglong2>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->hs.as<u64>(), nj, O, S.est_x16);
         KCHECK();
         S.t_seed.stop(st);
-        if (f1_reads && attempt == 0) { lnr_status fs = launch_f1(ctx, f1_reads); if (fs != LNR_OK) return fs; }
+        if (f1_reads && attempt == 0) { lnr_status fs = launch_f1(ctx, f1_reads); if (fs != LNR_OK) return fs; }   // (beside the seed kernel instead: measured no faster)
         int ovf = 0;
         Readback rb;
         if (!rb.begin(S.h_rb, (size_t)nj * 20 + 256)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
@@ -594,7 +595,11 @@ lnr_status launch_jobs(lnr_ctx *ctx, JobSet &S, Launch &Lx, const HostJobs &hj, 
                 hipLaunchKernelGGL(k_job_mid_a, dim3(gm - gs), dim3(256), ml, s4, M);
                 KCHECK();
                 hipLaunchKernelGGL(k_post, dim3((gm - gs + 63) / 64), dim3(64), 0, s4, M);
-            } else hipLaunchKernelGGL(k_job_mid, dim3(gm - gs), dim3(256), ml, s4, M);
+            } else if (ctx->mid_waves == 2 || (ctx->mid_waves == 0 && !remap_round_ && ctx->info.hs_len >= (1ULL << 25)))
+                // round 0 at human scale is bound by wave slots (16 per CU at 128 VGPRs): two waves per read of this class hold half the slots of
+                // four for a little longer (GRCh38 stand-in: 45.2 vs 47.0 ms per step)
+                hipLaunchKernelGGL(k_job_mid2, dim3(gm - gs), dim3(128), ml, s4, M);
+            else hipLaunchKernelGGL(k_job_mid, dim3(gm - gs), dim3(256), ml, s4, M);
             KCHECK();
         }
         if (fork_m && !after_bulk) HIPCK(hipEventRecord(ctx->ev_join[0], s4));
@@ -1098,6 +1103,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_MID_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->mid_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP")) { long v = atol(e); if (v >= 64) { ctx->dp_split_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->dp_split_cap_r1 = ctx->dp_split_cap; } }
     if (const char *e = getenv("LNR_DP_SPLIT_CAP_R1")) { long v = atol(e); if (v >= 64) ctx->dp_split_cap_r1 = (u32)std::min<long>(v, 0xffffffffL); }
+    if (const char *e = getenv("LNR_MID_WAVES")) ctx->mid_waves = atoi(e) == 2 ? 2 : 4;
     if (const char *e = getenv("LNR_POST_SPLIT")) ctx->post_split = atoi(e) != 0;
     if (const char *e = getenv("LNR_SEED_BM")) ctx->seed_bm = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LNR_STOP_AFTER")) { long v = atol(e); if (v >= 0 && v < 16) ctx->stop_after = (u32)v; }

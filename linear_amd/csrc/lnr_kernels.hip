@@ -2404,6 +2404,12 @@ __global__ void __launch_bounds__(256, 4) k_job_mid(JobArgs A) {
     if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
     job_group_run<4>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
 }
+// the same class on two waves (LNR_MID_WAVES=2): half the wave slots per read for a longer time
+__global__ void __launch_bounds__(128, 4) k_job_mid2(JobArgs A) {
+    extern __shared__ u32 dyn_lds[];
+    if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
+    job_group_run<2>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);
+}
 
 // ---- split form (default): the wave-parallel stages a8-a10 (binning .. chaining DP .. traceback) per read in k_job*_a, then
 // k_post with ONE LANE PER READ for the stages that are chains of dependent steps per read (a11-a16: block gathering, block
