@@ -150,6 +150,17 @@ void lnr_host_free(void *p);
  * streams.  The device inputs must be complete before the call (the caller synchronises the stream that produced them) and
  * the results are complete when the call returns.  Every entry point leaves the caller's current HIP device as it found it. */
 lnr_status lnr_filter_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads_concat, const uint64_t *d_off, uint32_t n, lnr_cords_dev *out);
+/* apx_gaps of the last filter call -- apxMap's second output (include/pmpfinder.h:213-225), the input of the reference's gap
+ * re-mapper mapGaps (src/mapper.cpp:448-453; not part of this library): per read, the uncovered stretches of the read as pairs of
+ * cord words (first, second), as gather_gaps_y_ leaves them before the re-map loop (src/pmpfinder.cpp:2744).  CSR over the reads of
+ * the batch; host arrays owned by the context, valid until the next call. */
+typedef struct lnr_gaps {
+    uint32_t n_reads;
+    uint64_t n_gaps;
+    const uint64_t *gap_off;    /* n_reads + 1 */
+    const uint64_t *gaps;       /* 2 * n_gaps: first, second */
+} lnr_gaps;
+lnr_status lnr_last_gaps(lnr_ctx *ctx, lnr_gaps *out);
 /* Copy the last device result to the context's host arrays. */
 lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out);
 

@@ -34,6 +34,10 @@ class LnrCordsDev(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("n_cords", C.c_uint64), ("d_cord_off", C.c_void_p), ("d_cords_str", C.c_void_p), ("d_cords_end", C.c_void_p)]
 
 
+class LnrGaps(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_gaps", C.c_uint64), ("gap_off", _u64p), ("gaps", _u64p)]
+
+
 class LnrAnchors(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("n_anchors", C.c_uint64), ("anchor_off", _u64p), ("anchors", _u64p)]
 
@@ -54,7 +58,7 @@ EXPORTS = ["lnr_opts_default", "lnr_create", "lnr_destroy", "lnr_strerror", "lnr
            "lnr_index_export", "lnr_index_alloc", "lnr_index_blob", "lnr_index_adopt", "lnr_filter_batch", "lnr_filter_batch_dev",
            "lnr_cords_to_host", "lnr_seed_lookup_batch", "lnr_seed_lookup_batch_dev", "lnr_last_stats", "lnr_filter_submit", "lnr_filter_wait",
            "lnr_host_alloc", "lnr_host_free", "lnr_reader_open", "lnr_reader_next", "lnr_reader_ids", "lnr_reader_error", "lnr_reader_close",
-           "lnr_writer_create", "lnr_writer_format", "lnr_writer_sam_header", "lnr_writer_destroy"]
+           "lnr_writer_create", "lnr_writer_format", "lnr_writer_sam_header", "lnr_writer_destroy", "lnr_last_gaps"]
 
 
 def load_library() -> C.CDLL:
@@ -95,6 +99,7 @@ def load_library() -> C.CDLL:
     lib.lnr_writer_format.argtypes = [C.c_void_p, C.POINTER(LnrCords), _u64p, C.c_char_p, _u64p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), _u64p]
     lib.lnr_writer_sam_header.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), _u64p]
     lib.lnr_writer_destroy.argtypes = [C.c_void_p]
+    lib.lnr_last_gaps.argtypes = [C.c_void_p, C.POINTER(LnrGaps)]
     return lib
 
 
@@ -244,6 +249,14 @@ class Filter:
         out = LnrCordsDev()
         self._ck(self.lib.lnr_filter_batch_dev(self.h, C.c_void_p(d_reads_ptr), C.c_void_p(d_off_ptr), n, C.byref(out)))
         return out
+
+    def last_gaps(self):
+        """apx_gaps of the last filter call: (gap_off[n+1], gaps[k, 2])."""
+        out = LnrGaps()
+        self._ck(self.lib.lnr_last_gaps(self.h, C.byref(out)))
+        goff = np.ctypeslib.as_array(out.gap_off, shape=(out.n_reads + 1,)).copy()
+        g = np.ctypeslib.as_array(out.gaps, shape=(2 * out.n_gaps,)).copy().reshape(-1, 2) if out.n_gaps else np.zeros((0, 2), np.uint64)
+        return goff, g
 
     def cords_to_host(self):
         out = LnrCords()

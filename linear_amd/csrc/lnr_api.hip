@@ -180,7 +180,8 @@ struct lnr_ctx {
     DevBuf prof, tl; u32 tl_round = 0, tl_n[4] = {0, 0, 0, 0}; u32 tl_nh[4] = {0, 0, 0, 0};
     // ---- results
     DevBuf r_off, r_str, r_end;
-    std::vector<u64> h_cord_off, h_anchor_off, h_anchors;
+    std::vector<u64> h_cord_off, h_anchor_off, h_anchors, h_gap_off, h_gap_pairs;
+    std::vector<u64> last_gaps_off;      // per-read offsets into ctx->gaps of the last batch (capacity layout)
     PinBuf h_cords_str, h_cords_end, h_up[2];   // results land in pinned memory (DMA at link rate, no page faults); h_up: upload staging ring
     hipEvent_t ev_up[2] = {nullptr, nullptr};
     std::vector<u32> dbg_r0w;   // round-0 anchors per read (LNR_DEBUG_R1 diagnostic)
@@ -809,6 +810,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     BatchHost B;
     lnr_status s = prepare_batch(ctx, d_reads, d_off, n, B, h_off);
     if (s != LNR_OK) return s;
+    ctx->last_gaps_off = B.gaps_off;
     laps.lap("prepare");
     // round 0: one job per read longer than 200 bases (mapper.cpp:430,440), whole read, default parameters
     HostJobs j0;
@@ -1363,6 +1365,41 @@ lnr_status lnr_filter_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads, const uint
     DevGuard dg_(ctx->device);
     lnr_status st_ = filter_dev(ctx, d_reads, d_off, n, out);
     return st_;
+}
+lnr_status lnr_last_gaps(lnr_ctx *ctx, lnr_gaps *out) {
+    if (!ctx || !out) return LNR_ERR_ARG;
+    DevGuard dg_(ctx->device);
+    u32 n = ctx->last_n;
+    out->n_reads = n; out->n_gaps = 0; out->gap_off = nullptr; out->gaps = nullptr;
+    ctx->h_gap_off.assign((size_t)n + 1, 0);
+    ctx->h_gap_pairs.clear();
+    if (n && ctx->last_gaps_off.size() == n) {
+        std::vector<u32> ng(n);
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        HIPCK(hipMemcpy(ng.data(), ctx->ngaps.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        u64 cap_tot = ctx->last_gaps_off[n - 1] + 0;
+        (void)cap_tot;
+        for (u32 i = 0; i < n; i++) ctx->h_gap_off[i + 1] = ctx->h_gap_off[i] + ng[i];
+        ctx->h_gap_pairs.resize(2 * ctx->h_gap_off[n]);
+        // the device keeps the gaps of a read at its capacity offset; gather them densely (not on the hot path)
+        u64 last = ctx->last_gaps_off[n - 1];
+        std::vector<UP> all;
+        {
+            // capacity of the last read: L / 1000 + 4 for reads longer than 200 (prepare_batch); copy a safe upper bound
+            u64 total_cap = last + 4 + (1u << 10);
+            if (total_cap * sizeof(UP) > ctx->gaps.cap) total_cap = ctx->gaps.cap / sizeof(UP);
+            all.resize(total_cap);
+            if (total_cap) HIPCK(hipMemcpy(all.data(), ctx->gaps.p, total_cap * sizeof(UP), hipMemcpyDeviceToHost));
+        }
+        for (u32 i = 0; i < n; i++)
+            for (u32 k = 0; k < ng[i]; k++) {
+                const UP &g = all[ctx->last_gaps_off[i] + k];
+                ctx->h_gap_pairs[2 * (ctx->h_gap_off[i] + k)] = g.first; ctx->h_gap_pairs[2 * (ctx->h_gap_off[i] + k) + 1] = g.second;
+            }
+    }
+    out->n_gaps = ctx->h_gap_off[n];
+    out->gap_off = ctx->h_gap_off.data(); out->gaps = ctx->h_gap_pairs.data();
+    return LNR_OK;
 }
 lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out) {
     if (!ctx || !out) return LNR_ERR_ARG;

@@ -1438,6 +1438,12 @@ void orc_lookup_hist(void *h, const uint8_t *read, uint64_t len, uint64_t *hist4
         }
     }
 }
+// apx_gaps of the last orc_map_read (apxMap's output for the gap re-mapper, pmpfinder.cpp:2744): pairs of cord words
+uint64_t orc_get_gaps(void *h, uint64_t *out_pairs, uint64_t cap_pairs) {
+    Work &w = ((Ctx *)h)->w;
+    for (size_t i = 0; i < w.apx_gaps.size() && i < cap_pairs; i++) { out_pairs[2 * i] = w.apx_gaps[i].first; out_pairs[2 * i + 1] = w.apx_gaps[i].second; }
+    return w.apx_gaps.size();
+}
 void orc_reset_stats(void *h) { Work *c = &((Ctx *)h)->w; c->stats = Stats(); c->pair_evals = 0; }
 void orc_get_stats(void *h, uint64_t *out5) {
     Work *c = &((Ctx *)h)->w;

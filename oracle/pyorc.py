@@ -141,6 +141,15 @@ class Checker:
         self._f("get_cords")(self.h, _p(cs, _u64p), _p(ce, _u64p))
         return cs[:n], ce[:n]
 
+    def gaps(self) -> np.ndarray:
+        """apx_gaps of the last map_read: [k, 2] cord words (start, end)."""
+        fn = self._f("get_gaps")
+        fn.restype = C.c_uint64
+        fn.argtypes = [C.c_void_p, _u64p, C.c_uint64]
+        out = np.zeros(2 * 4096, np.uint64)
+        n = fn(self.h, _p(out, _u64p), 4096)
+        return out[: 2 * n].reshape(-1, 2).copy()
+
     def map_batch(self, reads: np.ndarray, off: np.ndarray, threads: int = 1):
         """CSR cords for a batch on `threads` host threads; returns (cord_off, cords_str, cords_end, stats5).  The reference
         (kind "ref") runs its own per-thread scratch as Mapper::p_calRecords does and has no counters (stats5 = zeros)."""

@@ -131,6 +131,11 @@ uint64_t ref_map_read(void *h, const uint8_t *read, uint64_t len) {
     apxMap(*c->idx, r, c->anchors, c->hit, c->f1, c->f2, c->gaps, c->cs, c->ce, ci, 1, c->pg, c->pm);
     return length(c->cs);
 }
+uint64_t ref_get_gaps(void *h, uint64_t *out_pairs, uint64_t cap_pairs) {   // apx_gaps of the last ref_map_read
+    RefCtx *c = (RefCtx *)h;
+    for (uint64_t i = 0; i < length(c->gaps) && i < cap_pairs; i++) { out_pairs[2 * i] = c->gaps[i].first; out_pairs[2 * i + 1] = c->gaps[i].second; }
+    return length(c->gaps);
+}
 void ref_get_cords(void *h, uint64_t *cords_str, uint64_t *cords_end) {
     RefCtx *c = (RefCtx *)h;
     uint64_t n = length(c->cs);

@@ -18,7 +18,7 @@ SEQAN = "/root/reference/seqan/include"
 def test_header_is_plain_c_and_layouts_match_ctypes(tmp_path):
     from linear_amd import api
     pairs = [("lnr_opts", api.LnrOpts), ("lnr_index_info", api.LnrIndexInfo), ("lnr_cords", api.LnrCords), ("lnr_cords_dev", api.LnrCordsDev),
-             ("lnr_anchors", api.LnrAnchors), ("lnr_stats", api.LnrStats)]
+             ("lnr_anchors", api.LnrAnchors), ("lnr_stats", api.LnrStats), ("lnr_gaps", api.LnrGaps)]
     lines = ['#include <stddef.h>', '#include "linear_amd.h"']
     for cname, st in pairs:
         lines.append(f'_Static_assert(sizeof({cname}) == {C.sizeof(st)}, "sizeof {cname}");')

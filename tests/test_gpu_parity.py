@@ -333,3 +333,33 @@ def test_gpu_linear_filter_cli_end_to_end(case_inputs, tmp_path):
         assert [l for l in sam if l.startswith(b"@PG")][0].startswith(b"@PG\tID:M1-3\tPN:Linear\tCL:")
         apf = [l for l in open(tmp_path / "out.apf", "rb").read().split(b"\n") if l]
         assert apf == [l for l in g["apf"].tobytes().split(b"\n") if l]
+
+
+def test_gpu_apx_gaps_export(oracle_lib):
+    """apxMap's second output (the uncovered stretches the reference's gap re-mapper starts from) through lnr_last_gaps: the
+    oracle's apx_gaps, read by read -- junk and chimeric reads have gaps, clean reads none."""
+    from linear_amd import Filter, synth
+    refs = [synth.repeat_ref(500_000, 91), synth.random_ref(300_000, 92)]
+    rng = np.random.default_rng(93)
+    lst = []
+    for k in range(24):
+        a = synth.mutate(refs[0][30_000 + 7000 * k: 34_000 + 7000 * k], 0.08, rng)
+        junk = rng.integers(0, 4, size=1500 + 200 * (k % 5), dtype=np.uint8)
+        b = synth.mutate(refs[1][50_000 + 3000 * k: 53_500 + 3000 * k], 0.08, rng)
+        lst.append(np.concatenate([a, junk, b]) if k % 2 else a)
+    lst.append(rng.integers(0, 4, size=6000, dtype=np.uint8))
+    reads, off = synth.pack_reads(lst)
+    f = Filter(device=0)
+    f.build_index(refs, 2)
+    f.filter_batch(reads, off)
+    goff, gaps = f.last_gaps()
+    o = oracle_lib.Checker("oracle", refs, 2)
+    tot = 0
+    for i in range(off.size - 1):
+        o.map_read(reads[int(off[i]):int(off[i + 1])])
+        want = o.gaps()
+        got = gaps[int(goff[i]):int(goff[i + 1])]
+        assert np.array_equal(got, want), f"read {i}"
+        tot += want.shape[0]
+    assert tot >= 10
+    f.close()

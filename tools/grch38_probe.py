@@ -18,19 +18,26 @@ ap.add_argument("--read-len", type=int, default=10_000)
 ap.add_argument("--batches", type=int, default=3)
 ap.add_argument("--T", type=int, default=16)
 ap.add_argument("--seed-only", action="store_true")
+ap.add_argument("--chr22", action="store_true", help="the round-1 workload (configs[1]) instead of the GRCh38 stand-in")
 ap.add_argument("--check", type=int, default=0, help="compare the first N reads of batch 0 with the oracle (builds the oracle's own index)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-t0 = time.time(); gen, offs = grch38_like_cuda(dev, scale=a.scale); torch.cuda.synchronize()
+if a.chr22:
+    from linear_amd import synth
+    ref = synth.chr22_like()
+    gen = torch.from_numpy(ref).to(dev); offs = [0, ref.size]
+t0 = time.time()
+if not a.chr22:
+    gen, offs = grch38_like_cuda(dev, scale=a.scale); torch.cuda.synchronize()
 print(f"genome {gen.numel() / 1e6:.0f} Mb in {time.time() - t0:.1f}s, N fraction {(gen == 4).float().mean().item():.3f}", flush=True)
 f = Filter(device=0)
 t0 = time.time()
-info = f.build_index_ptrs([gen.data_ptr() + o for o in offs[:-1]], [offs[i + 1] - offs[i] for i in range(24)], a.T)
+info = f.build_index_ptrs([gen.data_ptr() + o for o in offs[:-1]], [offs[i + 1] - offs[i] for i in range(len(offs) - 1)], a.T)
 print(f"index {time.time() - t0:.2f}s wall, {info.build_ms:.0f} ms device: hs {info.hs_len} samples {info.n_samples} f2 {info.f2_len}", flush=True)
 print("mem GB", torch.cuda.mem_get_info()[0] / 1e9, "free of", torch.cuda.mem_get_info()[1] / 1e9, flush=True)
 batches = []
 for b in range(a.batches):
-    t0 = time.time(); r, o = sample_reads_multi_cuda(gen, offs, a.reads, a.read_len, 0.10, 777 + b); torch.cuda.synchronize()
+    t0 = time.time(); r, o = sample_reads_multi_cuda(gen, [10_510_000, offs[1]] if a.chr22 else offs, a.reads, a.read_len, 0.10, 777 + b); torch.cuda.synchronize()
     batches.append((r, o)); print(f"batch {b} generated in {time.time() - t0:.1f}s", flush=True)
 for rep in range(2):
     for b, (r, o) in enumerate(batches):
