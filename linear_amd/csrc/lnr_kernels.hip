@@ -1065,10 +1065,10 @@ __device__ void radix_sort_block(u64 *a, u64 *alt, u32 n, u32 (*rh)[256], u32 *t
             for (int u = 0; u < 4; u++) if (i0 + 64 * u + lane < hi) atomicAdd(&hist[(k[u] >> shift) & 255], 1u);
         }
         __syncthreads();
-        if (tid < 256) {
+        for (u32 b = tid; b < 256; b += NW * 64) {            // (a two-wave workgroup has 128 threads for the 256 bins)
             u32 t = 0;
-            for (int w = 0; w < NW; w++) t += rh[w][tid];
-            tot[tid] = t;
+            for (int w = 0; w < NW; w++) t += rh[w][b];
+            tot[b] = t;
             if (t == n) *flag = (u32)pass + 1;                // every key has this digit: the pass is the identity
         }
         __syncthreads();
@@ -1080,9 +1080,9 @@ __device__ void radix_sort_block(u64 *a, u64 *alt, u32 n, u32 (*rh)[256], u32 *t
             tot[4 * lane] = ex; tot[4 * lane + 1] = ex + c0; tot[4 * lane + 2] = ex + c0 + c1; tot[4 * lane + 3] = ex + c0 + c1 + c2;
         }
         __syncthreads();
-        if (tid < 256) {
-            u32 run = tot[tid];
-            for (int w = 0; w < NW; w++) { u32 c = rh[w][tid]; rh[w][tid] = run; run += c; }
+        for (u32 b = tid; b < 256; b += NW * 64) {
+            u32 run = tot[b];
+            for (int w = 0; w < NW; w++) { u32 c = rh[w][b]; rh[w][b] = run; run += c; }
         }
         __syncthreads();
         {   // place this wave's slice (radix_sort_wave's loop with the wave's own cursors)

@@ -117,6 +117,22 @@ def test_gpu_other_size_class_paths(case_inputs, monkeypatch, var, val):
     f.close()
 
 
+def test_gpu_two_wave_middle_class(case_inputs, monkeypatch):
+    """Force every job through the two-wave form of the middle class (the round-0 default at human scale): same cords.
+    (Found by bench.py's parity check against the reference: the workgroup radix sort assumed at least 256 threads.)"""
+    from linear_amd import Filter
+    monkeypatch.setenv("LNR_MID_CAP", "64")
+    monkeypatch.setenv("LNR_MID_WAVES", "2")
+    f = Filter(device=0)
+    for name, T in (("rep", 1), ("edge", 3), ("ont", 4)):
+        refs, reads, off = case_inputs(name)
+        g = np.load(os.path.join(GOLD, f"{name}_T{T}.npz"))
+        f.build_index(refs, T)
+        coff, cs, ce = f.filter_batch(reads, off)
+        assert np.array_equal(coff, g["cord_off"]) and np.array_equal(cs, g["cords_str"]) and np.array_equal(ce, g["cords_end"])
+    f.close()
+
+
 def test_gpu_heavy_path(case_inputs, monkeypatch):
     """Force every job through the 16-wave kernel: same cords."""
     from linear_amd import Filter

@@ -19,7 +19,7 @@ from oracle import pyorc  # noqa: E402
 
 OPTION_SETS = [{}, {}, {"LNR_MID_CAP": "64"}, {"LNR_MID_CAP": "64"}, {"LNR_HEAVY_CAP": "64"}, {"LNR_HEAVY_CAP": "64"}, {"LNR_DP_SPLIT_CAP": "64"}, {"LNR_SPLIT_CAP": "200"},
                {"LNR_SPLIT_CAP": "200", "LNR_LANE_ORDER": "heavy"}, {"LNR_MID_CAP": "300", "LNR_HEAVY_CAP": "900"}, {"LNR_JOB_LDS_KB": "2"},
-               {"LNR_SEED_BM": "0"}, {"LNR_SEED_BM": "0", "LNR_MID_CAP": "64"}, {"LNR_POST_SPLIT": "1"}, {"LNR_POST_SPLIT": "1", "LNR_SEED_BM": "0"}, {"LNR_JOB_LDS_KB": "1"}]
+               {"LNR_SEED_BM": "0"}, {"LNR_SEED_BM": "0", "LNR_MID_CAP": "64"}, {"LNR_POST_SPLIT": "1"}, {"LNR_POST_SPLIT": "1", "LNR_SEED_BM": "0"}, {"LNR_JOB_LDS_KB": "1"}, {"LNR_MID_CAP": "64", "LNR_MID_WAVES": "2"}, {"LNR_MID_CAP": "300", "LNR_MID_WAVES": "2", "LNR_SEED_BM": "0"}]
 ALL_KEYS = sorted({k for o in OPTION_SETS for k in o})
 
 
