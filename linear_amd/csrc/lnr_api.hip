@@ -148,7 +148,7 @@ struct lnr_ctx {
     // lane's seed / tail launches), s_bulk the single-wave kernel of the same launch.
     hipStream_t s_multi[2] = {nullptr, nullptr}, s_bulk[2] = {nullptr, nullptr}, s_tail = nullptr;   // s_tail: early tail B of the reads that skip the re-map round
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_start = nullptr, ev_lane[2] = {nullptr, nullptr}, ev_prep = nullptr, ev_f1 = nullptr;
-    DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines (k_ix_lines)
+    DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl, ov;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines, ov = their aligned overflow lines (k_ix_lines)
     // ---- batch inputs / per-read arrays
     // host-buffer entry points: two input slots, so that the upload of the next batch (copy stream) runs under the kernels of
     // the current one (lnr_filter_submit / lnr_filter_wait)
@@ -237,6 +237,31 @@ lnr_status dev_scan_i32(lnr_ctx *ctx, const i32 *in, i32 *out, u64 n, DevBuf &tm
     KCHECK();
     hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(SCAN_TPB), 0, ctx->stream, out, n, tmp.as<i32>());
     KCHECK();
+    return LNR_OK;
+}
+
+// The seed kernel's view of the DIndex, derived from dir / hs on this GPU: bucket bitmap, bucket lines and their overflow lines.
+lnr_status build_seed_view(lnr_ctx *ctx) {
+    u64 nb = ctx->info.dir_len - 1, nwords = (((nb + (1u << BM_GROUP_LOG2) - 1) >> BM_GROUP_LOG2) + 31) / 32;
+    ENSURE(ctx->bm, nwords * 4 + 16);
+    hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
+    KCHECK();
+    DevBuf ovoff, tmp;                                        // overflow lines per bucket -> first overflow line of every bucket
+    ENSURE(ovoff, (nb + 1) * 4 + 16);
+    hipLaunchKernelGGL(k_ix_ovcount, dim3((u32)((nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ovoff.as<i32>());
+    KCHECK();
+    lnr_status st = dev_scan_i32(ctx, ovoff.as<i32>(), ovoff.as<i32>(), nb + 1, tmp);
+    if (st != LNR_OK) return st;
+    i32 nov = 0;
+    HIPCK(hipMemcpyAsync(&nov, ovoff.as<i32>() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    if (nov < 0) { ctx->err = "overflow lines of the bucket view exceed 2^31"; return LNR_ERR_LIMIT; }
+    ENSURE(ctx->ov, ((u64)nov + 1) * 128);
+    ENSURE(ctx->bl, nb * 128);
+    hipLaunchKernelGGL(k_ix_lines, dim3((u32)((nb * 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), ctx->hs.as<u64>(), ovoff.as<i32>(), nb, ctx->bl.as<ulonglong2>(),
+                       ctx->ov.as<u64>());
+    KCHECK();
+    HIPCK(hipStreamSynchronize(ctx->stream));                 // ovoff / tmp go out of scope
     return LNR_OK;
 }
 
@@ -374,7 +399,7 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
         S.t_seed.start(st);
         // the bucket bitmap answers lookups of empty buckets without touching the bucket lines; once most buckets hold entries
         // (human scale: 328 M entries in 67 M buckets) it is one more dependent load in front of every lookup and is skipped
-        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->bl.as<ulonglong2>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->hs.as<u64>(), nj, O, S.est_x16);
+        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->bl.as<ulonglong2>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->ov.as<u64>(), nj, O, S.est_x16);
         KCHECK();
         S.t_seed.stop(st);
         if (f1_reads && attempt == 0) { lnr_status fs = launch_f1(ctx, f1_reads); if (fs != LNR_OK) return fs; }   // (beside the seed kernel instead: measured no faster)
@@ -1261,19 +1286,7 @@ lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64
             IXHIP(hipGetLastError());
         }
     }
-    // bucket-non-empty bitmap for the seed kernel
-    {
-        u64 nb = dir_len - 1, nwords = (((nb + (1u << BM_GROUP_LOG2) - 1) >> BM_GROUP_LOG2) + 31) / 32;
-        ENSURE(ctx->bm, nwords * 4 + 16);
-        hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
-        IXHIP(hipGetLastError());
-    }
-    {   // bucket lines for the seed kernel
-        u64 nb = dir_len - 1;
-        ENSURE(ctx->bl, nb * 128);
-        hipLaunchKernelGGL(k_ix_lines, dim3((u32)((nb * 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), ctx->hs.as<u64>(), nb, ctx->bl.as<ulonglong2>());
-        IXHIP(hipGetLastError());
-    }
+    IXCK(build_seed_view(ctx));   // bucket bitmap, bucket lines, overflow lines for the seed kernel
     // genome window features
     ENSURE(ctx->f2, std::max<u64>(ctx->info.f2_len * sizeof(F96), 16));
     if (ctx->info.f2_len) {
@@ -1348,13 +1361,7 @@ lnr_status lnr_index_adopt(lnr_ctx *ctx) {
     if (!ctx) return LNR_ERR_ARG;
     if (!ctx->g.p || !ctx->dir.p || !ctx->hs.p || !ctx->f2.p) return LNR_ERR_NO_INDEX;
     DevGuard dg_(ctx->device);
-    u64 nb = ctx->info.dir_len - 1, nwords = (((nb + (1u << BM_GROUP_LOG2) - 1) >> BM_GROUP_LOG2) + 31) / 32;   // derived structure: rebuilt from the received dir
-    ENSURE(ctx->bm, nwords * 4 + 16);
-    hipLaunchKernelGGL(k_ix_bitmap, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), nb, ctx->bm.as<u32>());
-    KCHECK();
-    ENSURE(ctx->bl, nb * 128);
-    hipLaunchKernelGGL(k_ix_lines, dim3((u32)((nb * 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), ctx->hs.as<u64>(), nb, ctx->bl.as<ulonglong2>());
-    KCHECK();
+    { lnr_status st_ = build_seed_view(ctx); if (st_ != LNR_OK) return st_; }   // derived structures: rebuilt from the received dir / hs
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->has_index = true;
     return LNR_OK;

@@ -565,27 +565,40 @@ __global__ void __launch_bounds__(256) k_ix_bitmap(const i32 *dir, u64 nbuckets,
     bm[w] = bits;
 }
 
-// Bucket lines: the seed kernel's view of the DIndex.  Bucket X owns the 128-byte line X of `bl`: word 0 = bucket start in hs
-// (low 32 bits) | bucket length (bits 32..47), words 1..15 = its first 15 entries (zero behind the end).  One HBM line then
-// answers a lookup of a bucket of up to 15 entries completely -- dir line, hs line and the line fragments at both ends of the
-// bucket's run in hs were three or more -- and longer buckets continue in hs from entry 15.  A derived structure like the
-// bitmap: built on every GPU from dir / hs (8.6 GB of the 288), never broadcast.  dir and hs stay the parity surface.
+// Bucket lines: the seed kernel's view of the DIndex.  Bucket X owns the 128-byte line X of `bl`: word 0 = first overflow line of
+// the bucket in `ov` (low 32 bits) | bucket length (bits 32..47), words 1..15 = its first 15 entries (zero behind the end).  One
+// HBM line then answers a lookup of a bucket of up to 15 entries completely -- dir line, hs line and the line fragments at both
+// ends of the bucket's run in hs were three or more.  Longer buckets continue in `ov`: entries 15.. of every such bucket copied
+// out of hs into whole 128-byte lines (zero padded), so that a run of m entries costs ceil(m / 16) lines and not the one more
+// that a run at an arbitrary offset of hs touches at its ends.  Derived structures like the bitmap: built on every GPU from
+// dir / hs (8.6 GB + ~2.6 GB of the 288 at GRCh38 scale), never broadcast.  dir and hs stay the parity surface.
 #define BL_INLINE 15
-__global__ void __launch_bounds__(256) k_ix_lines(const i32 *dir, const u64 *hs, u64 nbuckets, ulonglong2 *bl) {
+__global__ void __launch_bounds__(256) k_ix_ovcount(const i32 *dir, u64 nbuckets, i32 *novl) {
+    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nbuckets) return;
+    u32 dl = b < nbuckets ? (u32)(dir[b + 1] - dir[b]) : 0u;
+    novl[b] = dl > BL_INLINE ? (i32)((dl - BL_INLINE + 15) >> 4) : 0;
+}
+__global__ void __launch_bounds__(256) k_ix_lines(const i32 *dir, const u64 *hs, const i32 *ovoff, u64 nbuckets, ulonglong2 *bl, u64 *ov) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per 16-byte part of a line
     u64 b = t >> 3;
     if (b >= nbuckets) return;
     u32 part = (u32)t & 7;
     i32 ds = dir[b];
     u32 dl = (u32)(dir[b + 1] - ds);
+    u32 o0 = (u32)ovoff[b];
     u64 w[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         u32 slot = 2 * part + (u32)k;
-        if (slot == 0) w[k] = (u64)(u32)ds | ((u64)dl << 32);
+        if (slot == 0) w[k] = (u64)o0 | ((u64)dl << 32);
         else w[k] = slot - 1 < dl ? hs[(i64)ds + (i64)(slot - 1)] : 0ULL;
     }
     bl[t] = make_ulonglong2(w[0], w[1]);
+    if (dl > BL_INLINE) {                                    // the eight threads of the bucket copy its overflow run
+        u32 m = dl - BL_INLINE, mpad = ((m + 15) >> 4) << 4;
+        for (u32 i = part; i < mpad; i += 8) ov[(u64)o0 * 16 + i] = i < m ? hs[(i64)ds + BL_INLINE + (i64)i] : 0ULL;
+    }
 }
 
 // Seed lookup of one job per wave (getDIndexMatchAll, pmpfinder.cpp:1856-1913), one kernel, one pass over the read in chunks
@@ -593,11 +606,11 @@ __global__ void __launch_bounds__(256) k_ix_lines(const i32 *dir, const u64 *hs,
 //   1. lane = sample: minimizer (2-bit packed path; byte path where an N or hashInit state intervenes), the "minimizer
 //      changed" lookup rule (xpre == previous sample's X), optional bitmap test, then the header word of the bucket's line:
 //      start and length of the bucket (the fetch also brings the line on chip for step 2);
-//   2. lane = 128-byte line.  The lines a sample needs -- its bucket line, then the 128-byte-aligned lines of hs that hold its
-//      entries from the 16th on -- are numbered through the chunk in the reference's order; a lane takes one line (owner from
-//      one LDS scatter of the samples' first line numbers + a ballot + a count-leading-zeros), loads its 16 words with eight
-//      16-byte loads, runs the Y filter (pmpfinder.cpp:1890-1899) on the words in registers and keeps a 16-bit mask of the
-//      entries that pass and belong to the bucket;
+//   2. lane = 128-byte line.  The lines a sample needs -- its bucket line, then the lines of `ov` that hold its entries from
+//      the 16th on -- are numbered through the chunk in the reference's order; 64 lines per round go from HBM to LDS by
+//      LDS-DMA (eight lanes per line), a lane takes one line (owner from one LDS scatter of the samples' first line numbers
+//      + a ballot + a count-leading-zeros), runs the Y filter (pmpfinder.cpp:1890-1899) on its 16 words and keeps a 16-bit
+//      mask of the entries that pass and belong to the bucket;
 //   3. the survivors go, in lane order = the reference's order, into a ring in LDS; whenever 64 have gathered the wave turns
 //      them into anchors (val2Anchor, index_util.cpp:1509-1520) and stores 512 contiguous bytes.
 // The job's anchor segment is bump-allocated from an estimate (est_per_sample x samples, learned by the host from earlier
@@ -607,14 +620,28 @@ __global__ void __launch_bounds__(256) k_ix_lines(const i32 *dir, const u64 *hs,
 //   round 1 kernel (lane = entry, one load in flight, per-lane binary search for the owner)    8.55 ms, 32 GB of HBM traffic
 //   four loads in flight, owner by scatter + ballot, anchors from full groups of survivors     5.75 ms, 32 GB (5.6 TB/s: HBM bound)
 //   bucket lines, lane = entry                                                                  7.1 ms, 24 GB (issue bound: 2.5 G VALU)
-//   bucket lines, lane = line (this form)                                                       see DESIGN.md
+//   bucket lines, lane = line, LDS-DMA, headers one chunk ahead                                  5.35 ms, 31.5 GB
+//   + overflow runs in whole lines (`ov`), Y filter of 6 instead of 10 instructions per word (this form)   4.95 ms
+//   the same with the bucket lines prefetched into registers instead (every line fetched once: ~22 GB)     5.50 ms -- in-kernel
+//     stamps: a wave waits 0.57 us per round for its lines and spends 4.5 us issuing: the kernel is bound by its instruction
+//     count at 3 waves / SIMD (LDS: 13 KB per wave), not by traffic; the extra instructions of the register form cost more
+//     than the saved traffic gave
 #define SEED_RING 256
 LNR_HD inline u32 y_match32(u32 hs_y, u32 Y) {   // y_match on the 20-bit y field (pmpfinder.cpp:1893-1894, ctz(0) pinned to "match")
     u32 v = hs_y ^ Y;
     u32 low = v & (0u - v);                        // lowest set bit (0 if none)
     return (v < 4u * low || v == 0) ? 1u : 0u;     // (v >> ctz(v)) < 4
 }
-__global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, const ulonglong2 *bl, const u32 *bm /* null: table too dense to pay */, const u64 *hs, u32 njobs,
+// acc << 1 | "word does NOT pass the Y filter".  With v = y field ^ Y and low = lowest set bit of v: the word passes
+// (y_match32) iff v < 4 low or v == 0, i.e. iff 4 low - v >= 0 (4 low == v is impossible for v != 0: low would not be v's lowest
+// bit) -- the sign bit of 4 low - v is the answer and v_alignbit shifts it in.
+__device__ inline u32 y_nomatch_push(u32 acc, u32 word, u32 Y) {
+    u32 v = (word & 0xfffffu) ^ Y;
+    u32 nv = 0u - v;
+    u32 d = ((v & nv) << 2) + nv;
+    return __builtin_amdgcn_alignbit(acc, d, 31);
+}
+__global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, const ulonglong2 *bl, const u32 *bm /* null: table too dense to pay */, const u64 *ov, u32 njobs,
                                                    SeedOutArrays O, u32 est_per_sample_x16) {
     __shared__ uint4 s_rec[64];                // per sample: X, bucket start, bucket length, Y | strand << 8
     __shared__ u32 s_mk[64];                   // sample (lane + 1) whose first line has this number within the round
@@ -706,7 +733,7 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
         else if (base + 64 < ns) sample_chunk(base + 64, o_n, hdr_n);
         u32 ds = (u32)hdr, dl = (u32)(hdr >> 32) & 0xffffu;
         // lines of this sample: its bucket line + the aligned 16-entry lines of hs that hold entries 15 .. dl - 1
-        u32 nl = dl ? 1u + (dl > BL_INLINE ? ((ds + dl - 1) >> 4) - ((ds + BL_INLINE) >> 4) + 1u : 0u) : 0u;
+        u32 nl = dl ? 1u + ((dl + 15u - BL_INLINE) >> 4) : 0u;
         u32 lincl = wave_incl_scan(nl);
         u32 totalL = (u32)__builtin_amdgcn_readlane((int)lincl, 63);
         if (totalL == 0) continue;
@@ -739,11 +766,9 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
                 u32 n0 = rec.z < BL_INLINE ? rec.z : BL_INLINE;
                 vm = ((1u << n0) - 1u) << 1;                                // bucket line: words 1 .. n0
                 if (li) {
-                    u32 lb = ((rec.y + BL_INLINE) >> 4) + li - 1;           // line number in hs (16 entries per line)
-                    src = (const ulonglong2 *)(hs + (u64)lb * 16);
-                    i32 lo = (i32)(rec.y + BL_INLINE) - (i32)(lb * 16), hi = (i32)(rec.y + rec.z) - (i32)(lb * 16);
-                    lo = lo < 0 ? 0 : lo; hi = hi > 16 ? 16 : hi;
-                    vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                    src = (const ulonglong2 *)(ov + ((u64)rec.y + li - 1) * 16);
+                    u32 hi = rec.z - BL_INLINE - 16u * (li - 1);            // entries of the run from this line on
+                    vm = hi >= 16 ? 0xffffu : (1u << hi) - 1u;
                 }
                 if (!act) { vm = 0; src = bl; }
             }
@@ -760,14 +785,16 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             WLDS();
             u32 Y = rec.w & 0xffu;
-            u32 mm = 0;
+            u32 nm16 = 0;
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
-                u32 pt = ((u32)t + (u32)lane) & 7;                          // parts in rotated order: 2-way instead of 8-way bank conflicts
+            for (int t = 7; t >= 0; t--) {
+                u32 pt = ((u32)t + (u32)lane) & 7;
                 ulonglong2 w = s_line[lane][pt];
-                mm |= y_match32((u32)w.x & 0xfffffu, Y) << (2 * pt);
-                mm |= y_match32((u32)w.y & 0xfffffu, Y) << (2 * pt + 1);
+                nm16 = y_nomatch_push(nm16, (u32)w.y, Y);
+                nm16 = y_nomatch_push(nm16, (u32)w.x, Y);
             }
+            u32 mr = ~nm16 & 0xffffu, rs16 = (2u * (u32)lane) & 15u;
+            u32 mm = ((mr << rs16) | (mr >> (16u - rs16))) & 0xffffu;
             mm &= vm;
             u32 cnt = (u32)__popc(mm);
             u32 incl = wave_incl_scan(cnt);
