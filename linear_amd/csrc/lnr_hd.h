@@ -246,11 +246,18 @@ LNR_HD inline bool seed_sample_packed(const u64 *pk, const u32 *nm, u64 k, u64 k
         u64 r = lnr_brev64(win) >> 22;                                    // pair order reversed, bits inside pairs swapped
         v2 = ((r & 0x2AAAAAAAAAAULL) >> 1) | ((r & 0x15555555555ULL) << 1);
     } else v2 = (~win) & M42;
-    u64 X = M42, t = 0;
-    for (unsigned kk = 22; kk <= 38; kk += 2) {
-        u64 v1 = v2 << kk >> 38;
-        if (X > v1) { X = v1; t = kk; }
+    // smallest of the nine 26-bit windows v2 << kk >> 38, kk = 22, 24 .. 38 (= bits 38 - kk .. 63 - kk of v2), the first one on a
+    // tie: one 32-bit minimum over window << 4 | index (the 64-bit compare-and-select form was a quarter of this function)
+    u32 v2lo = (u32)v2, v2hi = (u32)(v2 >> 32);
+    u32 best = 0xffffffffu;
+#pragma unroll
+    for (u32 i = 0; i < 9; i++) {
+        u32 p = 16 - 2 * i;                                               // window i = kk 22 + 2 i starts at bit p
+        u32 f = p ? ((v2lo >> p) | (v2hi << (32 - p))) : v2lo;
+        u32 key = ((f & 0x3ffffffu) << 4) | i;
+        best = key < best ? key : best;
     }
+    u64 X = best >> 4, t = 22 + 2 * (best & 15u);
     u32 Y;
     if (x > 0) {
         u32 q = (u32)(t >> 1) + 2 + 4;                                   // span index of the first flank base

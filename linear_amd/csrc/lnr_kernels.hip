@@ -96,6 +96,11 @@ __global__ void __launch_bounds__(256) k_words_out(const u32 *src, u32 *dst, u64
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+#if defined(K_JOB_WAVES) && K_JOB_WAVES > 4
+#define JOB_INLINE __forceinline__
+#else
+#define JOB_INLINE
+#endif
 // ============================================================ generic scans ====
 #define SCAN_TPB 256
 #define SCAN_IPT 16
@@ -945,7 +950,7 @@ __device__ u32 binning_exact_wave(u64 *a, u32 n, u32 *binw, u32 hist_bytes, u32 
 // (Measured on the GRCh38 stand-in: no change of the kernel's time against the plain two-pass histogram -- the stage costs 1.3 ms of
 // 31 when the kernel has the chip to itself; what made it look like 7 ms was the 4-wave kernel holding 14 of 16 wave slots per CU.)
 #define BIN_HASH 4096u
-__device__ u32 binning_wave(u64 *a, u32 n, u64 *tmp, u32 *binw, u32 hist_bytes, u32 nbins) {
+__device__ JOB_INLINE u32 binning_wave(u64 *a, u32 n, u64 *tmp, u32 *binw, u32 hist_bytes, u32 nbins) {
     int lane = lane_id();
     if (n <= 256 || hist_bytes < BIN_HASH || !tmp) {           // short lists: the exact histogram directly (in place)
         u32 k = binning_exact_wave(a, n, binw, hist_bytes, nbins);
@@ -1160,7 +1165,7 @@ struct XDesc { LNR_HD bool operator()(const u64 &p, const u64 &q) const { return
 __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
     return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)v, l);
 }
-__device__ void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *tasks, LeaderScratch *ls /* LDS */, u64 *stage /* free LDS or null */, u32 stage_cap) {
+__device__ JOB_INLINE void introsort_xdesc_wave(u64 *a, u32 n, u32 *Lbuf, u32 *Rbuf, u64 *tasks, LeaderScratch *ls /* LDS */, u64 *stage /* free LDS or null */, u32 stage_cap) {
     int lane = lane_id();
     XDesc comp;
     if (n <= SORT_SMALL) {
@@ -1760,7 +1765,7 @@ __device__ void emit_chain_wave(AnchorSink &sink, const Rec &r, const i32 *chain
     sink.nchains++;
     WSYNC();
 }
-__device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int *s_flag, LeaderScratch *ls) {
+__device__ JOB_INLINE void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int *s_flag, LeaderScratch *ls) {
     int lane = lane_id();
     for (u32 i = lane; i < n; i += 64) cnt[i] = 0;
     WSYNC();
@@ -1855,7 +1860,7 @@ __device__ void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink, i32 *chain
 // end position afterwards, so the order in which lanes append them does not matter.  The j-loop's early stop
 // ("xy_strs[j] < length(hits)" in the loop condition) is the first block whose cursor reached the end of hits at the
 // start of the pass.  `sep` is the leader's Vec (its .n is broadcast through s_n); every lane returns the new count.
-__device__ u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &sep, u32 nb, u64 *cuts, u64 *xy_strs, Vec<UP> &tmp, LeaderScratch &ls) {
+__device__ JOB_INLINE u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &sep, u32 nb, u64 *cuts, u64 *xy_strs, Vec<UP> &tmp, LeaderScratch &ls) {
     int lane = lane_id();
     const u64 mask = 1ULL << 62;
     UP *sp = sep.p;
@@ -2383,7 +2388,13 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
 #endif
 }
 
-__global__ void __launch_bounds__(64, 4) k_job(JobArgs A) {
+// K_JOB_WAVES: waves per SIMD the single-wave kernel is compiled for (4: 128 VGPRs; 6: 80 VGPRs with spills -- the compiler's budget
+// for 5 is 104 registers, which the hardware's granule of 8 turns into 4 waves again).  The phase functions above are inlined by force
+// in the register-capped build: a call keeps the callee's own, uncapped register count (traceback 104, introsort 104).
+#ifndef K_JOB_WAVES
+#define K_JOB_WAVES 4
+#endif
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(K_JOB_WAVES, K_JOB_WAVES))) k_job(JobArgs A) {
     extern __shared__ u32 dyn_lds[];
     if (A.grp_lo + blockIdx.x >= A.grp_hi) return;
     job_group_run<1>(A, A.grp_order[A.grp_lo + blockIdx.x], dyn_lds);

@@ -62,7 +62,11 @@ struct RefCtx {
 
 extern "C" {
 
-void *ref_create(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T) {
+static void *ref_create_i(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T, int index_type);
+void *ref_create(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T) { return ref_create_i(seqs, lens, nseq, T, 1); }
+// index_type as on the command line: 1 = DIndex (default), 2 = HIndex (mapper.cpp:200, index_util.cpp:2436-2448)
+void *ref_create2(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T, int index_type) { return ref_create_i(seqs, lens, nseq, T, index_type); }
+static void *ref_create_i(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T, int index_type) {
     RefCtx *c = new RefCtx();
     c->T = T ? T : 1;
     omp_set_num_threads(c->T);
@@ -70,7 +74,7 @@ void *ref_create(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq
     for (uint32_t i = 0; i < nseq; i++) assign_padded(c->g[i], seqs[i], lens[i]);
     createFeatures(c->g, c->f2, 2, c->T);                     // linear.cpp:76 (process3)
     c->idx = new IndexDynamic(c->g);
-    c->idx->setIndexType(1);                                  // -i 1 -> DIndex
+    c->idx->setIndexType(index_type);                         // -i 1 -> DIndex, -i 2 -> HIndex
     createIndexDynamic(c->g, *c->idx, 0, length(c->g), c->T, false);
     c->pm.pm_cah.thd_stop_chain_len_ratio = 0;                // default preset -p 1 (mapper.cpp:181-185)
     resize(c->f1, 2);
