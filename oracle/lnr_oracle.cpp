@@ -270,6 +270,192 @@ static void createDIndex(const std::vector<const uint8_t *> &seqs, const std::ve
     index.fill_mismatch = mism;
 }
 
+
+// --------------------------------------------------------------- HIndex ----
+// `-i 2`.  hs / ysa word formats (index_util.cpp:136-157, 241-299): head = ptr[23] << 40 | X[40], bit 63 clear;
+// body = 1 << 63 | Y << 41 | reverse-strand flag << 40 | sequence id << 30 | position.
+static const u64 HS_TYPEFLAG = 1ULL << 63, HS_TYPEMASK = HS_TYPEFLAG - 1, HS_MASK40 = (1ULL << 40) - 1, HS_PTRMASK = (1ULL << 23) - 1;
+static const u64 HS_BODYYMASK = (1ULL << 20) - 1, HS_BODYCODEFLAG = 1ULL << 40;
+static inline u64 hsHead(u64 ptr, u64 x) { return ((ptr << 40) + x) & HS_TYPEMASK; }                      // Hs::setHsHead :245
+static inline u64 hsHeadPtr(u64 v) { return (v >> 40) & HS_PTRMASK; }                                      // Hs::getHeadPtr :261
+static inline u64 hsHeadX(u64 v) { return v & HS_MASK40; }                                                  // Hs::getHeadX :257
+static inline bool hsIsHead(u64 v) { return ((v & HS_TYPEFLAG) ^ HS_TYPEFLAG) != 0; }                      // Hs::isHead :241
+static inline u64 hsBody(u64 y, u64 id, u64 pos) { return ((y << 41) | HS_TYPEFLAG) + (id << 30) + pos; }  // Hs::setHsBody :265
+static inline u64 hsBodyY(u64 v) { return (v >> 41) & HS_BODYYMASK; }                                      // Hs::getHsBodyY :275
+static inline u64 hsBodyS(u64 v) { return v & HS_MASK40; }                                                 // Hs::getHsBodyS :283
+
+static inline void hashNext(Shape &me, const uint8_t *it) {                          // shape_extend.cpp:132-168 (index side of the HIndex)
+    u64 v1;
+    unsigned t = 0, span = me.span << 1, weight = me.weight << 1;
+    u64 v2 = it[me.span - 1];
+    u64 mask = getMask(span - 2);
+    me.hValue = ((me.hValue & mask) << 2) + v2;
+    me.crhValue = ((me.crhValue >> 2) & mask) + ((3ULL - v2) << (span - 2));
+    me.XValue = getMask(span);
+    me.x += (int)((v2 - (u64)(i64)me.leftChar) << 1);                                 // (v2 - leftChar) << 1 in uint64_t, added to the int
+    me.leftChar = it[0];
+    if (me.x > 0) { v2 = me.hValue; me.strand = 0; }
+    else { v2 = me.crhValue; me.strand = 1; }
+    for (unsigned k = 64 - span; k <= 64 - weight; k += 2) {
+        v1 = v2 << k >> (64 - weight);
+        if (me.XValue > v1) { me.XValue = v1; t = k; }
+    }
+    me.YValue = (v2 >> (64 - t) << (64 - t - weight)) + (v2 & ((1ULL << (64 - t - weight)) - 1)) + ((u64)t << (span - weight - 1));
+}
+
+struct XNode { u64 val1 = 0; unsigned val2 = 0; };
+struct HIndex {
+    std::vector<u64> ysa;
+    std::vector<XNode> xstr; u64 xmask = 0;
+    u64 emptyDir = 0;
+    unsigned span = 17, weight = 9;                                                  // index_util.cpp:2600,2604 (thd_shape_len 17), shape_extend.cpp:55-59
+};
+static inline u64 xhash(u64 key) {                                                   // XNodeFunc::hash index_util.cpp:971-982
+    key = (~key) + (key << 21); key = key ^ (key >> 24); key = (key + (key << 3)) + (key << 8); key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4); key = key ^ (key >> 28); key = key + (key << 31);
+    return key;
+}
+static void requestXNode(HIndex &ix, u64 xval, unsigned val2, u64 nodeType) {         // requestXNode_noCollision index_util.cpp:1006-1018 (returnType 0)
+    u64 h1 = xhash(xval) & ix.xmask, delta = 0;
+    while (ix.xstr[h1].val1) { h1 = (h1 + delta + 1) & ix.xmask; delta++; }
+    ix.xstr[h1].val1 = (xval << 2) + nodeType;
+    ix.xstr[h1].val2 = val2;
+}
+// XNodeBase::mask2 is (1 << 62) - 1 evaluated in int: undefined; the reference as compiled here (g++ -O2) holds all ones, so the
+// comparison below is on the whole word (checked on the library itself: oracle/_ref, symbol _DefaultXNodeBase).
+static u64 getXDir(const HIndex &ix, u64 xval, u64 yval) {                            // index_util.cpp:1071-1093
+    u64 val = (xval << 2) + 1, delta = 0;
+    u64 h1 = xhash(xval) & ix.xmask;
+    while (ix.xstr[h1].val1) {
+        u64 c = ix.xstr[h1].val1 ^ val;
+        if (c == 0) return ix.xstr[h1].val2;
+        if (c == 2) { val = (yval << 42) + (xval << 2) + 1; h1 = xhash((yval << 40) + xval) & ix.xmask; delta = 0; }
+        else { h1 = (h1 + delta + 1) & ix.xmask; delta++; }
+    }
+    return ix.emptyDir;
+}
+static void createHIndex(const std::vector<const uint8_t *> &seqs, const std::vector<u64> &lens, HIndex &ix, unsigned threads) {
+    const unsigned thd_step = 8; const u64 thd_blocklimit = 1024; const float alpha = 1.6f;   // index_util.cpp:2599-2603; XString::_fullSize default alpha (def_alpha)
+    Shape shape; shape.span = ix.span; shape.weight = ix.weight;
+    // ---- __createHsArray (index_util.cpp:719-818): every sequence cut into `threads` chunks, each with its own rolling state
+    u64 total = 0; for (u64 l : lens) total += l;
+    std::vector<u64> hs(total * 2 / thd_step + 1000 + 64 * (u64)threads * lens.size(), 0);
+    u64 hsRealEnd = 0;
+    for (u64 j = 0; j < seqs.size(); j++) {
+        const uint8_t *seq = seqs[j];
+        u64 npos = lens[j] - shape.span + 1;
+        u64 size2 = npos / threads;
+        std::vector<u64> cnt(threads, 0), hss(threads, 0);
+        for (unsigned thd_id = 0; thd_id < threads; thd_id++) {                       // (the reference runs these bodies concurrently; they share nothing)
+            Shape tshape = shape;
+            u64 preX = ~0ULL; i64 ptr = 0;
+            u64 chunk, start;
+            if (thd_id < npos - size2 * threads) { chunk = size2 + 1; start = (size2 + 1) * thd_id; }
+            else { chunk = size2; start = lens[j] + 1 - tshape.span - size2 * (threads - thd_id); }
+            u64 hsStart = hsRealEnd + (start << 1) / thd_step + thd_id * 10;
+            hss[thd_id] = hsStart;
+            u64 thd_count = 0;
+            hashInit(tshape, seq + start);
+            for (u64 k = start; k < start + chunk; k++) {
+                if (seq[k + tshape.span - 1] == 4) {
+                    k += hashInit(tshape, seq + k);
+                    if (k > chunk - tshape.span + 1 + start) k = chunk - (chunk + start) % thd_step + thd_step + start;
+                }
+                hashNext(tshape, seq + k);
+                if (k % thd_step == 0) {
+                    if (tshape.XValue ^ preX) {
+                        hs[hsStart + thd_count - ptr] = hsHead((u64)ptr, preX);
+                        hs[hsStart + ++thd_count] = hsBody(tshape.YValue, j, k);
+                        if (tshape.strand) hs[hsStart + thd_count] |= HS_BODYCODEFLAG;
+                        preX = tshape.XValue;
+                        ++thd_count;
+                        ptr = 2;
+                    }
+                }
+            }
+            hs[hsStart + thd_count - ptr] = hsHead((u64)ptr, tshape.XValue);         // the chunk's last block is filed under the X of its last hashed position
+            cnt[thd_id] = thd_count;
+        }
+        u64 acc = cnt[0];
+        for (unsigned t = 1; t < threads; t++) {
+            u64 it = hss[t];
+            for (u64 k = hsRealEnd + acc; k < hsRealEnd + acc + cnt[t]; k++) hs[k] = hs[it++];
+            acc += cnt[t];
+        }
+        hsRealEnd += acc;
+    }
+    hs.resize(hsRealEnd + 1);
+    hs[hsRealEnd] = hsHead(0, 0);
+    // ---- _hsSortX_1 (index_util.cpp:430-560): stable LSD radix sort of the blocks by the low 2 * weight bits of X
+    {
+        std::vector<u64> order;                                                        // block starts
+        for (u64 k = 0; k < hsRealEnd; k += hsHeadPtr(hs[k])) order.push_back(k);
+        const u64 xm = (1ULL << (2 * ix.weight)) - 1;
+        std::stable_sort(order.begin(), order.end(), [&](u64 a, u64 b) { return (hs[a] & xm) < (hs[b] & xm); });
+        std::vector<u64> out(hs.size());
+        u64 w = 0;
+        for (u64 b : order) { u64 p = hsHeadPtr(hs[b]); for (u64 q = 0; q < p; q++) out[w++] = hs[b + q]; }
+        out[w] = hs[hsRealEnd];
+        hs.swap(out);
+    }
+    // ---- _createYSA (index_util.cpp:1294-1461) on [0, getLength(hs))
+    u64 hs_end = hs.size();
+    while (hs_end > 0 && hsIsHead(hs[hs_end - 1]) && !hsHeadPtr(hs[hs_end - 1])) hs_end--;   // Hs::getLength :303-309
+    u64 ptr = hsHeadPtr(hs[0]), preX = hsHeadX(hs[0]), prek = 0, k = ptr, block_size = ptr, countMove = 0;
+    while (k < hs_end && hsHeadPtr(hs[k])) {
+        ptr = hsHeadPtr(hs[k]);
+        if (preX != hsHeadX(hs[k])) {
+            hs[k - countMove] = hs[k];
+            hs[prek] = (hs[prek] & HS_MASK40) + (block_size << 40);                   // setHsHeadPtr :279
+            prek = k - countMove; block_size = ptr; preX = hsHeadX(hs[k]);
+        } else { countMove++; block_size += ptr - 1; }
+        for (u64 q = k + 1; q < k + ptr; q++) hs[q - countMove] = hs[q];
+        k += ptr;
+    }
+    u64 hs_end_mod;
+    if (countMove > 2) {
+        hs_end_mod = k - countMove;
+        hs[prek] = (hs[prek] & HS_MASK40) + (block_size << 40);
+        if (hs.size() < k - countMove + 2) hs.resize(k - countMove + 2);
+        hs[k - countMove] = hsHead(0, 0); hs[k - countMove + 1] = hsHead(0, 0);
+        ix.emptyDir = k - countMove;
+    } else {                                                                           // "abort the last block"
+        hs_end_mod = prek;
+        if (hs.size() < prek + 2) hs.resize(prek + 2);
+        hs[prek] = hsHead(0, 0); hs[prek + 1] = hsHead(0, 0);
+        ix.emptyDir = prek;
+    }
+    hs.resize(k + 2 - countMove);
+    for (u64 q = 0; q < hs_end_mod; q++)
+        if (hsIsHead(hs[q])) { u64 p = hsHeadPtr(hs[q]); std::sort(hs.begin() + (long)q + 1, hs.begin() + (long)(q + p), std::greater<u64>()); }   // _sort_YSA_Block: bodies are distinct words
+    u64 count = 0;
+    k = 0;
+    while (hsHeadPtr(hs[k]) && k < hs_end_mod) {
+        ptr = hsHeadPtr(hs[k]);
+        if (ptr < thd_blocklimit) ++count;
+        else { for (unsigned q = (unsigned)k + 1; q < k + ptr; q++) if (hsBodyY(hs[q] ^ hs[q - 1])) ++count; ++count; }
+        k += ptr;
+    }
+    u64 len = 1; while (len < count * alpha) len <<= 1;                               // XString::_fullSize :221-232
+    ix.xstr.assign(len, XNode()); ix.xmask = len - 1;
+    for (u64 i = 0; i < hs_end_mod; i++) {
+        if (hsIsHead(hs[i]) && hsHeadPtr(hs[i])) {
+            ptr = hsHeadPtr(hs[i]);
+            if (ptr < thd_blocklimit) {
+                for (unsigned q = (unsigned)i + 1; q < i + ptr; q++) hs[q] &= ~(HS_BODYYMASK << 41);   // setHsBodyY(.., 0)
+                requestXNode(ix, hsHeadX(hs[i]), (unsigned)(i + 1), 1);
+            } else {
+                u64 xval = hsHeadX(hs[i]);
+                requestXNode(ix, xval, ~1u, 3);
+                for (unsigned q = (unsigned)i + 1; q < i + ptr; q++)
+                    if (hsBodyY(hs[q] ^ hs[q - 1])) requestXNode(ix, xval + ((hs[q] & ((1ULL << 61) - (1ULL << 41))) >> 1), q, 1);
+            }
+        }
+    }
+    ix.ysa.swap(hs);
+}
+static inline u64 make_anchor(u64 id, u64 x, u64 y, u64 strand) { return create_cord(id, x - y + const_anchor_zero, y, strand); }   // cords.cpp:319
+
 // ------------------------------------------------------------- features ----
 struct int96 { int v[3]; };
 static const int window48 = 48;
@@ -435,6 +621,44 @@ static void getDIndexMatchAll(const DIndex &index, const uint8_t *read, u64 read
                     }
                 }
                 xpre = shape.XValue;
+            }
+        }
+    }
+}
+
+
+static void getHIndexMatchAll(const HIndex &index, const uint8_t *read, u64 read_len, std::vector<u64> &set, u64 map_str, u64 map_end,
+                              const Parms &pm, Stats &st) {                           // pmpfinder.cpp:1918-1974
+    const u64 thd_delta = 64;                                                          // GetIndexMatchAllParms pmpfinder.cpp:1769-1776
+    int dt = 0;
+    Shape shape; shape.span = index.span; shape.weight = index.weight;
+    u64 xpre = 0;
+    hashInit(shape, read);
+    u64 read_str = get_cord_y(map_str), read_end = get_cord_y(map_end);
+    u64 idx_str = getCordX40(map_str), idx_end = getCordX40(map_end);
+    for (unsigned k = (unsigned)read_str; k < read_end - shape.span; k++) {
+        hashNexth(shape, read + k);
+        if (++dt == pm.thd_alpha) {
+            dt = 0;
+            hashNextX(shape, read + k);
+            st.samples++;
+            if (shape.XValue ^ xpre) {
+                xpre = shape.XValue;
+                u64 pos = getXDir(index, shape.XValue, shape.YValue);
+                u64 ptr = hsHeadPtr(index.ysa[pos - 1]);
+                st.lookups++;
+                if (pos == index.emptyDir || ptr >= thd_delta) { dt = 0; continue; }
+                while (hsBodyY(index.ysa[pos]) == shape.YValue || hsBodyY(index.ysa[pos]) == 0) {
+                    u64 idx = hsBodyS(index.ysa[pos]);
+                    st.bucket_entries++;
+                    if (idx >= idx_str && idx < idx_end) {
+                        u64 id = (idx >> 30) & ((1ULL << 10) - 1), x = idx & ((1ULL << 30) - 1);   // _getSA_i1 / _getSA_i2 index_util.cpp:110-117
+                        if (((index.ysa[pos] & HS_BODYCODEFLAG) >> 40) ^ shape.strand) set.push_back(make_anchor(id, x, read_len - 1 - k, 1));
+                        else set.push_back(make_anchor(id, x, k, 0));
+                        st.anchors++;
+                    }
+                    if (++pos > index.ysa.size() - 1) break;
+                }
             }
         }
     }
@@ -1239,6 +1463,8 @@ struct Ctx {          // shared, read-only after build
     std::vector<u64> lens;
     unsigned T = 1;
     DIndex index;
+    HIndex hindex;
+    int index_type = 1;   // -i: 1 DIndex, 2 HIndex (mapper.cpp:200)
     std::vector<Feat> f2;
     Work w;           // default single-thread work area
 };
@@ -1272,7 +1498,8 @@ static void apxMap_(const Ctx &cx, Work &c, const uint8_t *read, u64 read_len, s
     initCords(hits);             // initHits
     std::vector<int> hits_score;
     u64 read_str = get_cord_y(map_str), read_end = get_cord_y(map_end);
-    getDIndexMatchAll(cx.index, read, read_len, anchors, read_str, read_end, pm, c.stats);
+    if (cx.index_type == 2) getHIndexMatchAll(cx.hindex, read, read_len, anchors, map_str, map_end, pm, c.stats);   // getIndexMatchAll pmpfinder.cpp:2576-2583
+    else getDIndexMatchAll(cx.index, read, read_len, anchors, read_str, read_end, pm, c.stats);
     if (c.dbg.on && c.dbg.pass == 0) c.dbg.raw_anchors = anchors;
     getAnchorHitsChains(anchors, hits, hits_score, read_len, pm, c);
     // cords_info bookkeeping (pmpfinder.cpp:2655-2703) has no effect on cords; omitted.
@@ -1345,9 +1572,13 @@ static void apxMap(const Ctx &cx, Work &c, const uint8_t *read, u64 read_len) { 
 using namespace orc;
 extern "C" {
 
-void *orc_create(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T) {
+static void *orc_create_i(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T, int index_type);
+void *orc_create(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T) { return orc_create_i(seqs, lens, nseq, T, 1); }
+void *orc_create2(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T, int index_type) { return orc_create_i(seqs, lens, nseq, T, index_type); }
+static void *orc_create_i(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq, uint32_t T, int index_type) {
     Ctx *c = new Ctx();
     c->T = T ? T : 1;
+    c->index_type = index_type;
     std::vector<const uint8_t *> ptrs;
     for (uint32_t i = 0; i < nseq; i++) {
         c->seqs.emplace_back(lens[i] + SEQ_PAD, 0);
@@ -1355,7 +1586,8 @@ void *orc_create(const uint8_t *const *seqs, const uint64_t *lens, uint32_t nseq
         c->lens.push_back(lens[i]);
     }
     for (uint32_t i = 0; i < nseq; i++) ptrs.push_back(c->seqs[i].data());
-    createDIndex(ptrs, c->lens, c->index, c->T);
+    if (index_type == 2) createHIndex(ptrs, c->lens, c->hindex, c->T);
+    else createDIndex(ptrs, c->lens, c->index, c->T);
     c->f2.resize(nseq);
 #pragma omp parallel for schedule(dynamic, 1)
     for (uint32_t i = 0; i < nseq; i++) createFeatures2_48_par(ptrs[i], (i64)lens[i], c->f2[i], c->T);
@@ -1366,6 +1598,9 @@ uint64_t orc_dir_len(void *h) { return ((Ctx *)h)->index.dir.size(); }
 uint64_t orc_hs_len(void *h) { return ((Ctx *)h)->index.hs.size(); }
 const int32_t *orc_dir(void *h) { return ((Ctx *)h)->index.dir.data(); }
 const uint64_t *orc_hs(void *h) { return ((Ctx *)h)->index.hs.data(); }
+uint64_t orc_ysa_len(void *h) { return ((Ctx *)h)->hindex.ysa.size(); }
+const uint64_t *orc_ysa(void *h) { return ((Ctx *)h)->hindex.ysa.data(); }
+uint64_t orc_empty_dir(void *h) { return ((Ctx *)h)->hindex.emptyDir; }
 uint64_t orc_fill_mismatch(void *h) { return ((Ctx *)h)->index.fill_mismatch; }
 uint64_t orc_f2_len(void *h, uint32_t id) { return ((Ctx *)h)->f2[id].size(); }
 const int32_t *orc_f2(void *h, uint32_t id) { return (const int32_t *)((Ctx *)h)->f2[id].data(); }
@@ -1394,7 +1629,8 @@ uint64_t orc_seed_lookup(void *h, const uint8_t *read, uint64_t len, uint64_t re
     Parms pm;
     pm.thd_alpha = alpha;
     Stats st;
-    getDIndexMatchAll(c->index, s.data(), len, set, read_str, read_end, pm, st);
+    if (c->index_type == 2) getHIndexMatchAll(c->hindex, s.data(), len, set, read_str, create_cord(MAX_CORD_ID, MAX_CORD_X, read_end, 0), pm, st);   // map_str = y only, map_end as apxMap builds it
+    else getDIndexMatchAll(c->index, s.data(), len, set, read_str, read_end, pm, st);
     u64 n = std::min<u64>(set.size(), cap);
     if (out) memcpy(out, set.data(), n * 8);
     if (stats4) { stats4[0] = st.samples; stats4[1] = st.lookups; stats4[2] = st.bucket_entries; stats4[3] = st.anchors; }

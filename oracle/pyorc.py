@@ -32,7 +32,7 @@ def _p(a: np.ndarray, t):
 
 
 class Checker:
-    def __init__(self, kind: str, seqs: list[np.ndarray], T: int = 1):
+    def __init__(self, kind: str, seqs: list[np.ndarray], T: int = 1, index_type: int = 1):
         assert kind in ("oracle", "ref")
         path = os.path.join(HERE, "liblnr_oracle.so") if kind == "oracle" else os.path.join(HERE, "_ref", "libref_linear.so")
         if not os.path.exists(path):
@@ -42,8 +42,13 @@ class Checker:
         self.lib = C.CDLL(path)
         L = self.lib
         f = self._f
-        f("create").restype = C.c_void_p
-        f("create").argtypes = [C.POINTER(_u8p), _u64p, C.c_uint32, C.c_uint32]
+        f("create2").restype = C.c_void_p
+        f("create2").argtypes = [C.POINTER(_u8p), _u64p, C.c_uint32, C.c_uint32, C.c_int]
+        for n in ("ysa_len", "empty_dir"):
+            f(n).restype = C.c_uint64
+            f(n).argtypes = [C.c_void_p]
+        f("ysa").restype = _u64p
+        f("ysa").argtypes = [C.c_void_p]
         f("destroy").argtypes = [C.c_void_p]
         for n in ("dir_len", "hs_len"):
             f(n).restype = C.c_uint64
@@ -81,7 +86,8 @@ class Checker:
         self._seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
         ptrs = (_u8p * len(seqs))(*[_p(s, _u8p) for s in self._seqs])
         lens = np.array([s.size for s in self._seqs], dtype=np.uint64)
-        self.h = C.c_void_p(f("create")(ptrs, _p(lens, _u64p), len(seqs), T))
+        self.index_type = index_type   # the reference's -i: 1 DIndex, 2 HIndex
+        self.h = C.c_void_p(f("create2")(ptrs, _p(lens, _u64p), len(seqs), T, index_type))
         self.nseq = len(seqs)
 
     def _f(self, name):
@@ -99,6 +105,14 @@ class Checker:
             pass
 
     # ---- index / features
+    def ysa(self) -> np.ndarray:
+        """HIndex (-i 2): the sorted block array the lookups walk (parity surface like dir / hs for -i 1)."""
+        n = int(self._f("ysa_len")(self.h))
+        return np.ctypeslib.as_array(self._f("ysa")(self.h), shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint64)
+
+    def empty_dir(self) -> int:
+        return int(self._f("empty_dir")(self.h))
+
     def dir(self) -> np.ndarray:
         n = self._f("dir_len")(self.h)
         return np.ctypeslib.as_array(self._f("dir")(self.h), shape=(n,)).copy()

@@ -30,6 +30,8 @@ uint64_t filterAnchors(Anchors &anchors, uint64_t shape_len, uint64_t thd_anchor
                        unsigned thd_anchor_err_bit, uint64_t thd_max_anchors_num, uint64_t thd_anchor_accept_err, int alg_type);
 int chainAnchorsHits(String<uint64_t> &anchors, String<uint64_t> &hits, String<int> &hits_chains_score, PMPParms &pm_pmp);
 
+unsigned getHIndexMatchAll(LIndex &index, String<Dna5> &read, String<uint64_t> &set, uint64_t map_str, uint64_t map_end, PMPParms &pm_pmp);   // pmpfinder.cpp:1918
+
 namespace {
 const size_t PAD = 64;
 
@@ -87,6 +89,9 @@ uint64_t ref_dir_len(void *h) { return length(((RefCtx *)h)->idx->dindex.getDir(
 uint64_t ref_hs_len(void *h) { return length(((RefCtx *)h)->idx->dindex.getHs()); }
 const int32_t *ref_dir(void *h) { return (const int32_t *)&(((RefCtx *)h)->idx->dindex.getDir()[0]); }
 const uint64_t *ref_hs(void *h) { RefCtx *c = (RefCtx *)h; return length(c->idx->dindex.getHs()) ? &(c->idx->dindex.getHs()[0]) : nullptr; }
+uint64_t ref_ysa_len(void *h) { return length(((RefCtx *)h)->idx->hindex.ysa); }
+const uint64_t *ref_ysa(void *h) { RefCtx *c = (RefCtx *)h; return length(c->idx->hindex.ysa) ? &(c->idx->hindex.ysa[0]) : nullptr; }
+uint64_t ref_empty_dir(void *h) { return ((RefCtx *)h)->idx->hindex.emptyDir; }
 uint64_t ref_f2_len(void *h, uint32_t id) { return length(((RefCtx *)h)->f2[id].fs2_48); }
 const int32_t *ref_f2(void *h, uint32_t id) { return (const int32_t *)&(((RefCtx *)h)->f2[id].fs2_48[0]); }
 
@@ -112,7 +117,8 @@ uint64_t ref_seed_lookup(void *h, const uint8_t *read, uint64_t len, uint64_t re
     appendValue(set, 0);
     PMPParms pm;
     pm.pm_gdima.thd_alpha = alpha;
-    getDIndexMatchAll(c->idx->dindex, r, set, read_str, read_end, pm);
+    if (c->idx->isHIndex()) { pm.pm_ghima.thd_alpha = alpha; getHIndexMatchAll(c->idx->hindex, r, set, read_str, create_cord(MAX_CORD_ID, MAX_CORD_X, read_end, 0), pm); }
+    else getDIndexMatchAll(c->idx->dindex, r, set, read_str, read_end, pm);
     uint64_t n = length(set);
     if (out && n) memcpy(out, &set[0], (n < cap ? n : cap) * 8);
     if (stats4) { stats4[0] = stats4[1] = stats4[2] = 0; stats4[3] = n - 1; }

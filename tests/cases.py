@@ -59,6 +59,27 @@ def case_scale():
     return refs, reads, off
 
 
+def case_hbig():
+    """HIndex (-i 2) with blocks of 1024 entries and more: a 480 kb tandem repeat (period 40, 1 % substitutions) between random
+    flanks; every sampled X of the repeat collects thousands of entries, so lookups meet the virtual-head / (Y, X) nodes and the
+    `ptr >= 64` rule reads the word in front of a body."""
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, 40, dtype=np.uint8)
+    tand = np.tile(unit, 12000)
+    mut = rng.random(tand.size) < 0.01
+    tand[mut] = rng.integers(0, 4, int(mut.sum()), dtype=np.uint8)
+    ref = np.concatenate([synth.random_ref(300_000, 31), tand, synth.random_ref(200_000, 32)])
+    reads, off, _ = synth.sample_reads([ref], 30, 6000, 0.05, 91, "random")
+    return [ref], reads, off
+
+
+# HIndex (-i 2) goldens: name -> (builder, [T layouts]); files <name>_i2_T<T>.npz
+CASES_I2 = {
+    "c1": (case_c1, [1]),
+    "edge": (case_edge, [1, 3]),
+    "hbig": (case_hbig, [1, 4]),
+}
+
 CASES = {
     # name: (builder, [T layouts])
     "c1": (case_c1, [1]),

@@ -68,3 +68,45 @@ def test_oracle_matches_live_reference(oracle_lib):
         rd = reads[int(off[i]):int(off[i + 1])]
         a, b = o.map_read(rd), r.map_read(rd)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ---- HIndex (-i 2): ysa is the byte-exact surface (the open-addressed table's layout is not observable)
+PARAMS_I2 = [(n, T) for n, (_, Ts) in cases.CASES_I2.items() for T in Ts]
+
+
+@pytest.mark.parametrize("name,T", PARAMS_I2)
+def test_oracle_hindex_matches_reference_golden(oracle_lib, case_inputs, name, T):
+    refs, reads, off = case_inputs(name)
+    g = np.load(os.path.join(GOLD, f"{name}_i2_T{T}.npz"))
+    assert cases.input_digest(refs, reads, off) == str(g["digest"]), "synthetic generator drifted from the golden inputs"
+    o = oracle_lib.Checker("oracle", refs, T, index_type=2)
+    ysa = o.ysa()
+    assert ysa.size == int(g["ysa_len"]) and o.empty_dir() == int(g["empty_dir"])
+    assert np.array_equal(ysa[:4096], g["ysa_head"])
+    assert cases.sha(ysa) == str(g["ysa_sha"])
+    for k, i in enumerate(g["stage_reads"]):
+        rd = reads[int(off[i]):int(off[i + 1])]
+        assert np.array_equal(o.seed_lookup(rd)[0], g[f"st{k}_raw"]), f"raw anchors read {i}"
+        assert np.array_equal(o.seed_lookup(rd, 100, rd.size - 50, 7)[0], g[f"st{k}_raw7"]), f"raw anchors (alpha 7) read {i}"
+    coff = g["cord_off"]
+    for i in range(off.size - 1):
+        cs, ce = o.map_read(reads[int(off[i]):int(off[i + 1])])
+        assert np.array_equal(cs, g["cords_str"][int(coff[i]):int(coff[i + 1])]), f"cords read {i}"
+        assert np.array_equal(ce, g["cords_end"][int(coff[i]):int(coff[i + 1])])
+    o.close()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/pmpfinder.cpp"), reason="reference tree not present (GPU box)")
+def test_oracle_hindex_matches_live_reference(oracle_lib):
+    from linear_amd import synth
+    ref = synth.add_n_runs(synth.repeat_ref(400_000, 77), 3, n_runs=3, max_run=800)
+    reads, off, _ = synth.sample_reads([ref], 20, 7000, 0.08, 13, "random")
+    for T in (1, 5):
+        o = oracle_lib.Checker("oracle", [ref], T, index_type=2)
+        r = oracle_lib.Checker("ref", [ref], T, index_type=2)
+        assert np.array_equal(o.ysa(), r.ysa()) and o.empty_dir() == r.empty_dir()
+        for i in range(off.size - 1):
+            rd = reads[int(off[i]):int(off[i + 1])]
+            assert np.array_equal(o.seed_lookup(rd)[0], r.seed_lookup(rd)[0])
+            a, b = o.map_read(rd), r.map_read(rd)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

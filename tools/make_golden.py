@@ -45,6 +45,34 @@ def main():
                 d[name + ":bases"], d[name + ":off"], d[name + ":ids"] = b, o, np.array(ids)
             np.savez_compressed(os.path.join(outdir, "reader.npz"), **d)
             print("reader.npz:", {k: int(v.size) for k, v in d.items() if k.endswith(":off")})
+    # HIndex (-i 2): ysa digest, raw anchors of a few reads, cords of every read
+    for name, (builder, layouts) in cases.CASES_I2.items():
+        if only and (name + "_i2") not in only and "i2" not in only:
+            continue
+        refs, reads, off = builder()
+        n = off.size - 1
+        for T in layouts:
+            r = pyorc.Checker("ref", refs, T, index_type=2)
+            ysa = r.ysa()
+            d = {"digest": cases.input_digest(refs, reads, off), "T": T, "n_reads": n, "ysa_sha": cases.sha(ysa), "ysa_len": ysa.size,
+                 "ysa_head": ysa[:4096], "empty_dir": r.empty_dir()}
+            coff = np.zeros(n + 1, np.uint64)
+            cs_l, ce_l = [], []
+            for i in range(n):
+                cs, ce = r.map_read(reads[int(off[i]):int(off[i + 1])])
+                cs_l.append(cs); ce_l.append(ce)
+                coff[i + 1] = coff[i] + cs.size
+            d["cord_off"], d["cords_str"], d["cords_end"] = coff, np.concatenate(cs_l), np.concatenate(ce_l)
+            idx = [i for i in range(n) if int(off[i + 1] - off[i]) > 200][: cases.N_STAGE_READS]
+            d["stage_reads"] = np.array(idx)
+            for k, i in enumerate(idx):
+                rd = reads[int(off[i]):int(off[i + 1])]
+                d[f"st{k}_raw"], _ = r.seed_lookup(rd)
+                d[f"st{k}_raw7"], _ = r.seed_lookup(rd, 100, rd.size - 50, 7)
+            path = os.path.join(outdir, f"{name}_i2_T{T}.npz")
+            np.savez_compressed(path, **d)
+            print(f"{path}: reads {n} cords {int(coff[-1])} ysa {ysa.size} size {os.path.getsize(path) / 1024:.0f} kB")
+            r.close()
     for name, (builder, layouts) in cases.CASES.items():
         if only and name not in only:
             continue
