@@ -110,12 +110,13 @@ def _p(a: np.ndarray, t):
 class Filter:
     """One context = one GPU.  Mirrors the Mapper's compute interface: build the index once, then filter read blocks."""
 
-    def __init__(self, device: int = -1, scratch_budget: int = 0):
+    def __init__(self, device: int = -1, scratch_budget: int = 0, index_type: int = 1):
         self.lib = load_library()
         o = LnrOpts()
         self.lib.lnr_opts_default(C.byref(o))
         o.device = device
         o.scratch_budget = scratch_budget
+        o.index_type = index_type          # the reference's -i: 1 DIndex, 2 HIndex
         h = C.c_void_p()
         st = self.lib.lnr_create(C.byref(o), C.byref(h))
         if st != 0:

@@ -3,6 +3,7 @@
 //
 // There is no CPU execution path in this library: every stage runs in a HIP kernel, and every entry
 // point fails (LNR_ERR_NO_DEVICE / LNR_ERR_HIP) when no GPU is usable.
+#include <hipcub/hipcub.hpp>
 #include "lnr_kernels.hip"
 #include "../../include/linear_amd.h"
 
@@ -148,6 +149,7 @@ struct lnr_ctx {
     // lane's seed / tail launches), s_bulk the single-wave kernel of the same launch.
     hipStream_t s_multi[2] = {nullptr, nullptr}, s_bulk[2] = {nullptr, nullptr}, s_tail = nullptr;   // s_tail: early tail B of the reads that skip the re-map round
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_start = nullptr, ev_lane[2] = {nullptr, nullptr}, ev_prep = nullptr, ev_f1 = nullptr;
+    DevBuf hx_nkeys, hx_nvals; u32 hx_nnodes = 0; u64 hx_empty_dir = 0;   // HIndex (-i 2): dir = hdir[2^18] (head of the block of X, -1: none), hs = ysa, nodes of the large blocks
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl, ov;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines, ov = their aligned overflow lines (k_ix_lines)
     // ---- batch inputs / per-read arrays
     // host-buffer entry points: two input slots, so that the upload of the next batch (copy stream) runs under the kernels of
@@ -265,6 +267,109 @@ lnr_status build_seed_view(lnr_ctx *ctx) {
     return LNR_OK;
 }
 
+// ---- HIndex (-i 2): lookup tables from ysa (ctx->hs), at build and at adopt
+lnr_status hx_derive(lnr_ctx *ctx) {
+    u64 n = ctx->info.hs_len;
+    if (n < 2) { ctx->err = "empty HIndex"; return LNR_ERR_ARG; }
+    ctx->hx_empty_dir = n - 2;
+    ENSURE(ctx->dir, ctx->info.dir_len * 4);
+    HIPCK(hipMemsetAsync(ctx->dir.p, 0xff, ctx->info.dir_len * 4, ctx->stream));
+    DevBuf flag, tmp;
+    ENSURE(flag, (n + 1) * 4 + 16);
+    hipLaunchKernelGGL(k_hx_derive, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hs.as<u64>(), n, ctx->dir.as<i32>(), flag.as<i32>());
+    KCHECK();
+    HIPCK(hipMemsetAsync(flag.as<i32>() + n, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_hx_nodes_mark, dim3(1u << HX_XBITS), dim3(256), 0, ctx->stream, ctx->hs.as<u64>(), ctx->dir.as<i32>(), flag.as<i32>());
+    KCHECK();
+    DevBuf excl;
+    ENSURE(excl, (n + 1) * 4 + 16);
+    lnr_status st = dev_scan_i32(ctx, flag.as<i32>(), excl.as<i32>(), n + 1, tmp);
+    if (st != LNR_OK) return st;
+    i32 nn = 0;
+    HIPCK(hipMemcpyAsync(&nn, excl.as<i32>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    ctx->hx_nnodes = (u32)nn;
+    ENSURE(ctx->hx_nkeys, (size_t)std::max(nn, 1) * 8);
+    ENSURE(ctx->hx_nvals, (size_t)std::max(nn, 1) * 4);
+    if (nn) {
+        DevBuf k_in, v_in, cub;
+        ENSURE(k_in, (size_t)nn * 8); ENSURE(v_in, (size_t)nn * 4);
+        hipLaunchKernelGGL(k_hx_nodes_fill_blk, dim3(1u << HX_XBITS), dim3(256), 0, ctx->stream, ctx->hs.as<u64>(), ctx->dir.as<i32>(), flag.as<i32>(), excl.as<i32>(), k_in.as<u64>(), v_in.as<u32>());
+        KCHECK();
+        size_t tb = 0;   // stable sort by (X, Y20): equal keys keep ysa order, the lookup takes the first
+        HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.as<u64>(), ctx->hx_nkeys.as<u64>(), v_in.as<u32>(), ctx->hx_nvals.as<u32>(), nn, 0, 20 + HX_XBITS, ctx->stream));
+        ENSURE(cub, tb + 16);
+        HIPCK(hipcub::DeviceRadixSort::SortPairs(cub.p, tb, k_in.as<u64>(), ctx->hx_nkeys.as<u64>(), v_in.as<u32>(), ctx->hx_nvals.as<u32>(), nn, 0, 20 + HX_XBITS, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+    }
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    return LNR_OK;
+}
+// ---- HIndex build (createHIndex, index_util.cpp:1463-1476): samples per -t chunk, blocks by X, bodies descending, ysa
+lnr_status build_hindex(lnr_ctx *ctx, const u64 *len, u32 nseq, u32 T) {
+    std::vector<HxChunk> chunks;
+    u64 stage = 0;
+    for (u32 j = 0; j < nseq; j++) {
+        if (len[j] < HX_SPAN) { ctx->err = "sequence shorter than the HIndex shape (17 bases)"; return LNR_ERR_LIMIT; }
+        u64 npos = len[j] - HX_SPAN + 1, size2 = npos / T;
+        for (u32 t = 0; t < T; t++) {                                    // __createHsArray :745-760
+            HxChunk c; c.seq_off = ctx->seq_off[j]; c.seq_id = j; c.pad = 0;
+            if (t < npos - size2 * T) { c.chunk = size2 + 1; c.start = (size2 + 1) * t; }
+            else { c.chunk = size2; c.start = len[j] + 1 - HX_SPAN - size2 * (T - t); }
+            c.out_base = stage;
+            stage += c.chunk / HX_STEP + 4;
+            chunks.push_back(c);
+        }
+    }
+    u32 nch = (u32)chunks.size();
+    DevBuf d_ch, fileX, body, cnt, d_off, Xs, bodies, Xs2, bodies2, cub, flag, cntX, tmp;
+    lnr_status s;
+    if ((s = upload(ctx, d_ch, chunks)) != LNR_OK) return s;
+    ENSURE(fileX, stage * 4 + 16); ENSURE(body, stage * 8 + 16); ENSURE(cnt, (size_t)nch * 4 + 16);
+    hipLaunchKernelGGL(k_hx_chunk, dim3(nch), dim3(64), 0, ctx->stream, ctx->g.as<u8>(), d_ch.as<HxChunk>(), nch, fileX.as<u32>(), body.as<u64>(), cnt.as<u32>());
+    KCHECK();
+    std::vector<u32> hcnt(nch);
+    HIPCK(hipMemcpyAsync(hcnt.data(), cnt.p, (size_t)nch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    std::vector<u64> off(nch);
+    u64 n = 0;
+    for (u32 c = 0; c < nch; c++) { off[c] = n; n += hcnt[c]; }
+    if (n >= (1ULL << 31) - 4) { ctx->err = "too many HIndex samples"; return LNR_ERR_LIMIT; }
+    if (n == 0) { ctx->err = "no HIndex samples"; return LNR_ERR_ARG; }
+    ctx->info.n_samples = n;
+    if ((s = upload(ctx, d_off, off)) != LNR_OK) return s;
+    ENSURE(Xs, n * 4 + 16); ENSURE(bodies, n * 8 + 16); ENSURE(Xs2, n * 4 + 16); ENSURE(bodies2, n * 8 + 16);
+    hipLaunchKernelGGL(k_hx_compact, dim3(64, nch), dim3(256), 0, ctx->stream, d_ch.as<HxChunk>(), cnt.as<u32>(), d_off.as<u64>(), nch, fileX.as<u32>(), body.as<u64>(), Xs.as<u32>(), bodies.as<u64>());
+    KCHECK();
+    // blocks by X ascending, bodies of a block descending (_sort_YSA_Block :600-611): sort by body descending, then stable by X.
+    // (The reference's block sort is stable in file order, but the bodies of a block are re-sorted as whole words afterwards.)
+    size_t tb1 = 0, tb2 = 0;
+    HIPCK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb1, bodies.as<u64>(), bodies2.as<u64>(), Xs.as<u32>(), Xs2.as<u32>(), (int)n, 0, 64, ctx->stream));
+    HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, Xs2.as<u32>(), Xs.as<u32>(), bodies2.as<u64>(), bodies.as<u64>(), (int)n, 0, HX_XBITS, ctx->stream));
+    ENSURE(cub, std::max(tb1, tb2) + 16);
+    HIPCK(hipcub::DeviceRadixSort::SortPairsDescending(cub.p, tb1, bodies.as<u64>(), bodies2.as<u64>(), Xs.as<u32>(), Xs2.as<u32>(), (int)n, 0, 64, ctx->stream));
+    HIPCK(hipcub::DeviceRadixSort::SortPairs(cub.p, tb2, Xs2.as<u32>(), Xs.as<u32>(), bodies2.as<u64>(), bodies.as<u64>(), (int)n, 0, HX_XBITS, ctx->stream));
+    ENSURE(flag, (n + 1) * 4 + 16); ENSURE(cntX, ((size_t)1 << HX_XBITS) * 4);
+    HIPCK(hipMemsetAsync(cntX.p, 0, ((size_t)1 << HX_XBITS) * 4, ctx->stream));
+    HIPCK(hipMemsetAsync(flag.as<i32>() + n, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_hx_flags, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, Xs.as<u32>(), n, flag.as<i32>(), cntX.as<u32>());
+    KCHECK();
+    if ((s = dev_scan_i32(ctx, flag.as<i32>(), flag.as<i32>(), n + 1, tmp)) != LNR_OK) return s;
+    i32 ndist = 0;
+    HIPCK(hipMemcpyAsync(&ndist, flag.as<i32>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    // _createYSA :1336-1352: with fewer than three merged blocks the reference drops its last block and leaves words of it behind in
+    // file order -- a reference of a few hundred bases; not reproduced
+    if (n - (u64)ndist <= 2) { ctx->err = "reference too small for -i 2 (fewer than three repeated minimizers: the reference's countMove <= 2 branch)"; return LNR_ERR_UNSUPPORTED; }
+    u64 ysa_len = n + (u64)ndist + 2;
+    ctx->info.hs_len = ysa_len;
+    ENSURE(ctx->hs, ysa_len * 8 + 64);
+    hipLaunchKernelGGL(k_hx_assemble, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, Xs.as<u32>(), bodies.as<u64>(), n, flag.as<i32>(), cntX.as<u32>(), ctx->hs.as<u64>(), ysa_len);
+    KCHECK();
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    return hx_derive(ctx);
+}
+
 void set_index_layout(lnr_ctx *ctx, const u64 *len, u32 nseq) {
     ctx->seq_len.assign(len, len + nseq);
     ctx->seq_off.assign(nseq, 0);
@@ -278,7 +383,7 @@ void set_index_layout(lnr_ctx *ctx, const u64 *len, u32 nseq) {
     }
     ctx->info.nseq = nseq;
     ctx->info.genome_bytes = o;
-    ctx->info.dir_len = ((u64)1 << 26) + 1;
+    ctx->info.dir_len = ctx->opts.index_type == 2 ? ((u64)1 << HX_XBITS) + 1 : ((u64)1 << 26) + 1;
     ctx->info.f2_len = ctx->f2_off[nseq];
     ctx->nbins = (u32)((maxlen + (2ULL << 20)) / 30000 + 2);
 }
@@ -399,6 +504,10 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
         S.t_seed.start(st);
         // the bucket bitmap answers lookups of empty buckets without touching the bucket lines; once most buckets hold entries
         // (human scale: 328 M entries in 67 M buckets) it is one more dependent load in front of every lookup and is skipped
+        if (ctx->opts.index_type == 2)
+            hipLaunchKernelGGL(k_seed_hindex, dim3(nj), dim3(64), 0, st, J, R, ctx->hs.as<u64>(), ctx->info.hs_len, ctx->hx_empty_dir, ctx->dir.as<i32>(), ctx->hx_nkeys.as<u64>(), ctx->hx_nvals.as<u32>(), ctx->hx_nnodes, nj, O,
+                               S.est_x16);
+        else
         hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->bl.as<ulonglong2>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->ov.as<u64>(), nj, O, S.est_x16);
         KCHECK();
         S.t_seed.stop(st);
@@ -1105,7 +1214,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     *out = nullptr;
     lnr_opts o;
     if (opts) o = *opts; else lnr_opts_default(&o);
-    if (o.index_type != 1 || o.feature_type != 2 || o.gap_len != 0 || o.preset != 1) return LNR_ERR_UNSUPPORTED;
+    if ((o.index_type != 1 && o.index_type != 2) || o.feature_type != 2 || o.gap_len != 0 || o.preset != 1) return LNR_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return LNR_ERR_NO_DEVICE; }
     int dev = o.device;
@@ -1215,6 +1324,23 @@ lnr_status lnr_index_build(lnr_ctx *ctx, const uint8_t *const *seq, const uint64
     {   // ordinals above 4 -> N
         u64 n16 = (ctx->info.genome_bytes + 64) / 16;
         hipLaunchKernelGGL(k_clamp_bases, dim3((u32)((n16 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->g.as<u8>(), n16);
+    }
+    if (ctx->opts.index_type == 2) {   // HIndex: own build; genome features as for the DIndex
+        auto fail = [&](lnr_status st_) { tm.destroy(); return st_; };
+        lnr_status hst = build_hindex(ctx, len, nseq, T);
+        if (hst != LNR_OK) return fail(hst);
+        if (!ctx->f2.ensure(std::max<u64>(ctx->info.f2_len * sizeof(F96), 16))) { ctx->err = "device allocation failed during index build"; return fail(LNR_ERR_NOMEM); }
+        if (ctx->info.f2_len)
+            hipLaunchKernelGGL(k_f2, dim3((u32)((ctx->info.f2_len + 255) / 256)), dim3(256), 0, ctx->stream, ctx->g.as<u8>(), ctx->d_seq_off.as<u64>(), ctx->d_f2_off.as<u64>(), nseq,
+                               ctx->info.f2_len, ctx->f2.as<F96>());
+        tm.stop(ctx->stream);
+        hipError_t he = hipStreamSynchronize(ctx->stream);
+        if (he == hipSuccess) he = hipGetLastError();
+        if (he != hipSuccess) { ctx->err = std::string("HIndex build: ") + hipGetErrorString(he); return fail(LNR_ERR_HIP); }
+        ctx->info.build_ms = tm.ms();
+        tm.destroy();
+        ctx->has_index = true;
+        return LNR_OK;
     }
     // chunks of the T-thread layout (index_util.cpp:1654-1666)
     std::vector<ChunkDesc> chunks;
@@ -1361,7 +1487,7 @@ lnr_status lnr_index_adopt(lnr_ctx *ctx) {
     if (!ctx) return LNR_ERR_ARG;
     if (!ctx->g.p || !ctx->dir.p || !ctx->hs.p || !ctx->f2.p) return LNR_ERR_NO_INDEX;
     DevGuard dg_(ctx->device);
-    { lnr_status st_ = build_seed_view(ctx); if (st_ != LNR_OK) return st_; }   // derived structures: rebuilt from the received dir / hs
+    { lnr_status st_ = ctx->opts.index_type == 2 ? hx_derive(ctx) : build_seed_view(ctx); if (st_ != LNR_OK) return st_; }   // derived structures: rebuilt from the received dir / hs (ysa)
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->has_index = true;
     return LNR_OK;

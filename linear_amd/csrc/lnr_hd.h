@@ -162,28 +162,35 @@ struct ByteSeq {
 };
 struct SeedOut { u32 X; u32 Y; u32 strand; };
 
-template <class Seq> LNR_HD inline int shape_init_skip(const Seq &s) {   // N-skip of hashInit (shape_extend.cpp:95-105)
+// Shape span / weight: 21 / 13 for the DIndex (-i 1, index_util.cpp:2586), 17 / 9 for the HIndex (-i 2, index_util.cpp:2600-2604).
+template <int SPAN, class Seq> LNR_HD inline int shape_init_skip_t(const Seq &s) {   // N-skip of hashInit (shape_extend.cpp:95-105)
     u64 k = 0, count = 0;
-    while (count < 21) {
+    while (count < (u64)SPAN) {
         if (s[k + count] == 4) { k += count + 1; count = 0; }
         else count++;
     }
     return (int)k;
 }
-template <class Seq> LNR_HD inline int shape_const(const Seq &s, u64 init_at, int ks, u64 k0) {
+template <class Seq> LNR_HD inline int shape_init_skip(const Seq &s) { return shape_init_skip_t<21>(s); }
+// x (the strand selector) after the roll at k is C + 2 * (sum of the SPAN bases at k): hashInit leaves -3 SPAN + 2 a (a = its SPAN - 1
+// bases), every roll adds 2 * (base in - base out), the first one with "base out" = 0
+template <int SPAN, class Seq> LNR_HD inline int shape_const_t(const Seq &s, u64 init_at, int ks, u64 k0) {
     int a = 0, b = 0;
-    for (int i = 0; i < 20; i++) { a += s[init_at + ks + i]; b += s[k0 + i]; }
-    return -63 + 2 * a - 2 * b;
+    for (int i = 0; i < SPAN - 1; i++) { a += s[init_at + ks + i]; b += s[k0 + i]; }
+    return -3 * SPAN + 2 * a - 2 * b;
 }
+template <class Seq> LNR_HD inline int shape_const(const Seq &s, u64 init_at, int ks, u64 k0) { return shape_const_t<21>(s, init_at, ks, k0); }
 LNR_HD inline int shape_const(const PackedSeq &s, u64 init_at, int ks, u64 k0) {   // same value from the packed words
     return -63 + 2 * s.sum20(init_at + (u64)ks) - 2 * s.sum20(k0);
 }
-template <class Seq> LNR_HD inline SeedOut seed_sample(const Seq &s, u64 k, u64 k0, u64 init_at, int ks, int C) {
+// hashNexth + hashNextX at position k (shape_extend.cpp:173-184, 245-348) as a function of the bases: the rolling state after
+// n = k - k0 + 1 rolls since hashInit (at init_at, N-skip ks) is the last SPAN bases pushed, the oldest of them hashInit's own.
+template <int SPAN, int WEIGHT, class Seq> LNR_HD inline SeedOut seed_sample_t(const Seq &s, u64 k, u64 k0, u64 init_at, int ks, int C) {
     u64 h = 0, crh = 0;
     int W = 0;
     u64 n = k - k0 + 1;
-    int stale = n < 21 ? (int)(21 - n) : 0;
-    for (int p = 0; p < 21; p++) {
+    int stale = n < (u64)SPAN ? (int)(SPAN - n) : 0;
+    for (int p = 0; p < SPAN; p++) {
         u64 real = s[k + p];
         W += (int)real;
         u64 v = p < stale ? (u64)s[init_at + ks + n - 1 + p] : real;
@@ -191,23 +198,24 @@ template <class Seq> LNR_HD inline SeedOut seed_sample(const Seq &s, u64 k, u64 
         crh |= ((3 - v) & 3) << (2 * p);
     }
     int x = C + 2 * W;
-    u64 v2 = x > 0 ? (h & ((1ULL << 42) - 1)) : crh;
-    u64 X = (1ULL << 42) - 1, t = 0;
-    for (unsigned kk = 22; kk <= 38; kk += 2) {
-        u64 v1 = v2 << kk >> 38;
+    u64 v2 = x > 0 ? (h & ((1ULL << (2 * SPAN)) - 1)) : crh;
+    u64 X = (1ULL << (2 * SPAN)) - 1, t = 0;
+    for (unsigned kk = 64 - 2 * SPAN; kk <= 64 - 2 * WEIGHT; kk += 2) {
+        u64 v1 = v2 << kk >> (64 - 2 * WEIGHT);
         if (X > v1) { X = v1; t = kk; }
     }
     u64 Y = 0;
     if (x > 0) {
-        i64 d = (i64)(t >> 1) + 2;
-        for (i64 i = d; i < d + 4; i++) { u64 val = s[k + i]; Y = val > 3 ? (Y << 2) : (Y << 2) + val; }
+        i64 d = (i64)(t >> 1) + SPAN + WEIGHT - 32;
+        for (i64 i = d; i < d + 4; i++) { u64 val = s[(u64)((i64)k + i)]; Y = val > 3 ? (Y << 2) : (Y << 2) + val; }
     } else {
-        i64 d = 18 - (i64)(t >> 1);
+        i64 d = 31 - WEIGHT - (i64)(t >> 1);
         for (i64 i = d; i > d - 4; i--) { i64 val = 3 - (i64)s[(u64)((i64)k + i)]; Y = val < 0 ? (Y << 2) : (Y << 2) + (u64)val; }
     }
     SeedOut o; o.X = (u32)X; o.Y = (u32)Y; o.strand = x > 0 ? 0 : 1;
     return o;
 }
+template <class Seq> LNR_HD inline SeedOut seed_sample(const Seq &s, u64 k, u64 k0, u64 init_at, int ks, int C) { return seed_sample_t<21, 13>(s, k, k0, init_at, ks, C); }
 // --- the same sample from a 2-bit packed read ---------------------------------------------------------------
 // pk: bases packed LSB-first, 32 per u64 (N stored as 0); nm: one bit per base, set for N.  A sample at k needs the
 // 29 bases [k-4, k+25): the 21-mer plus the four flanking bases either side that YValue may read

@@ -838,6 +838,257 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
     if (lane == 0) { O.job_cap[j] = cap + 1; O.job_look[j] = looks; O.anc_off[j] = off; O.n_anchors[j] = dead ? 0 : nout; }
 }
 
+// ===================================================== HIndex (-i 2) build + lookup ====
+// SURVEY 8 a21 / f3.  The parity surface is `ysa` (index_util.cpp:719-845 hash array, 430-560 block sort, 1294-1461 _createYSA): blocks
+// [head = ptr << 40 | X][bodies = 1 << 63 | Y << 41 | reverse << 40 | id << 30 | pos, descending], X ascending, two zero words behind.
+// The reference's open-addressed table (XString) is an exact dictionary as compiled, so this build keeps its own
+// lookup tables, derived from ysa: hdir[X] = index of the block's head, and for the blocks of >= 1024 entries the sorted list of
+// (X, Y20) -> first body of the Y run that the reference's table holds.
+#define HX_SPAN 17
+#define HX_WEIGHT 9
+#define HX_STEP 8u
+#define HX_BLOCKLIMIT 1024u
+#define HX_XBITS (2 * HX_WEIGHT)
+static const u64 HS_TYPEFLAG = 1ULL << 63, HS_MASK40 = (1ULL << 40) - 1, HS_PTRMASK = (1ULL << 23) - 1, HS_YMASK = (1ULL << 20) - 1, HS_CODEFLAG = 1ULL << 40;
+LNR_HD inline u64 hs_head(u64 ptr, u64 x) { return ((ptr << 40) + x) & (HS_TYPEFLAG - 1); }
+LNR_HD inline u64 hs_head_ptr(u64 v) { return (v >> 40) & HS_PTRMASK; }
+LNR_HD inline u64 hs_body_y(u64 v) { return (v >> 41) & HS_YMASK; }
+struct HxChunk { u64 seq_off; u64 start, chunk; u64 out_base; u32 seq_id; u32 pad; };
+// sequence bytes through an 8-byte window (one thread walks a chunk: a byte load per base would be a memory round trip per base)
+struct HxBytes {
+    const u8 *base; u64 cur; u64 word;
+    __device__ u32 get(u64 i) {
+        u64 w = i >> 3;
+        if (w != cur) { word = *(const u64 *)(base + (w << 3)); cur = w; }
+        return (u32)(word >> (8 * (i & 7))) & 0xffu;
+    }
+};
+struct HxShape { u64 h, crh; int x, left; };
+__device__ inline u64 hx_hash_init(HxShape &me, HxBytes &b, u64 p) {                // hashInit shape_extend.cpp:86-116
+    me.left = 0; me.h = 0; me.crh = 0; me.x = -3;
+    u64 k = 0, count = 0;
+    while (count < HX_SPAN) {
+        if (b.get(p + k + count) == 4) { k += count + 1; count = 0; }
+        else count++;
+    }
+    unsigned bit = 2;
+    for (unsigned i = 0; i < HX_SPAN - 1; ++i) {
+        u64 val = b.get(p + k + i);
+        me.x += ((int)val << 1) - 3;
+        me.h = (me.h << 2) + val;
+        me.crh += (3ULL - val) << bit;
+        bit += 2;
+    }
+    return k;
+}
+__device__ inline void hx_roll(HxShape &me, u32 v_in, u32 v_left) {                 // state update of hashNext shape_extend.cpp:136-145
+    const u64 mask = (1ULL << (2 * HX_SPAN - 2)) - 1;
+    me.h = ((me.h & mask) << 2) + v_in;
+    me.crh = ((me.crh >> 2) & mask) + ((3ULL - (u64)v_in) << (2 * HX_SPAN - 2));
+    me.x += (int)(((u64)v_in - (u64)(i64)me.left) << 1);
+    me.left = (int)v_left;
+}
+__device__ inline void hx_xy(const HxShape &me, u32 &X, u64 &Y, u32 &strand) {       // X / Y of hashNext shape_extend.cpp:146-167
+    u64 v2; unsigned t = 0;
+    if (me.x > 0) { v2 = me.h; strand = 0; } else { v2 = me.crh; strand = 1; }
+    u64 xv = (1ULL << (2 * HX_SPAN)) - 1;
+    for (unsigned k = 64 - 2 * HX_SPAN; k <= 64 - 2 * HX_WEIGHT; k += 2) {
+        u64 v1 = v2 << k >> (64 - 2 * HX_WEIGHT);
+        if (xv > v1) { xv = v1; t = k; }
+    }
+    X = (u32)xv;
+    Y = (v2 >> (64 - t) << (64 - t - 2 * HX_WEIGHT)) + (v2 & ((1ULL << (64 - t - 2 * HX_WEIGHT)) - 1)) + ((u64)t << (2 * HX_SPAN - 2 * HX_WEIGHT - 1));
+}
+// One thread per (sequence, -t chunk): the reference's loop as written (__createHsArray, index_util.cpp:736-800), its samples into the
+// chunk's staging area: fileX[i] = X the sample's block is filed under, body[i].  A first correct form: the chunks of a sequence
+// are few and each is a sequential walk; clean stretches could be sampled in closed form like the DIndex build does.
+__global__ void __launch_bounds__(64) k_hx_chunk(const u8 *g, const HxChunk *ch, u32 nch, u32 *fileX, u64 *body, u32 *cnt) {
+    u32 c = blockIdx.x;
+    if (c >= nch || threadIdx.x != 0) return;
+    HxChunk d = ch[c];
+    HxBytes bi; bi.base = g + d.seq_off; bi.cur = ~0ULL; bi.word = 0;      // bytes entering the window
+    HxBytes bl = bi;                                                           // bytes leaving it
+    HxShape sh;
+    u64 start = d.start, chunk = d.chunk;
+    hx_hash_init(sh, bi, start);
+    u32 preX = 0xffffffffu;                                                    // (~0: never equal to an 18-bit X)
+    u64 n = 0;
+    u32 *fx = fileX + d.out_base; u64 *bd = body + d.out_base;
+    for (u64 k = start; k < start + chunk; k++) {
+        if (bi.get(k + HX_SPAN - 1) == 4) {
+            k += hx_hash_init(sh, bi, k);
+            if (k > chunk - HX_SPAN + 1 + start) k = chunk - (chunk + start) % HX_STEP + HX_STEP + start;
+        }
+        hx_roll(sh, bi.get(k + HX_SPAN - 1), bl.get(k));
+        if (k % HX_STEP == 0) {
+            u32 X, strand; u64 Y;
+            hx_xy(sh, X, Y, strand);
+            if (X != preX) {
+                u64 w = (((Y << 41) | HS_TYPEFLAG) + ((u64)d.seq_id << 30) + k);
+                if (strand) w |= HS_CODEFLAG;
+                fx[n] = X; bd[n] = w; n++;
+                preX = X;
+            }
+        }
+    }
+    if (n) { u32 X, strand; u64 Y; hx_xy(sh, X, Y, strand); fx[n - 1] = X; }   // the chunk's last block is filed under the X of its last hashed position (:801)
+    cnt[c] = (u32)n;
+}
+__global__ void __launch_bounds__(256) k_hx_compact(const HxChunk *ch, const u32 *cnt, const u64 *dst_off, u32 nch, const u32 *fileX, const u64 *body, u32 *Xs, u64 *bodies) {
+    u32 c = blockIdx.y;
+    if (c >= nch) return;
+    u64 n = cnt[c], so = ch[c].out_base, dof = dst_off[c];
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) { Xs[dof + i] = fileX[so + i]; bodies[dof + i] = body[so + i]; }
+}
+// after the two sorts (bodies descending, then stable by X): run starts and per-X counts
+__global__ void __launch_bounds__(256) k_hx_flags(const u32 *Xs, u64 n, i32 *flag, u32 *cntX) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 x = Xs[i];
+    flag[i] = (i == 0 || Xs[i - 1] != x) ? 1 : 0;
+    atomicAdd(&cntX[x], 1u);
+}
+// ysa[i + r] = body i (r = run starts up to and including i), the run's first body also writes the head; bodies of blocks under the
+// block limit lose their Y field (_createYSA :1431-1434)
+__global__ void __launch_bounds__(256) k_hx_assemble(const u32 *Xs, const u64 *bodies, u64 n, const i32 *flag_excl, const u32 *cntX, u64 *ysa, u64 ysa_len) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { ysa[ysa_len - 2] = 0; ysa[ysa_len - 1] = 0; }
+    if (i >= n) return;
+    u32 x = Xs[i];
+    bool st = i == 0 || Xs[i - 1] != x;
+    u64 r = (u64)flag_excl[i] + (st ? 1 : 0);
+    u32 c = cntX[x];
+    u64 w = bodies[i];
+    if (c + 1 < HX_BLOCKLIMIT) w &= ~(HS_YMASK << 41);
+    ysa[i + r] = w;
+    if (st) ysa[i + r - 1] = hs_head((u64)c + 1, x);
+}
+// ---- lookup tables derived from ysa (at build and at adopt)
+__global__ void __launch_bounds__(256) k_hx_derive(const u64 *ysa, u64 ysa_len, i32 *hdir, i32 *node_flag) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ysa_len) return;
+    u64 w = ysa[i];
+    node_flag[i] = 0;
+    if (!(w & HS_TYPEFLAG)) { if (hs_head_ptr(w)) hdir[(u32)(w & ((1u << HX_XBITS) - 1))] = (i32)i; }
+}
+// nodes of the blocks of >= 1024 entries: a body whose Y field differs from the word in front of it (head included), _createYSA :1446-1452
+__global__ void __launch_bounds__(256) k_hx_nodes_mark(const u64 *ysa, const i32 *hdir, i32 *node_flag) {
+    u32 x = blockIdx.x;                                      // one workgroup per X
+    i32 hd = hdir[x];
+    if (hd < 0) return;
+    u64 ptr = hs_head_ptr(ysa[hd]);
+    if (ptr < HX_BLOCKLIMIT) return;
+    for (u64 q = (u64)hd + 1 + threadIdx.x; q < (u64)hd + ptr; q += blockDim.x)
+        if (hs_body_y(ysa[q] ^ ysa[q - 1])) node_flag[q] = 1;
+}
+__global__ void __launch_bounds__(256) k_hx_nodes_fill_blk(const u64 *ysa, const i32 *hdir, const i32 *node_flag, const i32 *node_excl, u64 *nkeys, u32 *nvals) {
+    u32 x = blockIdx.x;
+    i32 hd = hdir[x];
+    if (hd < 0) return;
+    u64 ptr = hs_head_ptr(ysa[hd]);
+    if (ptr < HX_BLOCKLIMIT) return;
+    for (u64 q = (u64)hd + 1 + threadIdx.x; q < (u64)hd + ptr; q += blockDim.x)
+        if (node_flag[q]) { u32 slot = (u32)node_excl[q]; nkeys[slot] = ((u64)x << 20) | hs_body_y(ysa[q]); nvals[slot] = (u32)q; }
+}
+// getXDir (index_util.cpp:1071-1093) on the derived tables
+__device__ inline u64 hx_get_xdir(u32 X, u32 Y, const u64 *ysa, u64 empty_dir, const i32 *hdir, const u64 *nkeys, const u32 *nvals, u32 nnodes) {
+    i32 hd = hdir[X];
+    if (hd < 0) return empty_dir;
+    u64 ptr = hs_head_ptr(ysa[hd]);
+    if (ptr < HX_BLOCKLIMIT) return (u64)hd + 1;
+    if (Y > HS_YMASK || nnodes == 0) return empty_dir;
+    u64 key = ((u64)X << 20) | Y;
+    u32 lo = 0, hi = nnodes;                                 // first node with key >= key (the list is sorted, equal keys in ysa order)
+    while (lo < hi) { u32 mid = (lo + hi) >> 1; if (nkeys[mid] < key) lo = mid + 1; else hi = mid; }
+    return (lo < nnodes && nkeys[lo] == key) ? (u64)nvals[lo] : empty_dir;
+}
+// Seed lookup of one job per wave against the HIndex (getHIndexMatchAll, pmpfinder.cpp:1918-1974).  lane = sample for the
+// minimizers of a chunk of 64; the lookups then run one after the other in sample order, the wave walking ysa 64 words at a time.
+__global__ void __launch_bounds__(64) k_seed_hindex(JobArrays J, ReadArrays R, const u64 *ysa, u64 ysa_len, u64 empty_dir, const i32 *hdir, const u64 *nkeys, const u32 *nvals, u32 nnodes,
+                                                    u32 njobs, SeedOutArrays O, u32 est_per_sample_x16) {
+    u32 j = blockIdx.x;
+    if (j >= njobs) return;
+    int lane = lane_id();
+    u32 r = J.read[j];
+    PackedSeq s; s.pk = R.pk + R.pk_off[r]; s.nm = R.nm + R.pk_off[r]; s.L = R.len[r];
+    u64 L = s.L;
+    u64 rs = J.str[j], re = J.end[j];
+    u32 alpha = (u32)job_parm((int)J.mode[j]).alpha;
+    u64 k0 = rs;                                                                   // the loop rolls from read_str on (the DIndex form starts a span later)
+    u32 ns = 0;
+    if (re > HX_SPAN && rs + alpha - 1 < re - HX_SPAN) ns = (u32)((re - HX_SPAN - 1 - (rs + alpha - 1)) / alpha) + 1;   // samples k = rs + alpha - 1 + alpha i < re - span
+    int ks = shape_init_skip_t<HX_SPAN>(s);
+    int C = shape_const_t<HX_SPAN>(s, 0, ks, k0);
+    u64 seg_cap = ((((u64)ns * est_per_sample_x16) >> 4) + 192) & ~1ULL;
+    unsigned long long off = 0;
+    if (lane == 0) off = atomicAdd(O.cursor, (unsigned long long)seg_cap);
+    off = __shfl((long long)off, 0);
+    if (off + seg_cap > O.capacity) {
+        if (lane == 0) { *O.overflow = 1; O.n_anchors[j] = 0; O.job_cap[j] = 1; O.job_look[j] = 0; O.anc_off[j] = 0; }
+        return;
+    }
+    u64 *out = O.anchors + off;
+    if (lane == 0) out[0] = 0;
+    u32 nout = 1, cap = 0, looks = 0, carry = 0;
+    bool dead = false;
+    for (u32 base = 0; base < ns && !dead; base += 64) {
+        u32 si = base + (u32)lane;
+        bool valid = si < ns;
+        SeedOut o; o.X = 0; o.Y = 0; o.strand = 0;
+        u64 k = k0 + alpha - 1 + (u64)alpha * si;
+        if (valid) o = seed_sample_t<HX_SPAN, HX_WEIGHT>(s, k, k0, 0, ks, C);
+        u32 prev = __shfl_up(o.X, 1);
+        if (lane == 0) prev = carry;
+        carry = __shfl(o.X, 63);
+        bool look = valid && o.X != prev;
+        u64 lm = __ballot(look);
+        looks += (u32)__popcll(lm);
+        while (lm && !dead) {
+            int q = __builtin_ctzll(lm);
+            lm &= lm - 1;
+            u32 X = (u32)__builtin_amdgcn_readlane((int)o.X, q), Y = (u32)__builtin_amdgcn_readlane((int)o.Y, q), strand = (u32)__builtin_amdgcn_readlane((int)o.strand, q);
+            u64 kq = k0 + alpha - 1 + (u64)alpha * (base + (u32)q);
+            u64 pos = hx_get_xdir(X, Y, ysa, empty_dir, hdir, nkeys, nvals, nnodes);
+            u64 ptr = hs_head_ptr(ysa[pos - 1]);
+            if (pos == empty_dir || ptr >= 64) continue;
+            for (;;) {                                                              // while (Y field == Y or == 0) emit; stop at the end of ysa
+                u64 p = pos + (u64)lane;
+                bool inr = p <= ysa_len - 1;
+                u64 w = inr ? ysa[p] : 0;
+                u32 wy = (u32)hs_body_y(w);
+                bool ok = inr && (wy == Y || wy == 0);
+                u64 bad = __ballot(!ok);
+                u32 nv = bad ? (u32)__builtin_ctzll(bad) : 64u;
+                if (nv) {
+                    if ((u64)nout + nv > seg_cap) {                                 // segment full: move to one of twice the size
+                        u64 ncap = (2 * seg_cap + 128) & ~1ULL;
+                        unsigned long long noff = 0;
+                        if (lane == 0) noff = atomicAdd(O.cursor, (unsigned long long)ncap);
+                        noff = __shfl((long long)noff, 0);
+                        if (noff + ncap > O.capacity) { if (lane == 0) *O.overflow = 1; dead = true; break; }
+                        u64 *nw = O.anchors + noff;
+                        WSYNC();
+                        for (u32 i = (u32)lane; i < nout; i += 64) nw[i] = out[i];
+                        out = nw; off = noff; seg_cap = ncap;
+                    }
+                    if ((u32)lane < nv) {
+                        u64 idx = w & HS_MASK40;                                    // (idx_str = 0, idx_end = 2^40 - 1 for every job of this path: never out of range)
+                        u64 id = (idx >> 30) & 1023ULL, x = idx & ((1ULL << 30) - 1);
+                        u64 rev = ((w >> 40) & 1ULL) ^ strand;
+                        u64 y = rev ? L - 1 - kq : kq;
+                        out[nout + (u32)lane] = create_cord(id, x - y + ANCHOR_ZERO, y, rev);
+                    }
+                    nout += nv; cap += nv;
+                }
+                if (nv < 64) break;
+                pos += 64;
+                if (pos > ysa_len - 1) break;
+            }
+        }
+    }
+    if (lane == 0) { O.job_cap[j] = cap + 1; O.job_look[j] = looks; O.anc_off[j] = off; O.n_anchors[j] = dead ? 0 : nout; }
+}
+
 // =================================================================== job =====
 struct JobArgs {
     const u32 *grp_order;   // groups in launch order (heaviest first: the long tail of repeat-rich reads starts early)

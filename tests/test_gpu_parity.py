@@ -379,3 +379,64 @@ def test_gpu_apx_gaps_export(oracle_lib):
         tot += want.shape[0]
     assert tot >= 10
     f.close()
+
+
+# ---- HIndex (-i 2)
+PARAMS_I2 = [(n, T) for n, (_, Ts) in cases.CASES_I2.items() for T in Ts]
+
+
+@pytest.mark.parametrize("name,T", PARAMS_I2)
+def test_gpu_hindex_matches_golden(case_inputs, name, T):
+    """-i 2 through the C ABI against the reference's own output: ysa byte for byte, raw anchors of the stage reads (both
+    sampling steps) and the cords of every read."""
+    from linear_amd import Filter
+    refs, reads, off = case_inputs(name)
+    g = np.load(os.path.join(GOLD, f"{name}_i2_T{T}.npz"))
+    assert cases.input_digest(refs, reads, off) == str(g["digest"])
+    f = Filter(device=0, index_type=2)
+    info = f.build_index(refs, T)
+    assert info.hs_len == int(g["ysa_len"])
+    _, ysa, _, _ = f.index_export()
+    assert np.array_equal(ysa[:4096], g["ysa_head"])
+    assert cases.sha(ysa) == str(g["ysa_sha"]), "ysa differs from the reference"
+    aoff, anc = f.seed_lookup_batch(reads, off)
+    for k, i in enumerate(g["stage_reads"]):
+        assert np.array_equal(anc[int(aoff[i]):int(aoff[i + 1])], g[f"st{k}_raw"]), f"raw anchors of read {i}"
+    coff, cs, ce = f.filter_batch(reads, off)
+    assert np.array_equal(coff, g["cord_off"])
+    assert np.array_equal(cs, g["cords_str"])
+    assert np.array_equal(ce, g["cords_end"])
+    f.close()
+
+
+def test_gpu_hindex_matches_oracle_fresh_seed(oracle_lib):
+    """-i 2 on inputs without a golden (N runs, three sequences, reads that go through the re-map round), the oracle as the checker;
+    and the receiver path: a second context adopts the broadcast blobs and derives its lookup tables from ysa."""
+    import torch
+    from linear_amd import Filter, synth
+    from linear_amd.dist import blob_tensor
+    refs = [synth.add_n_runs(synth.repeat_ref(500_000, 41), 42, n_runs=3, max_run=900, lead=2500), synth.random_ref(150_000, 43), synth.repeat_ref(60_000, 44)]
+    reads, off, _ = synth.sample_reads(refs, 120, 7000, 0.1, 45, "random", len_jitter=0.6)
+    o = oracle_lib.Checker("oracle", refs, 3, index_type=2)
+    f = Filter(device=0, index_type=2)
+    f.build_index(refs, 3)
+    _, ysa, _, _ = f.index_export()
+    assert np.array_equal(ysa, o.ysa())
+    want = [o.map_read(reads[int(off[i]):int(off[i + 1])]) for i in range(off.size - 1)]
+    for flt in (f, None):
+        if flt is None:
+            flt = Filter(device=0, index_type=2)
+            flt.index_alloc_from(f.index_info_vec(), f.seq_len())
+            for (ps, bs), (pd, bd) in zip(f.index_blobs(), flt.index_blobs()):
+                assert bs == bd
+                if bs:
+                    blob_tensor(pd, bd, "cuda:0").copy_(blob_tensor(ps, bs, "cuda:0"))
+            torch.cuda.synchronize()
+            flt.index_adopt()
+        coff, cs, ce = flt.filter_batch(reads, off)
+        for i in range(off.size - 1):
+            a, b = int(coff[i]), int(coff[i + 1])
+            assert np.array_equal(cs[a:b], want[i][0]) and np.array_equal(ce[a:b], want[i][1]), f"read {i}"
+        if flt is not f:
+            flt.close()
+    f.close()
