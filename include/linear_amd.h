@@ -46,14 +46,15 @@ typedef enum lnr_status {
     LNR_ERR_NOMEM = -4,       /* device or host allocation failed */
     LNR_ERR_NO_INDEX = -5,    /* filter/seed call before lnr_index_build / lnr_index_adopt */
     LNR_ERR_LIMIT = -6,       /* input exceeds a format limit (read >= 2^20, sequence >= 2^30 - 2^20; cords.cpp:13-15) */
-    LNR_ERR_UNSUPPORTED = -7, /* option outside this build (index_type != 1, feature_type != 2, gap_len != 0) */
+    LNR_ERR_UNSUPPORTED = -7, /* option outside this build (index_type not 1 or 2, feature_type != 2, gap_len != 0; -i 2 on a reference with fewer
+                                 than three repeated minimizers) */
     LNR_ERR_INTERNAL = -8     /* device-side capacity overflow that retries could not resolve */
 } lnr_status;
 
 /* Options = the subset of the reference's `Options` (base.cpp:26-54) that reaches this path. */
 typedef struct lnr_opts {
     int32_t device;            /* HIP device ordinal; -1 = current device */
-    uint32_t index_type;       /* -i : 1 = DIndex (reference default).  2 (HIndex) not built yet */
+    uint32_t index_type;       /* -i : 1 = DIndex (reference default), 2 = HIndex (index_util.cpp:2593-2610: shape 17/9, one sample per 8 bases) */
     uint32_t feature_type;     /* -f : 2 = 2-mer/48 window features (reference default) */
     uint32_t preset;           /* -p : 1 (reference default: chain stop ratio 0) */
     uint32_t gap_len;          /* -g : must be 0 here (apxMap only; gap re-mapper is next tier) */
@@ -65,8 +66,8 @@ typedef struct lnr_index_info {
     uint32_t nseq;
     uint32_t layout_threads;   /* the reference's -t the index layout reproduces */
     uint64_t genome_bytes;     /* padded device copy of the sequences */
-    uint64_t dir_len;          /* int32 entries (4^13 + 1) */
-    uint64_t hs_len;           /* uint64 entries */
+    uint64_t dir_len;          /* int32 entries (4^13 + 1); -i 2: 4^9 + 1 entries of a derived table (head of the block of X, -1 = none) */
+    uint64_t hs_len;           /* uint64 entries; -i 2: the words of ysa, the reference's block array (the parity surface of that index) */
     uint64_t f2_len;           /* 16-byte feature entries over all sequences */
     uint64_t n_samples;        /* genome minimizer samples examined */
     double build_ms;           /* device time of the last build */

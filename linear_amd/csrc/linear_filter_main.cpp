@@ -25,18 +25,19 @@ struct Block {
 
 int main(int argc, char **argv) {
     if (argc < 4 || strcmp(argv[1], "filter") != 0) {
-        fprintf(stderr, "usage: %s filter <reads.fa|fq[.gz]> <genome.fa[.gz]> [-o prefix] [-t threads] [-g 0] [-ot 1|2|3] [-b reads_per_block]\n", argv[0]);
+        fprintf(stderr, "usage: %s filter <reads.fa|fq[.gz]> <genome.fa[.gz]> [-o prefix] [-t threads] [-i 1|2] [-g 0] [-ot 1|2|3] [-b reads_per_block]\n", argv[0]);
         return 2;
     }
     std::string reads_path = argv[2], genome_path = argv[3], prefix = "out", cmd;
     for (int i = 0; i < argc; i++) { if (i) cmd += ' '; cmd += argv[i]; }
-    unsigned threads = 1, ot = 3, gap = 0;
+    unsigned threads = 1, ot = 3, gap = 0, index_type = 1;
     uint32_t block_reads = 65536;
     for (int i = 4; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "-o") prefix = argv[i + 1];
         else if (k == "-t") threads = (unsigned)atoi(argv[i + 1]);
         else if (k == "-g") gap = (unsigned)atoi(argv[i + 1]);
+        else if (k == "-i") index_type = (unsigned)atoi(argv[i + 1]);   // 1 DIndex, 2 HIndex (args_parser.cpp:221)
         else if (k == "-ot") ot = (unsigned)atoi(argv[i + 1]);
         else if (k == "-b") block_reads = (uint32_t)atoi(argv[i + 1]);
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
@@ -67,7 +68,10 @@ int main(int argc, char **argv) {
     }
     if (genome.empty() || genome.size() >= 1024) { fprintf(stderr, "E: %zu reference sequences (1 .. 1023 supported, linear.cpp:107)\n", genome.size()); return 1; }
     lnr_ctx *ctx = nullptr;
-    lnr_status s = lnr_create(nullptr, &ctx);
+    lnr_opts opts;
+    lnr_opts_default(&opts);
+    opts.index_type = index_type;
+    lnr_status s = lnr_create(&opts, &ctx);
     if (s != LNR_OK) { fprintf(stderr, "E: %s\n", lnr_strerror(s)); return 1; }
     std::vector<const uint8_t *> gp; std::vector<uint64_t> gl; std::vector<const char *> gn;
     for (size_t i = 0; i < genome.size(); i++) { gp.push_back(genome[i].data()); gl.push_back(genome[i].size()); gn.push_back(gid[i].c_str()); }

@@ -19,6 +19,7 @@ ap.add_argument("--batches", type=int, default=3)
 ap.add_argument("--T", type=int, default=16)
 ap.add_argument("--seed-only", action="store_true")
 ap.add_argument("--chr22", action="store_true", help="the round-1 workload (configs[1]) instead of the GRCh38 stand-in")
+ap.add_argument("--index-type", type=int, default=1, help="the reference's -i: 1 DIndex, 2 HIndex")
 ap.add_argument("--check", type=int, default=0, help="compare the first N reads of batch 0 with the oracle (builds the oracle's own index)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -30,7 +31,7 @@ t0 = time.time()
 if not a.chr22:
     gen, offs = grch38_like_cuda(dev, scale=a.scale); torch.cuda.synchronize()
 print(f"genome {gen.numel() / 1e6:.0f} Mb in {time.time() - t0:.1f}s, N fraction {(gen == 4).float().mean().item():.3f}", flush=True)
-f = Filter(device=0)
+f = Filter(device=0, index_type=a.index_type)
 t0 = time.time()
 info = f.build_index_ptrs([gen.data_ptr() + o for o in offs[:-1]], [offs[i + 1] - offs[i] for i in range(len(offs) - 1)], a.T)
 print(f"index {time.time() - t0:.2f}s wall, {info.build_ms:.0f} ms device: hs {info.hs_len} samples {info.n_samples} f2 {info.f2_len}", flush=True)
@@ -52,11 +53,12 @@ if a.check:
     from oracle import pyorc
     pyorc.build(ref=False)
     h = gen.cpu().numpy()
-    t0 = time.time(); orc = pyorc.Checker("oracle", [h[offs[i]:offs[i + 1]] for i in range(24)], a.T); print(f"oracle index {time.time() - t0:.1f}s", flush=True)
+    t0 = time.time(); orc = pyorc.Checker("oracle", [h[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], a.T, a.index_type); print(f"oracle index {time.time() - t0:.1f}s", flush=True)
     r, o = batches[0]
     hr = r[: a.check * a.read_len].cpu().numpy(); ho = o[: a.check + 1].cpu().numpy().astype(np.uint64)
     t0 = time.time(); ooff, ocs, oce, ost = orc.map_batch(hr, ho, threads=os.cpu_count()); tc = time.time() - t0
     coff, cs, ce = f.filter_batch(hr, ho)
     print(f"oracle {a.check / tc:.0f} reads/s on {os.cpu_count()} threads; parity {np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce)}", flush=True)
     dir_, hs, _, _ = f.index_export()
-    print("index parity", np.array_equal(dir_, orc.dir()), np.array_equal(hs, orc.hs()), flush=True)
+    if a.index_type == 2: print("index parity (ysa)", np.array_equal(hs, orc.ysa()), flush=True)
+    else: print("index parity", np.array_equal(dir_, orc.dir()), np.array_equal(hs, orc.hs()), flush=True)

@@ -32,6 +32,7 @@ def main():
     bad = 0
     only = {int(x) for x in os.environ.get("LNR_STRESS_ONLY", "").split(",") if x}
     libs = [x for x in os.environ.get("LNR_STRESS_LIBS", "").split(",") if x]
+    itype = int(os.environ.get("LNR_STRESS_INDEX_TYPE", "1"))   # the reference's -i: 1 DIndex, 2 HIndex
     for k in range(ncfg):
         s = int(rng.integers(1, 1 << 30))
         kind = int(rng.integers(0, 3))
@@ -56,13 +57,13 @@ def main():
             os.environ.pop(kv, None)
         os.environ.update(opt)
         t0 = time.time()
-        o = pyorc.Checker("oracle", refs, T)
+        o = pyorc.Checker("oracle", refs, T, itype)
         ooff, ocs, oce, _ = o.map_batch(reads, off, threads=8)
         t1 = time.time()
         for lib in libs:
             from linear_amd import api
             api.SO = os.path.abspath(lib)
-            f = Filter(device=0)
+            f = Filter(device=0, index_type=itype)
             f.build_index(refs, T)
             coff, cs, ce = f.filter_batch(reads, off)
             f.close()
@@ -73,7 +74,7 @@ def main():
                 rd = np.unique(np.searchsorted(ooff, d, side="right") - 1)
                 nd = len(rd)
             print(f"[stress] cfg {k} lib {lib}: {'ok' if same else 'MISMATCH'} (reads differing: {nd})", flush=True)
-        f = Filter(device=0)
+        f = Filter(device=0, index_type=itype)
         f.build_index(refs, T)
         coff, cs, ce = f.filter_batch(reads, off)
         f.close()
@@ -81,7 +82,7 @@ def main():
         bad += 0 if same else 1
         print(f"[stress] cfg {k}: kind {kind} T {T} L {L} err {err} reads {nreads} opts {opt} cords {cs.size}: {'ok' if same else 'MISMATCH'} (oracle {t1 - t0:.1f}s)", flush=True)
     nrun = len(only) if only else ncfg
-    print(f"[stress] {nrun - bad}/{nrun} configurations bit-exact")
+    print(f"[stress] {nrun - bad}/{nrun} configurations bit-exact (index type {itype})")
     sys.exit(1 if bad else 0)
 
 
