@@ -18,10 +18,11 @@
 
 struct GpuFilter {
     lnr_ctx *ctx;
-    explicit GpuFilter(int device = -1) : ctx(nullptr) {
+    explicit GpuFilter(int device = -1, unsigned index_type = 1 /* options.index_t: 1 DIndex, 2 HIndex (mapper.cpp:200) */) : ctx(nullptr) {
         lnr_opts o;
         lnr_opts_default(&o);
         o.device = device;
+        o.index_type = index_type;
         if (lnr_create(&o, &ctx) != LNR_OK) ctx = nullptr;   // no GPU -> the caller keeps the CPU path
     }
     ~GpuFilter() { lnr_destroy(ctx); }
