@@ -14,6 +14,7 @@
 #include "index_util.h"
 #include "cluster_util.h"
 #include "pmpfinder.h"
+#include "gap.h"
 #include <seqan/seq_io.h>
 #include "f_io.h"
 #include <fstream>
@@ -139,6 +140,24 @@ uint64_t ref_map_read(void *h, const uint8_t *read, uint64_t len) {
     createFeatures(begin(r), end(r), c->f1[0]);
     createFeatures(begin(c->com), end(c->com), c->f1[1]);
     apxMap(*c->idx, r, c->anchors, c->hit, c->f1, c->f2, c->gaps, c->cs, c->ce, ci, 1, c->pg, c->pm);
+    return length(c->cs);
+}
+// apxMap + the gap re-mapper as Mapper::p_calRecords runs them for `-g gap_len [-dup f_dup]` (mapper.cpp:207-231,438-453): SURVEY 8 f1,
+// not built on the GPU yet -- this entry point makes its goldens.
+uint64_t ref_map_read_g(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup) {
+    uint64_t n0 = ref_map_read(h, read, len);
+    RefCtx *c = (RefCtx *)h;
+    if (len <= 200 || gap_len == 0) return n0;
+    String<Dna5> r;
+    assign_padded(r, read, len);
+    GapParms gp(0.2);
+    gp.f_dup = f_dup;
+    gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
+    gp.read_id = "read";
+    String<uint64_t> clips;
+    mapGaps(c->g, r, c->com, c->cs, c->ce, clips, c->gaps, c->f1, c->f2, gp);
+    CordsParms cp;
+    reformCords(c->cs, c->ce, &reformCordsDxDy1, cp);
     return length(c->cs);
 }
 uint64_t ref_get_gaps(void *h, uint64_t *out_pairs, uint64_t cap_pairs) {   // apx_gaps of the last ref_map_read

@@ -45,6 +45,26 @@ def main():
                 d[name + ":bases"], d[name + ":off"], d[name + ":ids"] = b, o, np.array(ids)
             np.savez_compressed(os.path.join(outdir, "reader.npz"), **d)
             print("reader.npz:", {k: int(v.size) for k, v in d.items() if k.endswith(":off")})
+    # gap path (-g 50; not built on the GPU yet): the reference's cords after mapGaps + reformCords, for the next tier
+    for name, T in (("ont", 1), ("edge", 1)):
+        if only and "g50" not in only:
+            continue
+        refs, reads, off = cases.CASES[name][0]()
+        n = off.size - 1
+        r = pyorc.Checker("ref", refs, T)
+        d = {"digest": cases.input_digest(refs, reads, off), "T": T, "n_reads": n}
+        for dup in (0, 1):
+            coff = np.zeros(n + 1, np.uint64)
+            cs_l, ce_l = [], []
+            for i in range(n):
+                cs, ce = r.map_read_gap(reads[int(off[i]):int(off[i + 1])], 50, dup)
+                cs_l.append(cs); ce_l.append(ce)
+                coff[i + 1] = coff[i] + cs.size
+            d[f"cord_off_dup{dup}"], d[f"cords_str_dup{dup}"], d[f"cords_end_dup{dup}"] = coff, np.concatenate(cs_l), np.concatenate(ce_l)
+        path = os.path.join(outdir, f"{name}_g50_T{T}.npz")
+        np.savez_compressed(path, **d)
+        print(f"{path}: reads {n} cords {int(d['cord_off_dup0'][-1])} / {int(d['cord_off_dup1'][-1])} size {os.path.getsize(path) / 1024:.0f} kB")
+        r.close()
     # HIndex (-i 2): ysa digest, raw anchors of a few reads, cords of every read
     for name, (builder, layouts) in cases.CASES_I2.items():
         if only and (name + "_i2") not in only and "i2" not in only:
