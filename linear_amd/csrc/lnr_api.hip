@@ -307,39 +307,90 @@ lnr_status hx_derive(lnr_ctx *ctx) {
 }
 // ---- HIndex build (createHIndex, index_util.cpp:1463-1476): samples per -t chunk, blocks by X, bodies descending, ysa
 lnr_status build_hindex(lnr_ctx *ctx, const u64 *len, u32 nseq, u32 T) {
-    std::vector<HxChunk> chunks;
+    std::vector<HxPiece> pieces;
+    std::vector<u32> chunk_first;                                        // index of every chunk's first piece (+ end sentinel)
     u64 stage = 0;
     for (u32 j = 0; j < nseq; j++) {
         if (len[j] < HX_SPAN) { ctx->err = "sequence shorter than the HIndex shape (17 bases)"; return LNR_ERR_LIMIT; }
         u64 npos = len[j] - HX_SPAN + 1, size2 = npos / T;
         for (u32 t = 0; t < T; t++) {                                    // __createHsArray :745-760
-            HxChunk c; c.seq_off = ctx->seq_off[j]; c.seq_id = j; c.pad = 0;
-            if (t < npos - size2 * T) { c.chunk = size2 + 1; c.start = (size2 + 1) * t; }
-            else { c.chunk = size2; c.start = len[j] + 1 - HX_SPAN - size2 * (T - t); }
-            c.out_base = stage;
-            stage += c.chunk / HX_STEP + 4;
-            chunks.push_back(c);
+            u64 chunk, start;
+            if (t < npos - size2 * T) { chunk = size2 + 1; start = (size2 + 1) * t; }
+            else { chunk = size2; start = len[j] + 1 - HX_SPAN - size2 * (T - t); }
+            chunk_first.push_back((u32)pieces.size());
+            u64 u = start;
+            do {                                                         // (a chunk of no positions still has its hashInit: one empty piece)
+                HxPiece c; c.seq_off = ctx->seq_off[j]; c.seq_id = j; c.start = start; c.chunk = chunk;
+                c.u = u; c.v = std::min(u + HX_PIECE, start + chunk); if (c.v < c.u) c.v = c.u;
+                if (start + chunk - c.v < 64) c.v = start + chunk;       // no sliver at the end: the last piece holds the chunk's end rule
+                c.first = u == start ? 1 : 0; c.out_base = stage; c.kt0 = ~0ULL; c.kinit = start; c.nc = ~0ULL; c.slen = len[j];
+                stage += (c.v - c.u) / HX_STEP + 4;
+                pieces.push_back(c);
+                u = c.v;
+            } while (u < start + chunk);
         }
     }
-    u32 nch = (u32)chunks.size();
-    DevBuf d_ch, fileX, body, cnt, d_off, Xs, bodies, Xs2, bodies2, cub, flag, cntX, tmp;
+    chunk_first.push_back((u32)pieces.size());
+    u32 npc = (u32)pieces.size(), nchk = (u32)chunk_first.size() - 1;
+    DevBuf d_pc, fileX, body, d_po, d_cp, d_fn, d_fc, d_tc, Xs, bodies, Xs2, bodies2, cub, flag, cntX, tmp;
     lnr_status s;
-    if ((s = upload(ctx, d_ch, chunks)) != LNR_OK) return s;
-    ENSURE(fileX, stage * 4 + 16); ENSURE(body, stage * 8 + 16); ENSURE(cnt, (size_t)nch * 4 + 16);
-    hipLaunchKernelGGL(k_hx_chunk, dim3(nch), dim3(64), 0, ctx->stream, ctx->g.as<u8>(), d_ch.as<HxChunk>(), nch, fileX.as<u32>(), body.as<u64>(), cnt.as<u32>());
+    if ((s = upload(ctx, d_pc, pieces)) != LNR_OK) return s;
+    ENSURE(d_fn, (size_t)npc * 8 + 16); ENSURE(d_fc, (size_t)npc * 8 + 16); ENSURE(d_tc, (size_t)npc * 8 + 16);
+    hipLaunchKernelGGL(k_hx_pre, dim3((npc + 63) / 64), dim3(64), 0, ctx->stream, ctx->g.as<u8>(), d_pc.as<HxPiece>(), npc, d_fn.as<u64>(), d_fc.as<u64>(), d_tc.as<u64>());
     KCHECK();
-    std::vector<u32> hcnt(nch);
-    HIPCK(hipMemcpyAsync(hcnt.data(), cnt.p, (size_t)nch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    {   // what a piece needs from its neighbours: where a jump over an N cluster lands behind it (nc), the chunk's first clean window
+        // (kinit: the state its hashInit leaves) and where the first N enters a window of the chunk (kt0)
+        std::vector<u64> fn(npc), fc(npc), tc(npc);
+        HIPCK(hipMemcpyAsync(fn.data(), d_fn.p, (size_t)npc * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipMemcpyAsync(fc.data(), d_fc.p, (size_t)npc * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipMemcpyAsync(tc.data(), d_tc.p, (size_t)npc * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        u64 carried = ~0ULL;
+        for (i64 q = (i64)npc - 1; q >= 0; q--) {                                // pieces are in sequence order, positions ascending
+            bool seq_last = q == (i64)npc - 1 || pieces[q + 1].seq_id != pieces[q].seq_id;
+            if (seq_last) carried = tc[q];                                        // (position len is always clean: padding)
+            pieces[q].nc = carried;
+            if (fc[q] != ~0ULL) carried = fc[q];
+        }
+        for (u32 c = 0; c < nchk; c++) {
+            u32 p0 = chunk_first[c], p1 = chunk_first[c + 1];
+            u64 kt0 = ~0ULL;
+            for (u32 q = p0; q < p1; q++) if (fn[q] != ~0ULL) { kt0 = fn[q] - 16; break; }
+            u64 kinit = fc[p0] != ~0ULL ? fc[p0] : pieces[p0].nc;
+            for (u32 q = p0; q < p1; q++) { pieces[q].kt0 = kt0; pieces[q].kinit = kinit; }
+        }
+        if ((s = upload(ctx, d_pc, pieces)) != LNR_OK) return s;
+    }
+    ENSURE(fileX, stage * 4 + 16); ENSURE(body, stage * 8 + 16); ENSURE(d_po, (size_t)npc * sizeof(HxPieceOut) + 16);
+    hipLaunchKernelGGL(k_hx_piece, dim3((npc + 63) / 64), dim3(64), 0, ctx->stream, ctx->g.as<u8>(), d_pc.as<HxPiece>(), npc, fileX.as<u32>(), body.as<u64>(), d_po.as<HxPieceOut>());
+    KCHECK();
+    std::vector<HxPieceOut> po(npc);
+    HIPCK(hipMemcpyAsync(po.data(), d_po.p, (size_t)npc * sizeof(HxPieceOut), hipMemcpyDeviceToHost, ctx->stream));
     HIPCK(hipStreamSynchronize(ctx->stream));
-    std::vector<u64> off(nch);
+    std::vector<HxCopy> cp(npc);
     u64 n = 0;
-    for (u32 c = 0; c < nch; c++) { off[c] = n; n += hcnt[c]; }
+    for (u32 c = 0; c < nchk; c++) {
+        u32 p0 = chunk_first[c], p1 = chunk_first[c + 1];
+        bool have_prev = false; u32 prevX = 0, endX = 0; bool any_hashed = false; i64 last_emit = -1;
+        for (u32 q = p0; q < p1; q++) {
+            HxCopy k; k.src = pieces[q].out_base; k.n = po[q].cnt; k.patch = 0; k.patchX = 0; k.pad = 0;
+            if (po[q].cnt) {
+                if (q != p0 && have_prev && po[q].firstX == prevX) { k.src++; k.n--; }   // first sample of the piece repeats the X of the sample before it
+                have_prev = true; prevX = po[q].lastX;
+            }
+            k.dst = n; n += k.n;
+            if (k.n) last_emit = q;
+            if (po[q].hashed) { any_hashed = true; endX = po[q].endX; }
+            cp[q] = k;
+        }
+        if (last_emit >= 0 && any_hashed) { cp[(u32)last_emit].patch = 1; cp[(u32)last_emit].patchX = endX; }   // :801
+    }
     if (n >= (1ULL << 31) - 4) { ctx->err = "too many HIndex samples"; return LNR_ERR_LIMIT; }
     if (n == 0) { ctx->err = "no HIndex samples"; return LNR_ERR_ARG; }
     ctx->info.n_samples = n;
-    if ((s = upload(ctx, d_off, off)) != LNR_OK) return s;
+    if ((s = upload(ctx, d_cp, cp)) != LNR_OK) return s;
     ENSURE(Xs, n * 4 + 16); ENSURE(bodies, n * 8 + 16); ENSURE(Xs2, n * 4 + 16); ENSURE(bodies2, n * 8 + 16);
-    hipLaunchKernelGGL(k_hx_compact, dim3(64, nch), dim3(256), 0, ctx->stream, d_ch.as<HxChunk>(), cnt.as<u32>(), d_off.as<u64>(), nch, fileX.as<u32>(), body.as<u64>(), Xs.as<u32>(), bodies.as<u64>());
+    hipLaunchKernelGGL(k_hx_compact, dim3(npc), dim3(256), 0, ctx->stream, d_cp.as<HxCopy>(), npc, fileX.as<u32>(), body.as<u64>(), Xs.as<u32>(), bodies.as<u64>());
     KCHECK();
     // blocks by X ascending, bodies of a block descending (_sort_YSA_Block :600-611): sort by body descending, then stable by X.
     // (The reference's block sort is stable in file order, but the bodies of a block are re-sorted as whole words afterwards.)

@@ -853,7 +853,17 @@ static const u64 HS_TYPEFLAG = 1ULL << 63, HS_MASK40 = (1ULL << 40) - 1, HS_PTRM
 LNR_HD inline u64 hs_head(u64 ptr, u64 x) { return ((ptr << 40) + x) & (HS_TYPEFLAG - 1); }
 LNR_HD inline u64 hs_head_ptr(u64 v) { return (v >> 40) & HS_PTRMASK; }
 LNR_HD inline u64 hs_body_y(u64 v) { return (v >> 41) & HS_YMASK; }
-struct HxChunk { u64 seq_off; u64 start, chunk; u64 out_base; u32 seq_id; u32 pad; };
+// A -t chunk of a sequence is cut into pieces of HX_PIECE positions, one thread each.  The reference's loop (__createHsArray,
+// index_util.cpp:736-800) is a sequential walk with a rolling state, but the state is a function of the bases: after 17 rolls the
+// hash words are the window itself, and the strand selector x is C + 2 * (sum of the window) with C = -51 from any hashInit whose
+// window was clean -- only the chunk's very first hashInit can leave another C (an N among the chunk's first 16 bases), and that C
+// holds until the first N enters a window (position kt0).  So a piece whose predecessor position has a clean window rebuilds the
+// state there; one that starts inside an N cluster starts like the reference's re-initialisation does, at the first clean window.
+// What needs the neighbours is settled on the host from four words per piece: the first sample of a piece is dropped when its X
+// equals the X of the sample before it, and the chunk's last block is filed under the X of the chunk's last hashed position.
+#define HX_PIECE 32768u
+struct HxPiece { u64 seq_off; u64 start, chunk; u64 u, v; u64 out_base; u64 kt0; u64 kinit; u64 nc; u64 slen; u32 seq_id; u32 first; };
+struct HxPieceOut { u32 cnt, firstX, lastX, endX, hashed, pad; };
 // sequence bytes through an 8-byte window (one thread walks a chunk: a byte load per base would be a memory round trip per base)
 struct HxBytes {
     const u8 *base; u64 cur; u64 word;
@@ -899,46 +909,106 @@ __device__ inline void hx_xy(const HxShape &me, u32 &X, u64 &Y, u32 &strand) {  
     X = (u32)xv;
     Y = (v2 >> (64 - t) << (64 - t - 2 * HX_WEIGHT)) + (v2 & ((1ULL << (64 - t - 2 * HX_WEIGHT)) - 1)) + ((u64)t << (2 * HX_SPAN - 2 * HX_WEIGHT - 1));
 }
-// One thread per (sequence, -t chunk): the reference's loop as written (__createHsArray, index_util.cpp:736-800), its samples into the
-// chunk's staging area: fileX[i] = X the sample's block is filed under, body[i].  A first correct form: the chunks of a sequence
-// are few and each is a sequential walk; clean stretches could be sampled in closed form like the DIndex build does.
-__global__ void __launch_bounds__(64) k_hx_chunk(const u8 *g, const HxChunk *ch, u32 nch, u32 *fileX, u64 *body, u32 *cnt) {
-    u32 c = blockIdx.x;
-    if (c >= nch || threadIdx.x != 0) return;
-    HxChunk d = ch[c];
+// first position p in [from, limit) whose 17 bases hold no N, or ~0 (reads bytes up to limit + 15)
+__device__ inline u64 hx_find_clean(HxBytes &b, u64 from, u64 limit) {
+    u32 run = 0;
+    for (u64 q = from; q < limit + HX_SPAN - 1; q++) {
+        if (b.get(q) == 4) run = 0; else run++;
+        if (run >= HX_SPAN) return q - (HX_SPAN - 1);
+    }
+    return ~0ULL;
+}
+// per piece, bounded scans: first N among the bases that enter the piece's windows ([u + 16, v + 16)), first clean window in [u, v);
+// the last piece of a sequence also looks behind the last window (positions v .. len: the padding is clean)
+__global__ void __launch_bounds__(64) k_hx_pre(const u8 *g, const HxPiece *pc, u32 npc, u64 *firstN, u64 *firstClean, u64 *tailClean) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npc) return;
+    HxPiece d = pc[i];
+    HxBytes b; b.base = g + d.seq_off; b.cur = ~0ULL; b.word = 0;
+    u64 hit = ~0ULL;
+    for (u64 p = d.u + 16; p < d.v + 16; p++) if (b.get(p) == 4) { hit = p; break; }
+    firstN[i] = hit;
+    firstClean[i] = hx_find_clean(b, d.u, d.v);
+    tailClean[i] = d.v + HX_SPAN - 1 >= d.slen ? hx_find_clean(b, d.v, d.slen + 1) : ~0ULL;
+}
+__global__ void __launch_bounds__(64) k_hx_piece(const u8 *g, const HxPiece *pc, u32 npc, u32 *fileX, u64 *body, HxPieceOut *po) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npc) return;
+    HxPiece d = pc[i];
     HxBytes bi; bi.base = g + d.seq_off; bi.cur = ~0ULL; bi.word = 0;      // bytes entering the window
     HxBytes bl = bi;                                                           // bytes leaving it
     HxShape sh;
-    u64 start = d.start, chunk = d.chunk;
-    hx_hash_init(sh, bi, start);
-    u32 preX = 0xffffffffu;                                                    // (~0: never equal to an 18-bit X)
-    u64 n = 0;
+    const u64 start = d.start, chunk = d.chunk, v = d.v;
+    const u64 bound = chunk - HX_SPAN + 1 + start;                              // jumps beyond it end the chunk (:771-774)
+    const u64 k_end = chunk - (chunk + start) % HX_STEP + HX_STEP + start;
+    u64 k = start;
+    bool go = true;
+    if (d.first) hx_hash_init(sh, bi, d.kinit);                                // = hashInit(start): kinit is the first clean window at or behind start
+    else {
+        u64 km = d.u - 1;
+        bool clean = true;
+        int W = 0;
+        for (int q = 0; q < HX_SPAN; q++) { u32 c = bi.get(km + q); if (c == 4) clean = false; W += (int)c; }
+        if (clean) {                                                            // the walk hashes u - 1: its state there, from the bases
+            sh.h = 0; sh.crh = 0;
+            for (int q = 0; q < HX_SPAN; q++) { u64 c = bi.get(km + q); sh.h = (sh.h << 2) + c; sh.crh |= (3ULL - c) << (2 * q); }
+            int C = -3 * HX_SPAN;
+            if (d.kinit != start && km < d.kt0) {                               // still under the chunk's first hashInit, which skipped Ns: C = -51 + 2 a - 2 b
+                int a_ = 0, b_ = 0;
+                for (int q = 0; q < HX_SPAN - 1; q++) { a_ += (int)bl.get(d.kinit + q); b_ += (int)bl.get(start + q); }
+                C += 2 * a_ - 2 * b_;
+            }
+            sh.x = C + 2 * W;
+            sh.left = (int)bi.get(km);
+            k = d.u;
+        } else {                                                                // the walk is jumping over an N cluster here: it lands on the first clean window
+            u64 kc = hx_find_clean(bi, d.u, v);
+            if (kc == ~0ULL || kc > bound) go = false;                          // (a landing beyond the bound belongs to the piece that held the trigger)
+            else { hx_hash_init(sh, bi, kc); k = kc; }
+        }
+    }
+    u32 preX = 0xffffffffu, firstX = 0, n = 0, hashed = 0;
+    bool have_first = d.first != 0;                                             // the chunk's first sample is always kept (preX = ~0)
     u32 *fx = fileX + d.out_base; u64 *bd = body + d.out_base;
-    for (u64 k = start; k < start + chunk; k++) {
+    if (go) for (; k < v; k++) {
+        bool last = false;
         if (bi.get(k + HX_SPAN - 1) == 4) {
-            k += hx_hash_init(sh, bi, k);
-            if (k > chunk - HX_SPAN + 1 + start) k = chunk - (chunk + start) % HX_STEP + HX_STEP + start;
+            u64 kc = hx_find_clean(bi, k, v);
+            if (kc == ~0ULL) kc = d.nc;                                          // exact landing position behind this piece (host: suffix over the pieces)
+            if (kc > bound) { hx_hash_init(sh, bi, kc); k = k_end; last = true; }
+            else if (kc >= v) break;
+            else { hx_hash_init(sh, bi, kc); k = kc; }
         }
         hx_roll(sh, bi.get(k + HX_SPAN - 1), bl.get(k));
+        hashed = 1;
         if (k % HX_STEP == 0) {
             u32 X, strand; u64 Y;
             hx_xy(sh, X, Y, strand);
-            if (X != preX) {
+            if (!have_first || X != preX) {
                 u64 w = (((Y << 41) | HS_TYPEFLAG) + ((u64)d.seq_id << 30) + k);
                 if (strand) w |= HS_CODEFLAG;
                 fx[n] = X; bd[n] = w; n++;
-                preX = X;
             }
+            if (!have_first) { firstX = X; have_first = true; }
+            preX = X;
         }
+        if (last) break;
     }
-    if (n) { u32 X, strand; u64 Y; hx_xy(sh, X, Y, strand); fx[n - 1] = X; }   // the chunk's last block is filed under the X of its last hashed position (:801)
-    cnt[c] = (u32)n;
+    HxPieceOut o; o.cnt = n; o.firstX = firstX; o.lastX = preX; o.hashed = hashed; o.pad = 0; o.endX = 0;
+    if (hashed) { u32 X, strand; u64 Y; hx_xy(sh, X, Y, strand); o.endX = X; }
+    po[i] = o;
 }
-__global__ void __launch_bounds__(256) k_hx_compact(const HxChunk *ch, const u32 *cnt, const u64 *dst_off, u32 nch, const u32 *fileX, const u64 *body, u32 *Xs, u64 *bodies) {
-    u32 c = blockIdx.y;
-    if (c >= nch) return;
-    u64 n = cnt[c], so = ch[c].out_base, dof = dst_off[c];
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) { Xs[dof + i] = fileX[so + i]; bodies[dof + i] = body[so + i]; }
+// staging -> dense arrays; src_skip drops the piece's first sample (its X equals the sample before it), patchX files the chunk's last block
+struct HxCopy { u64 src, dst; u32 n; u32 patch; u32 patchX; u32 pad; };
+__global__ void __launch_bounds__(256) k_hx_compact(const HxCopy *cp, u32 npc, const u32 *fileX, const u64 *body, u32 *Xs, u64 *bodies) {
+    u32 c = blockIdx.x;
+    if (c >= npc) return;
+    HxCopy d = cp[c];
+    for (u32 i = threadIdx.x; i < d.n; i += blockDim.x) {
+        u32 x = fileX[d.src + i];
+        if (d.patch && i == d.n - 1) x = d.patchX;
+        Xs[d.dst + i] = x; bodies[d.dst + i] = body[d.src + i];
+    }
 }
 // after the two sorts (bodies descending, then stable by X): run starts and per-X counts
 __global__ void __launch_bounds__(256) k_hx_flags(const u32 *Xs, u64 n, i32 *flag, u32 *cntX) {
