@@ -149,6 +149,10 @@ struct lnr_ctx {
     // lane's seed / tail launches), s_bulk the single-wave kernel of the same launch.
     hipStream_t s_multi[2] = {nullptr, nullptr}, s_bulk[2] = {nullptr, nullptr}, s_tail = nullptr;   // s_tail: early tail B of the reads that skip the re-map round
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr}, ev_start = nullptr, ev_lane[2] = {nullptr, nullptr}, ev_prep = nullptr, ev_f1 = nullptr;
+    u32 cap_scale = 1;      // per-read capacities (cords, gaps) x this: raised for the re-run of a batch in which a read overflowed
+    u32 cap_shrink = 1;     // diagnostic (LNR_CAP_SHRINK): capacities / this, to exercise that re-run
+    u32 overflow_reruns = 0;
+    u32 seed_lds_pad = 0;   // diagnostic (LNR_SEED_LDS_PAD): dynamic LDS the seed kernel does not use, to lower its waves per CU
     DevBuf hx_nkeys, hx_nvals; u32 hx_nnodes = 0; u64 hx_empty_dir = 0;   // HIndex (-i 2): dir = hdir[2^18] (head of the block of X, -1: none), hs = ysa, nodes of the large blocks
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl, ov;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines, ov = their aligned overflow lines (k_ix_lines)
     // ---- batch inputs / per-read arrays
@@ -559,7 +563,7 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
             hipLaunchKernelGGL(k_seed_hindex, dim3(nj), dim3(64), 0, st, J, R, ctx->hs.as<u64>(), ctx->info.hs_len, ctx->hx_empty_dir, ctx->dir.as<i32>(), ctx->hx_nkeys.as<u64>(), ctx->hx_nvals.as<u32>(), ctx->hx_nnodes, nj, O,
                                S.est_x16);
         else
-        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), 0, st, J, R, ctx->bl.as<ulonglong2>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->ov.as<u64>(), nj, O, S.est_x16);
+        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), ctx->seed_lds_pad, st, J, R, ctx->bl.as<ulonglong2>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->ov.as<u64>(), nj, O, S.est_x16);
         KCHECK();
         S.t_seed.stop(st);
         if (f1_reads && attempt == 0) { lnr_status fs = launch_f1(ctx, f1_reads); if (fs != LNR_OK) return fs; }   // (beside the seed kernel instead: measured no faster)
@@ -824,9 +828,9 @@ lnr_status prepare_batch(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 
         B.pk_off[i] = po; po += 2 * packed_words(L);   // forward + reverse-complement strand
         B.nf[i] = L > 200 ? read_feature_count(L) : 0;
         B.f1_off[i] = fo; fo += 2ULL * B.nf[i];
-        B.cords_cap[i] = L > 200 ? (u32)(16 * (L / 64) + 256) : 0;
+        B.cords_cap[i] = L > 200 ? (u32)std::min<u64>(std::max<u64>((16 * (L / 64) + 256) / ctx->cap_shrink, 8) * ctx->cap_scale, 1u << 24) : 0;
         B.cords_off[i] = co; co += B.cords_cap[i];
-        B.gaps_cap[i] = L > 200 ? (u32)(L / 1000 + 4) : 0;
+        B.gaps_cap[i] = L > 200 ? (u32)((L / 1000 + 4) * ctx->cap_scale) : 0;
         B.gaps_off[i] = go; go += B.gaps_cap[i];
     }
     lnr_status s;
@@ -978,7 +982,7 @@ lnr_status remap_round(lnr_ctx *ctx, const BatchHost &B, const std::vector<u32> 
     return s;
 }
 
-lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, lnr_cords_dev *out, const u64 *h_off = nullptr) {
+lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, lnr_cords_dev *out, const u64 *h_off = nullptr, int attempt = 0) {
     if (!ctx->has_index) { ctx->err = "no index: call lnr_index_build or lnr_index_adopt first"; return LNR_ERR_NO_INDEX; }
     reset_stats(ctx);
     ctx->last_n = n; ctx->last_ncords = 0;
@@ -1087,8 +1091,19 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     ctx->stats.tail_ms += ctx->t_tail.ms();
     for (u32 i = 0; i < n; i++)
         if (rerr[i]) {
+            // A read outgrew a per-read capacity (cords: 16 per 64 bases + 256; gaps: one per 1000 bases + 4 -- heuristics, generous by an
+            // order of magnitude).  Nothing of the batch is handed out; the batch is run again with 4x, then 16x the capacities.
+            if (attempt < 2) {
+                ctx->t_total.stop(ctx->stream);
+                HIPCK(hipStreamSynchronize(ctx->stream));
+                ctx->cap_scale = attempt == 0 ? 4 : 16;
+                ctx->overflow_reruns++;
+                lnr_status rs = filter_dev(ctx, d_reads, d_off, n, out, h_off, attempt + 1);
+                ctx->cap_scale = 1;
+                return rs;
+            }
             char b[160];
-            snprintf(b, sizeof b, "device capacity overflow on read %u (stage code %d, length %u)", i, rerr[i], B.len[i]);
+            snprintf(b, sizeof b, "device capacity overflow on read %u (stage code %d, length %u) with 16x capacities", i, rerr[i], B.len[i]);
             ctx->err = b;
             return LNR_ERR_INTERNAL;
         }
@@ -1280,6 +1295,8 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     ctx->opts = o;
     ctx->device = dev;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
+    if (const char *e = getenv("LNR_CAP_SHRINK")) { long v = atol(e); if (v >= 1 && v <= 4096) ctx->cap_shrink = (u32)v; }
+    if (const char *e = getenv("LNR_SEED_LDS_PAD")) { long v = atol(e); if (v >= 0 && v <= 100000) ctx->seed_lds_pad = (u32)v; }
     if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_JOB_STAGE_KB")) { long kb = atol(e); if (kb >= 0 && kb <= 60) ctx->job_stage_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_HEAVY_CAP")) { long v = atol(e); if (v >= 64) { ctx->heavy_cap = (u32)std::min<long>(v, 0xffffffffL); ctx->heavy_cap_r1 = ctx->heavy_cap; } }

@@ -440,3 +440,26 @@ def test_gpu_hindex_matches_oracle_fresh_seed(oracle_lib):
         if flt is not f:
             flt.close()
     f.close()
+
+
+def test_gpu_batch_rerun_on_per_read_overflow(case_inputs, monkeypatch):
+    """A read that outgrows its cord capacity does not cost the batch: the batch is run again with 4x, then 16x the
+    per-read capacities.  LNR_CAP_SHRINK makes the first attempt(s) overflow; the result must still be the reference's, and with
+    capacities that stay too small the call fails loudly instead of returning short lists."""
+    from linear_amd import Filter
+    from linear_amd.api import LnrError
+    refs, reads, off = case_inputs("ont")
+    g = np.load(os.path.join(GOLD, "ont_T1.npz"))
+    monkeypatch.setenv("LNR_CAP_SHRINK", "64")
+    f = Filter(device=0)
+    f.build_index(refs, 1)
+    coff, cs, ce = f.filter_batch(reads, off)
+    assert np.array_equal(coff, g["cord_off"]) and np.array_equal(cs, g["cords_str"]) and np.array_equal(ce, g["cords_end"])
+    f.close()
+    monkeypatch.setenv("LNR_CAP_SHRINK", "4096")
+    f = Filter(device=0)
+    f.build_index(refs, 1)
+    with pytest.raises(LnrError) as e:
+        f.filter_batch(reads, off)
+    assert e.value.status == -8 and "overflow" in str(e.value)
+    f.close()
