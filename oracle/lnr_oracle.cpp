@@ -1566,6 +1566,8 @@ static void apxMap(const Ctx &cx, Work &c, const uint8_t *read, u64 read_len) { 
     }
 }
 
+#include "lnr_gap.inc"
+
 }  // namespace orc
 
 // ================================================================= C API ====
@@ -1675,6 +1677,54 @@ void orc_lookup_hist(void *h, const uint8_t *read, uint64_t len, uint64_t *hist4
     }
 }
 // apx_gaps of the last orc_map_read (apxMap's output for the gap re-mapper, pmpfinder.cpp:2744): pairs of cord words
+
+// ---- unit hooks of the gap path restatement (lnr_gap.inc), mirrored by ref_gap_* in ref_harness.cpp
+static uint64_t out_u64(const std::vector<u64> &v, uint64_t *out, uint64_t cap) { for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i]; return v.size(); }
+static std::vector<uint8_t> padded(const uint8_t *p, uint64_t n) { std::vector<uint8_t> s(n + SEQ_PAD, 0); memcpy(s.data(), p, n); return s; }
+uint64_t orc_gap_anchors(const uint8_t *g, uint64_t glen, const uint8_t *r, uint64_t rlen, uint64_t gap_str, uint64_t gap_end, int shape_len, int step1, int step2, int direction,
+                         int64_t anchor_lower, int64_t anchor_upper, uint64_t rvcp_const, uint64_t *out, uint64_t cap) {
+    auto a = padded(g, glen), b = padded(r, rlen);
+    Seq s1{a.data(), glen}, s2{b.data(), rlen};
+    GapParms gp; std::vector<u64> g_hs, anc;
+    g_stream_(s1, s2, g_hs, gap_str, gap_end, (unsigned)shape_len, step1, step2);
+    g_create_anchors_(g_hs, anc, shape_len, direction, anchor_lower, anchor_upper, rvcp_const, gap_str, gap_end, gp);
+    return out_u64(anc, out, cap);
+}
+uint64_t orc_gap_anchor_pair(const uint8_t *g, uint64_t glen, const uint8_t *r, uint64_t rlen, uint64_t gs, uint64_t ge, int shape_len, int step1, int step2, uint64_t rvcp_const,
+                             uint64_t gap_str1, uint64_t gap_end1, uint64_t gap_str2, uint64_t gap_end2, uint64_t *out1, uint64_t *n1, uint64_t *out2, uint64_t cap) {
+    auto a = padded(g, glen), b = padded(r, rlen);
+    Seq s1{a.data(), glen}, s2{b.data(), rlen};
+    GapParms gp; std::vector<u64> g_hs, a1, a2;
+    g_stream_(s1, s2, g_hs, gs, ge, (unsigned)shape_len, step1, step2);
+    g_CreateExtendAnchorsPair_(g_hs, a1, a2, shape_len, rvcp_const, gap_str1, gap_end1, gap_str2, gap_end2, gp);
+    *n1 = out_u64(a1, out1, cap);
+    return out_u64(a2, out2, cap);
+}
+uint64_t orc_gap_canchors(const uint8_t *g, uint64_t glen, const uint8_t *r, uint64_t rlen, uint64_t s1s, uint64_t s1e, uint64_t s2s, uint64_t s2e, int step1, int step2, int shape_len,
+                          int64_t anchor_lower, int64_t anchor_upper, uint64_t *out, uint64_t cap) {
+    auto a = padded(g, glen), b = padded(r, rlen);
+    Seq s1{a.data(), glen}, s2{b.data(), rlen};
+    std::vector<u64> g_hs, anc;
+    c_stream_(s1, g_hs, s1s, s1e, step1, shape_len, 0);
+    c_stream_(s2, g_hs, s2s, s2e, step2, shape_len, 1);
+    c_createAnchors2(g_hs, anc, (int)g_hs.size(), anchor_lower, anchor_upper);
+    return out_u64(anc, out, cap);
+}
+int orc_gap_score(int which, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t read_len, int strand) {
+    switch (which) {
+        case 1: return getGapAnchorsChainScore(a, b);
+        case 2: return getGapAnchorsChainScore2(a, b);
+        case 3: return getGapBlocksChainScore2(a, b, c, d, read_len, strand);
+        default: return getGapBlocksChainScore3(a, b, c, d, read_len, strand);
+    }
+}
+uint64_t orc_gap_xdrop(uint64_t *chain, uint64_t n, int direction, int f_erase, int *ret) {
+    std::vector<u64> c(chain, chain + n);
+    GapParms gp;
+    *ret = dropChainGapX(c, ganc_x, ganc_y, direction, f_erase != 0, gp);
+    for (size_t i = 0; i < c.size(); i++) chain[i] = c[i];
+    return c.size();
+}
 uint64_t orc_get_gaps(void *h, uint64_t *out_pairs, uint64_t cap_pairs) {
     Work &w = ((Ctx *)h)->w;
     for (size_t i = 0; i < w.apx_gaps.size() && i < cap_pairs; i++) { out_pairs[2 * i] = w.apx_gaps[i].first; out_pairs[2 * i + 1] = w.apx_gaps[i].second; }

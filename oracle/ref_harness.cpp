@@ -33,6 +33,17 @@ int chainAnchorsHits(String<uint64_t> &anchors, String<uint64_t> &hits, String<i
 
 unsigned getHIndexMatchAll(LIndex &index, String<Dna5> &read, String<uint64_t> &set, uint64_t map_str, uint64_t map_end, PMPParms &pm_pmp);   // pmpfinder.cpp:1918
 
+// external-linkage functions of gap_util.cpp that have no header declaration (unit hooks for the gap path restatement)
+int g_stream_(String<Dna5> &seq1, String<Dna5> &seq2, String<uint64_t> &g_hs, uint64_t gap_str, uint64_t gap_end, unsigned shape_len, int step1, int step2, GapParms &gap_parms);
+int g_create_anchors_(String<uint64_t> &g_hs, String<uint64_t> &g_hs_anchor, int shape_len, int direction, int64_t anchor_lower, int64_t anchor_upper, uint64_t rvcp_const, uint64_t gap_str,
+                      uint64_t gap_end, GapParms &gap_parms);
+int g_CreateExtendAnchorsPair_(String<uint64_t> &g_hs, String<uint64_t> &g_hs_anchor1, String<uint64_t> &g_hs_anchor2, int shape_len, uint64_t rvcp_const, uint64_t gap_str1, uint64_t gap_end1,
+                               uint64_t gap_str2, uint64_t gap_end2, GapParms &gap_parms);
+int c_createAnchors2(String<uint64_t> &g_hs, String<uint64_t> &g_anchors, int g_hs_end, int64_t anchor_lower, int64_t anchor_upper);
+int dropChainGapX(String<uint64_t> &chains, uint64_t (*getX)(uint64_t), uint64_t (*getY)(uint64_t), int direction, bool f_erase, GapParms &gap_parms);
+uint64_t g_hs_anchor_getX(uint64_t val);
+uint64_t g_hs_anchor_getY(uint64_t val);
+
 namespace {
 const size_t PAD = 64;
 
@@ -159,6 +170,53 @@ uint64_t ref_map_read_g(void *h, const uint8_t *read, uint64_t len, uint32_t gap
     CordsParms cp;
     reformCords(c->cs, c->ce, &reformCordsDxDy1, cp);
     return length(c->cs);
+}
+
+// ---- unit hooks for the restatement of the gap path (oracle/lnr_gap.inc): single reference functions on raw arrays
+static uint64_t out_u64(String<uint64_t> &v, uint64_t *out, uint64_t cap) { uint64_t n = length(v); for (uint64_t i = 0; i < n && i < cap; i++) out[i] = v[i]; return n; }
+uint64_t ref_gap_anchors(const uint8_t *g, uint64_t glen, const uint8_t *r, uint64_t rlen, uint64_t gap_str, uint64_t gap_end, int shape_len, int step1, int step2, int direction,
+                         int64_t anchor_lower, int64_t anchor_upper, uint64_t rvcp_const, uint64_t *out, uint64_t cap) {
+    String<Dna5> s1, s2; assign_padded(s1, g, glen); assign_padded(s2, r, rlen);
+    GapParms gp(0.2);
+    String<uint64_t> g_hs, anc;
+    g_stream_(s1, s2, g_hs, gap_str, gap_end, (unsigned)shape_len, step1, step2, gp);
+    g_create_anchors_(g_hs, anc, shape_len, direction, anchor_lower, anchor_upper, rvcp_const, gap_str, gap_end, gp);
+    return out_u64(anc, out, cap);
+}
+uint64_t ref_gap_anchor_pair(const uint8_t *g, uint64_t glen, const uint8_t *r, uint64_t rlen, uint64_t gs, uint64_t ge, int shape_len, int step1, int step2, uint64_t rvcp_const,
+                             uint64_t gap_str1, uint64_t gap_end1, uint64_t gap_str2, uint64_t gap_end2, uint64_t *out1, uint64_t *n1, uint64_t *out2, uint64_t cap) {
+    String<Dna5> s1, s2; assign_padded(s1, g, glen); assign_padded(s2, r, rlen);
+    GapParms gp(0.2);
+    String<uint64_t> g_hs, a1, a2;
+    g_stream_(s1, s2, g_hs, gs, ge, (unsigned)shape_len, step1, step2, gp);
+    g_CreateExtendAnchorsPair_(g_hs, a1, a2, shape_len, rvcp_const, gap_str1, gap_end1, gap_str2, gap_end2, gp);
+    *n1 = out_u64(a1, out1, cap);
+    return out_u64(a2, out2, cap);
+}
+uint64_t ref_gap_canchors(const uint8_t *g, uint64_t glen, const uint8_t *r, uint64_t rlen, uint64_t s1s, uint64_t s1e, uint64_t s2s, uint64_t s2e, int step1, int step2, int shape_len,
+                          int64_t anchor_lower, int64_t anchor_upper, uint64_t *out, uint64_t cap) {
+    String<Dna5> s1, s2; assign_padded(s1, g, glen); assign_padded(s2, r, rlen);
+    String<uint64_t> g_hs, anc;
+    c_stream_(s1, g_hs, s1s, s1e, step1, shape_len, 0);
+    c_stream_(s2, g_hs, s2s, s2e, step2, shape_len, 1);
+    c_createAnchors2(g_hs, anc, (int)length(g_hs), anchor_lower, anchor_upper);
+    return out_u64(anc, out, cap);
+}
+int ref_gap_score(int which, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t read_len, int strand) {
+    ChainScoreParms p; p.chn_block_strand = strand;
+    switch (which) {
+        case 1: return getGapAnchorsChainScore(a, b, p);
+        case 2: return getGapAnchorsChainScore2(a, b, p);
+        case 3: return getGapBlocksChainScore2(a, b, c, d, read_len, p);
+        default: return getGapBlocksChainScore3(a, b, c, d, read_len, p);
+    }
+}
+uint64_t ref_gap_xdrop(uint64_t *chain, uint64_t n, int direction, int f_erase, int *ret) {
+    String<uint64_t> c; resize(c, n); for (uint64_t i = 0; i < n; i++) c[i] = chain[i];
+    GapParms gp(0.2);
+    *ret = dropChainGapX(c, &g_hs_anchor_getX, &g_hs_anchor_getY, direction, f_erase != 0, gp);
+    for (uint64_t i = 0; i < length(c); i++) chain[i] = c[i];
+    return length(c);
 }
 uint64_t ref_get_gaps(void *h, uint64_t *out_pairs, uint64_t cap_pairs) {   // apx_gaps of the last ref_map_read
     RefCtx *c = (RefCtx *)h;

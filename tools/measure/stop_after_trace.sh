@@ -15,6 +15,7 @@ idx = max(i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("lnr::k_p
 d = {}
 for r in rows[idx:]:
     n = r["Kernel_Name"].split("(")[0][5:]
+    if n.startswith("k_job_mid"): n = "k_job_mid"
     if n not in d: d[n] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 print("stop_after %2s: k_job %.2f ms  k_job_mid %.2f ms  seed %.2f" % (k, d.get("k_job", 0), d.get("k_job_mid", 0), d.get("k_seed_fused", 0)))
 PY
