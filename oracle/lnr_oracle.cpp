@@ -1178,7 +1178,7 @@ static void chainBlocksHits(std::vector<u64> &hits, std::vector<UPair> &sep, std
 }
 
 // ------------------------------------------------------------- windows ----
-static u64 previousWindow(const Feat &f1, const Feat &f2, u64 cord) {                // pmpfinder.cpp:883-945
+static u64 previousWindow(const Feat &f1, const Feat &f2, u64 cord, float *score = nullptr) {   // pmpfinder.cpp:883-945 (score form :838-880: adds the window's distance)
     u64 genomeId = get_cord_id(cord), strand = get_cord_strand(cord);
     u64 x_suf = get_cord_x(cord) >> 4, y_suf = get_cord_y(cord) >> 4;
     u64 x_min = 0, y, new_cord = 0;
@@ -1194,9 +1194,10 @@ static u64 previousWindow(const Feat &f1, const Feat &f2, u64 cord) {           
         new_cord = createCord(create_id_x(genomeId, (x_suf - P_med) << 4), (x_suf - x_min - P_med + y) << 4, strand);
     else
         new_cord = createCord(create_id_x(genomeId, x_min << 4), y << 4, strand);
+    if (score) *score += (float)min;
     return new_cord;
 }
-static u64 nextWindow(const Feat &f1, const Feat &f2, u64 cord) {                    // pmpfinder.cpp:1079-1150
+static u64 nextWindow(const Feat &f1, const Feat &f2, u64 cord, float *score = nullptr) {       // pmpfinder.cpp:1079-1150 (score form :995-1045)
     u64 genomeId = get_cord_id(cord), strand = get_cord_strand(cord);
     u64 x_pre = get_cord_x(cord) >> 4, y_pre = get_cord_y(cord) >> 4;
     u64 x_min = 0, y, new_cord = 0;
@@ -1213,6 +1214,7 @@ static u64 nextWindow(const Feat &f1, const Feat &f2, u64 cord) {               
         new_cord = createCord(create_id_x(genomeId, (x_pre + P_med) << 4), (x_pre + P_med - x_min + y) << 4, strand);
     else
         new_cord = createCord(create_id_x(genomeId, x_min << 4), y << 4, strand);
+    if (score) *score += (float)min;
     return new_cord;
 }
 static int extendWindow(const Feat &f1, const Feat &f2, std::vector<u64> &cords, u64 cordy_str, u64 cordy_end) { // pmpfinder.cpp:1152-1178
@@ -1709,6 +1711,15 @@ uint64_t orc_gap_canchors(const uint8_t *g, uint64_t glen, const uint8_t *r, uin
     c_stream_(s2, g_hs, s2s, s2e, step2, shape_len, 1);
     c_createAnchors2(g_hs, anc, (int)g_hs.size(), anchor_lower, anchor_upper);
     return out_u64(anc, out, cap);
+}
+
+static void gp_alt(GapParms &gp, int alt) { if (alt) { gp.chn1_min_len = 1; gp.chn1_abort = 0; gp.chn1_fn = 2; gp.chn2_abort = 0; gp.chn2_fn = 3; } }
+uint64_t orc_gap_chains(const uint64_t *anchors, uint64_t n, uint64_t read_len, int alt, int direction, uint64_t gap_str, uint64_t gap_end, int closest, uint64_t *out, uint64_t cap, int *pr) {
+    std::vector<u64> a(anchors, anchors + n), tiles;
+    GapParms gp; gp_alt(gp, alt); gp.direction = direction;
+    g_CreateChainsFromAnchors_(a, tiles, read_len, gp);
+    if (closest) { std::pair<int, int> r = getClosestExtensionChain_(tiles, gap_str, gap_end, closest == 2, gp); pr[0] = r.first; pr[1] = r.second; }
+    return out_u64(tiles, out, cap);
 }
 int orc_gap_score(int which, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t read_len, int strand) {
     switch (which) {

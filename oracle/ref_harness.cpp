@@ -43,6 +43,8 @@ int c_createAnchors2(String<uint64_t> &g_hs, String<uint64_t> &g_anchors, int g_
 int dropChainGapX(String<uint64_t> &chains, uint64_t (*getX)(uint64_t), uint64_t (*getY)(uint64_t), int direction, bool f_erase, GapParms &gap_parms);
 uint64_t g_hs_anchor_getX(uint64_t val);
 uint64_t g_hs_anchor_getY(uint64_t val);
+int g_CreateChainsFromAnchors_(String<uint64_t> &anchors, String<uint64_t> &tiles, uint64_t &gap_str, uint64_t &gap_end, uint64_t read_len, GapParms &gap_parms);
+std::pair<int, int> getClosestExtensionChain_(String<uint64_t> &tmp_tiles, uint64_t gap_str, uint64_t gap_end, bool f_erase_tiles, GapParms &gap_parms);
 
 namespace {
 const size_t PAD = 64;
@@ -201,6 +203,20 @@ uint64_t ref_gap_canchors(const uint8_t *g, uint64_t glen, const uint8_t *r, uin
     c_stream_(s2, g_hs, s2s, s2e, step2, shape_len, 1);
     c_createAnchors2(g_hs, anc, (int)length(g_hs), anchor_lower, anchor_upper);
     return out_u64(anc, out, cap);
+}
+
+// alt != 0: the chain metrics as mapGap_ sets them for its indel branch (gap.cpp:123-130)
+static void gp_alt(GapParms &gp, int alt) {
+    if (!alt) return;
+    gp.chn_score1.thd_min_chain_len = 1; gp.chn_score1.thd_abort_score = 0; gp.chn_score1.getScore = &getGapAnchorsChainScore2;
+    gp.chn_score2.thd_abort_score = 0; gp.chn_score2.getScore2 = &getGapBlocksChainScore3;
+}
+uint64_t ref_gap_chains(const uint64_t *anchors, uint64_t n, uint64_t read_len, int alt, int direction, uint64_t gap_str, uint64_t gap_end, int closest, uint64_t *out, uint64_t cap, int *pr) {
+    String<uint64_t> a, tiles; resize(a, n); for (uint64_t i = 0; i < n; i++) a[i] = anchors[i];
+    GapParms gp(0.2); gp_alt(gp, alt); gp.direction = direction;
+    g_CreateChainsFromAnchors_(a, tiles, gap_str, gap_end, read_len, gp);
+    if (closest) { std::pair<int, int> r = getClosestExtensionChain_(tiles, gap_str, gap_end, closest == 2, gp); pr[0] = r.first; pr[1] = r.second; }
+    return out_u64(tiles, out, cap);
 }
 int ref_gap_score(int which, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t read_len, int strand) {
     ChainScoreParms p; p.chn_block_strand = strand;

@@ -118,3 +118,38 @@ def test_gap_chain_scores_and_xdrop_match_reference():
                 ra, rb = C.c_int(), C.c_int()
                 na = o.orc_gap_xdrop(p(a, u64p), n, direction, er, C.byref(ra)); nb = r.ref_gap_xdrop(p(b, u64p), n, direction, er, C.byref(rb))
                 assert na == nb and ra.value == rb.value and np.array_equal(a[:na], b[:nb])
+
+
+def test_gap_chains_from_anchors_match_reference():
+    """anchors -> chains (chainAnchorsBase with the gap scores) -> tiles -> block chaining of the tiles (chainTiles), with both sets
+    of chain metrics, and the choice of the chain that continues the gap's end (getClosestExtensionChain_)."""
+    o, r = libs()
+    for lib, pfx in ((o, "orc_"), (r, "ref_")):
+        f = getattr(lib, pfx + "gap_chains")
+        f.restype = C.c_uint64
+        f.argtypes = [u64p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, u64p, C.c_uint64, C.POINTER(C.c_int)]
+    cap = 1 << 20
+    n_nonempty = 0
+    for seed in range(16):
+        g, rd, x0 = make_pair(300 + seed, err=0.05 + 0.01 * (seed % 8))
+        if seed % 4 == 1:   # a duplicated stretch: two chains compete
+            g = np.ascontiguousarray(np.concatenate([g[:3000], g[2200:3000], g[3000:]]))
+        rng = np.random.default_rng(seed)
+        xs, ys = x0 + 50, 50
+        xe, ye = min(xs + 2500, g.size - 1), min(ys + 2500, rd.size - 1)
+        gs, ge = cord(0, xs, ys), cord(0, xe, ye)
+        for shape_len, s1, s2, direction in ((9, 5, 1, 0), (5, 3, 1, 1), (9, 5, 1, -1)):
+            a = np.zeros(cap, np.uint64)
+            lo, hi = xs - ys - 200, xs - ys + 200
+            na = o.orc_gap_anchors(p(g, u8p), g.size, p(rd, u8p), rd.size, gs, ge, shape_len, s1, s2, direction, lo, hi, rd.size - 1, p(a, u64p), cap)
+            anc = np.ascontiguousarray(a[:na])
+            for alt in (0, 1):
+                for closest in (0, 1, 2):
+                    ta, tb = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+                    pa, pb = (C.c_int * 2)(), (C.c_int * 2)()
+                    d = direction if direction else 1
+                    n1 = o.orc_gap_chains(p(anc, u64p), na, rd.size, alt, d, gs, ge, closest, p(ta, u64p), cap, pa)
+                    n2 = r.ref_gap_chains(p(anc, u64p), na, rd.size, alt, d, gs, ge, closest, p(tb, u64p), cap, pb)
+                    assert n1 == n2 and np.array_equal(ta[:n1], tb[:n2]) and (not closest or (pa[0], pa[1]) == (pb[0], pb[1])), (seed, shape_len, direction, alt, closest, n1, n2)
+                    n_nonempty += n1 > 0
+    assert n_nonempty > 50
