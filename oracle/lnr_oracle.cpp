@@ -1721,6 +1721,31 @@ uint64_t orc_gap_chains(const uint64_t *anchors, uint64_t n, uint64_t read_len, 
     if (closest) { std::pair<int, int> r = getClosestExtensionChain_(tiles, gap_str, gap_end, closest == 2, gp); pr[0] = r.first; pr[1] = r.second; }
     return out_u64(tiles, out, cap);
 }
+
+uint64_t orc_gap_map(void *h, const uint8_t *read, uint64_t len, int which, uint64_t gs1, uint64_t ge1, uint64_t gs2, uint64_t ge2, int direction, int alt, uint64_t *out_str, uint64_t *out_end,
+                     uint64_t *n2, uint64_t cap) {
+    Ctx *c = (Ctx *)h;
+    auto rd = padded(read, len);
+    std::vector<uint8_t> com(len + SEQ_PAD, 0);
+    static const uint8_t cpl[5] = {3, 2, 1, 0, 4};
+    for (u64 k = 0; k < len; k++) com[k] = cpl[rd[len - k - 1]];
+    Feat f1[2];
+    createFeatures2_48(rd.data(), (i64)len, f1[0]);
+    createFeatures2_48(com.data(), (i64)len, f1[1]);
+    GapFeat F{f1, &c->f2};
+    u64 id = get_cord_id(gs1);
+    GapSeqs Q{Seq{c->seqs[id].data(), c->lens[id]}, Seq{rd.data(), len}, Seq{com.data(), len}};
+    GapParms gp; gp_alt(gp, alt); gp.read_len = len; gp.ref_len = c->lens[id];
+    std::vector<u64> ts1, te1, ts2, te2;
+    if (which == 1) mapGeneric(Q, F, ts1, te1, gs1, ge1, gp);
+    else if (which == 2) mapExtend(Q, F, ts1, te1, gs1, ge1, direction, gp);
+    else mapExtends(Q, F, ts1, te1, ts2, te2, gs1, ge1, gs2, ge2, gp);
+    u64 n1 = ts1.size();
+    for (u64 i = 0; i < n1 && i < cap; i++) { out_str[i] = ts1[i]; out_end[i] = i < te1.size() ? te1[i] : 0; }
+    *n2 = ts2.size();
+    for (u64 i = 0; i < ts2.size() && n1 + i < cap; i++) { out_str[n1 + i] = ts2[i]; out_end[n1 + i] = i < te2.size() ? te2[i] : 0; }
+    return n1 | ((u64)te1.size() << 32);
+}
 int orc_gap_score(int which, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t read_len, int strand) {
     switch (which) {
         case 1: return getGapAnchorsChainScore(a, b);

@@ -218,6 +218,28 @@ uint64_t ref_gap_chains(const uint64_t *anchors, uint64_t n, uint64_t read_len, 
     if (closest) { std::pair<int, int> r = getClosestExtensionChain_(tiles, gap_str, gap_end, closest == 2, gp); pr[0] = r.first; pr[1] = r.second; }
     return out_u64(tiles, out, cap);
 }
+
+// mapGeneric (which 1), mapExtend (2, direction), mapExtends (3) of one read against the context's genome; tiles_str then tiles_end
+uint64_t ref_gap_map(void *h, const uint8_t *read, uint64_t len, int which, uint64_t gs1, uint64_t ge1, uint64_t gs2, uint64_t ge2, int direction, int alt, uint64_t *out_str, uint64_t *out_end,
+                     uint64_t *n2, uint64_t cap) {
+    RefCtx *c = (RefCtx *)h;
+    String<Dna5> r; assign_padded(r, read, len);
+    _compltRvseStr(r, c->com);
+    { uint64_t n = length(c->com); resize(c->com, n + PAD, Dna5(0)); resize(c->com, n); }
+    createFeatures(begin(r), end(r), c->f1[0]);
+    createFeatures(begin(c->com), end(c->com), c->f1[1]);
+    GapParms gp(0.2); gp_alt(gp, alt);
+    gp.read_len = len; gp.ref_len = length(c->g[get_cord_id(gs1)]);
+    String<uint64_t> ts1, te1, ts2, te2;
+    if (which == 1) mapGeneric(c->g, r, c->com, c->f1, c->f2, ts1, te1, gs1, ge1, gp);
+    else if (which == 2) mapExtend(c->g, r, c->com, c->f1, c->f2, ts1, te1, gs1, ge1, direction, gp);
+    else mapExtends(c->g, r, c->com, c->f1, c->f2, ts1, te1, ts2, te2, gs1, ge1, gs2, ge2, 0, gp);
+    uint64_t n1 = length(ts1);
+    for (uint64_t i = 0; i < n1 && i < cap; i++) { out_str[i] = ts1[i]; out_end[i] = i < length(te1) ? te1[i] : 0; }
+    *n2 = length(ts2);
+    for (uint64_t i = 0; i < length(ts2) && n1 + i < cap; i++) { out_str[n1 + i] = ts2[i]; out_end[n1 + i] = i < length(te2) ? te2[i] : 0; }
+    return n1 | ((uint64_t)length(te1) << 32);
+}
 int ref_gap_score(int which, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t read_len, int strand) {
     ChainScoreParms p; p.chn_block_strand = strand;
     switch (which) {

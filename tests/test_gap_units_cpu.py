@@ -153,3 +153,47 @@ def test_gap_chains_from_anchors_match_reference():
                     assert n1 == n2 and np.array_equal(ta[:n1], tb[:n2]) and (not closest or (pa[0], pa[1]) == (pb[0], pb[1])), (seed, shape_len, direction, alt, closest, n1, n2)
                     n_nonempty += n1 > 0
     assert n_nonempty > 50
+
+
+def test_gap_map_generic_and_extend_match_reference():
+    """mapGeneric / mapExtend / mapExtends (k-mer join, chaining, re-extension with the small pattern, clipping, tiles along the chains
+    with the window features, reform_tiles) of reads with planted insertions and deletions, against the reference."""
+    from oracle import pyorc
+    o, r = libs()
+    for lib, pfx in ((o, "orc_"), (r, "ref_")):
+        f = getattr(lib, pfx + "gap_map")
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, u64p, u64p, u64p, C.c_uint64]
+    rng = np.random.default_rng(11)
+    g = synth.random_ref(60000, 77)
+    co, cr = pyorc.Checker("oracle", [g], 1), pyorc.Checker("ref", [g], 1)
+    cap = 4096
+    nontrivial = 0
+    for k in range(40):
+        x0 = int(rng.integers(1000, 40000))
+        L = 6000
+        seg = g[x0:x0 + L + 600].copy()
+        kind = k % 4
+        cut = int(rng.integers(2000, 3500))
+        if kind == 1:   # deletion in the read
+            seg = np.concatenate([seg[:cut], seg[cut + int(rng.integers(150, 500)):]])
+        elif kind == 2:  # insertion in the read
+            seg = np.concatenate([seg[:cut], rng.integers(0, 4, int(rng.integers(150, 500)), dtype=np.uint8), seg[cut:]])
+        elif kind == 3:  # tandem duplication
+            d = int(rng.integers(150, 400)); seg = np.concatenate([seg[:cut], seg[cut - d:cut], seg[cut:]])
+        reads, off, _ = synth.sample_reads([seg], 1, L, 0.06, 500 + k, "none")
+        rd = np.ascontiguousarray(reads[: int(off[1])])
+        ys, ye = cut - int(rng.integers(300, 900)), min(cut + int(rng.integers(600, 1400)), rd.size - 200)
+        xs, xe = x0 + ys, x0 + ye + int(rng.integers(-200, 200))
+        gs, ge = cord(0, xs, ys), cord(0, xe, ye)
+        cases_ = [(1, gs, ge, 0, 0, 0, 0), (1, gs, ge, 0, 0, 0, 1), (2, gs, cord(0, xs + 1500, ys + 1500), 0, 0, 1, 0), (2, cord(0, xe - 1500, ye - 1500), ge, 0, 0, -1, 0),
+                  (3, gs, cord(0, xs + 1200, ys + 1200), cord(0, xe - 1200, ye - 1200), ge, 0, 1)]
+        for which, a, b, c2, d2, direction, alt in cases_:
+            sa, ea, sb, eb = (np.zeros(cap, np.uint64) for _ in range(4))
+            na2, nb2 = C.c_uint64(), C.c_uint64()
+            na = o.orc_gap_map(co.h, p(rd, u8p), rd.size, which, a, b, c2, d2, direction, alt, p(sa, u64p), p(ea, u64p), C.byref(na2), cap)
+            nb = r.ref_gap_map(cr.h, p(rd, u8p), rd.size, which, a, b, c2, d2, direction, alt, p(sb, u64p), p(eb, u64p), C.byref(nb2), cap)
+            tot = (na & 0xffffffff) + na2.value
+            assert na == nb and na2.value == nb2.value and np.array_equal(sa[:tot], sb[:tot]) and np.array_equal(ea[:tot], eb[:tot]), (k, kind, which, direction, alt, na, nb)
+            nontrivial += tot > 3
+    assert nontrivial > 60
