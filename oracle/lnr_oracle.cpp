@@ -1746,6 +1746,28 @@ uint64_t orc_gap_map(void *h, const uint8_t *read, uint64_t len, int which, uint
     for (u64 i = 0; i < ts2.size() && n1 + i < cap; i++) { out_str[n1 + i] = ts2[i]; out_end[n1 + i] = i < te2.size() ? te2[i] : 0; }
     return n1 | ((u64)te1.size() << 32);
 }
+
+// apxMap + mapGaps + reformCords as Mapper::p_calRecords runs them for -g gap_len [-dup] (mapper.cpp:207-231,438-453)
+uint64_t orc_map_read_g(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup) {
+    Ctx *c = (Ctx *)h;
+    auto rd = padded(read, len);
+    apxMap(*c, c->w, rd.data(), len);
+    if (len <= 200 || gap_len == 0) return c->w.cords_str.size();
+    std::vector<uint8_t> com(len + SEQ_PAD, 0);
+    static const uint8_t cpl[5] = {3, 2, 1, 0, 4};
+    for (u64 k = 0; k < len; k++) com[k] = cpl[rd[len - k - 1]];
+    Feat f1[2];
+    createFeatures2_48(rd.data(), (i64)len, f1[0]);
+    createFeatures2_48(com.data(), (i64)len, f1[1]);
+    GapFeat F{f1, &c->f2};
+    GapGenome G{&c->seqs, &c->lens};
+    GapParms gp;
+    gp.f_dup = f_dup;
+    gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
+    mapGaps(G, Seq{rd.data(), len}, Seq{com.data(), len}, c->w.cords_str, c->w.cords_end, c->w.apx_gaps, F, gp);
+    reformCords(c->w.cords_str, c->w.cords_end);
+    return c->w.cords_str.size();
+}
 int orc_gap_score(int which, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t read_len, int strand) {
     switch (which) {
         case 1: return getGapAnchorsChainScore(a, b);

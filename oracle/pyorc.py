@@ -156,13 +156,12 @@ class Checker:
         return cs[:n], ce[:n]
 
     def map_read_gap(self, read: np.ndarray, gap_len: int = 50, dup: int = 0):
-        """Reference only: apxMap + mapGaps + reformCords as `linear filter -g gap_len [-dup 1]` runs them."""
-        assert self.kind == "ref"
-        L = self.lib
-        L.ref_map_read_g.restype = C.c_uint64
-        L.ref_map_read_g.argtypes = [C.c_void_p, _u8p, C.c_uint64, C.c_uint32, C.c_int]
+        """apxMap + mapGaps + reformCords as `linear filter -g gap_len [-dup 1]` runs them."""
+        fn = self._f("map_read_g")
+        fn.restype = C.c_uint64
+        fn.argtypes = [C.c_void_p, _u8p, C.c_uint64, C.c_uint32, C.c_int]
         read = np.ascontiguousarray(read, dtype=np.uint8)
-        n = int(L.ref_map_read_g(self.h, _p(read, _u8p), read.size, gap_len, dup))
+        n = int(fn(self.h, _p(read, _u8p), read.size, gap_len, dup))
         cs, ce = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
         if n:
             self._f("get_cords")(self.h, _p(cs, _u64p), _p(ce, _u64p))
