@@ -110,3 +110,50 @@ def test_oracle_hindex_matches_live_reference(oracle_lib):
             assert np.array_equal(o.seed_lookup(rd)[0], r.seed_lookup(rd)[0])
             a, b = o.map_read(rd), r.map_read(rd)
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ---- gap path (-g 50 [-dup 1]): the oracle's restatement (oracle/lnr_gap.inc) against the reference's goldens
+@pytest.mark.parametrize("name", ["ont", "edge"])
+def test_oracle_gap_path_matches_reference_golden(oracle_lib, case_inputs, name):
+    refs, reads, off = case_inputs(name)
+    g = np.load(os.path.join(GOLD, f"{name}_g50_T1.npz"))
+    assert cases.input_digest(refs, reads, off) == str(g["digest"])
+    o = oracle_lib.Checker("oracle", refs, 1)
+    for dup in (0, 1):
+        co = g[f"cord_off_dup{dup}"]
+        for i in range(off.size - 1):
+            cs, ce = o.map_read_gap(reads[int(off[i]):int(off[i + 1])], 50, dup)
+            assert np.array_equal(cs, g[f"cords_str_dup{dup}"][int(co[i]):int(co[i + 1])]), f"dup {dup} read {i}"
+            assert np.array_equal(ce, g[f"cords_end_dup{dup}"][int(co[i]):int(co[i + 1])]), f"dup {dup} read {i}"
+    o.close()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/gap_util.cpp"), reason="reference tree not present (GPU box)")
+def test_oracle_gap_path_matches_live_reference(oracle_lib):
+    """Fresh inputs: reads with planted insertions, deletions, duplications and inversions (the gap re-mapper's cases), several -g
+    values, with and without -dup, repeat-rich and multi-sequence references, -t 1 and 3."""
+    from linear_amd import synth
+    rng = np.random.default_rng(2026)
+    refs = [synth.repeat_ref(300_000, 61), synth.add_n_runs(synth.random_ref(200_000, 62), 63, n_runs=2, max_run=600)]
+    reads_l = []
+    cpl = np.array([3, 2, 1, 0, 4], np.uint8)
+    for k in range(60):
+        ref = refs[k % 2]
+        x0 = int(rng.integers(1000, ref.size - 12000))
+        seg = ref[x0:x0 + 9000].copy()
+        cut = int(rng.integers(2000, 6000)); n = int(rng.integers(60, 1500))
+        kind = k % 6
+        if kind == 1: seg = np.concatenate([seg[:cut], seg[cut + n:]])
+        elif kind == 2: seg = np.concatenate([seg[:cut], rng.integers(0, 4, n, dtype=np.uint8), seg[cut:]])
+        elif kind == 3: seg = np.concatenate([seg[:cut], seg[max(cut - n, 0):cut], seg[cut:]])
+        elif kind == 4: seg = np.concatenate([seg[:cut], cpl[seg[cut:cut + n][::-1]], seg[cut + n:]])
+        elif kind == 5: seg = np.concatenate([seg[:cut], ref[x0 + 20000 - min(20000, x0):][:n], seg[cut:]])
+        r, o_, _ = synth.sample_reads([seg], 1, min(seg.size - 50, 8000), float(rng.choice([0.0, 0.03, 0.1])), 700 + k, "random")
+        reads_l.append(np.ascontiguousarray(r[: int(o_[1])]))
+    for T in (1, 3):
+        o = oracle_lib.Checker("oracle", refs, T)
+        r = oracle_lib.Checker("ref", refs, T)
+        for i, rd in enumerate(reads_l):
+            for gap_len, dup in ((50, 0), (50, 1), (1, 0), (5, 1), (200, 0)):
+                a, b = o.map_read_gap(rd, gap_len, dup), r.map_read_gap(rd, gap_len, dup)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (T, i, gap_len, dup)
