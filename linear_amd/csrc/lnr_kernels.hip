@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(256) k_ix_lines(const i32 *dir, const u64 *hs,
 //     stamps: a wave waits 0.57 us per round for its lines and spends 4.5 us issuing: the kernel is bound by its instruction
 //     count at 3 waves / SIMD (LDS: 13 KB per wave), not by traffic; the extra instructions of the register form cost more
 //     than the saved traffic gave
-#define SEED_RING 128
+#define SEED_RING 256
 LNR_HD inline u32 y_match32(u32 hs_y, u32 Y) {   // y_match on the 20-bit y field (pmpfinder.cpp:1893-1894, ctz(0) pinned to "match")
     u32 v = hs_y ^ Y;
     u32 low = v & (0u - v);                        // lowest set bit (0 if none)
@@ -807,23 +807,19 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
             if (tot == 0) continue;
             u32 pos = incl - cnt;
             u32 sqv = (base + q) | ((rec.w >> 8) << 31);
-            // ---- 3. survivors -> ring, anchors out.  All lanes at once when the ring (128 entries: every LDS byte of this kernel is
-            // occupancy) takes them, else in two halves, else four lanes at a time (<= 64 survivors + the < 64 already waiting).
+            // ---- 3. survivors -> ring (all lanes at once when they fit, else eight lanes at a time), anchors out.
             // A line has about one survivor: the k-th survivor of every lane is read from the staged line and placed at pos + k.
+            // (A ring of 128 entries -- 14 instead of 12 waves per CU -- with sub-rounds of 32 / 4 lanes measured 1 % faster in a loop
+            // over the seed stage alone and 1-2 % slower in the whole path: the four-lane fallback is taken often at sampling step 7.)
             const u64 *srcw = (const u64 *)&s_line[lane][0];
-            u32 lsh = 6;                                                    // sub-round = 1 << lsh lanes
-            if (sc + tot > SEED_RING) {
-                u32 h0 = (u32)__builtin_amdgcn_readlane((int)incl, 31);
-                lsh = (sc + h0 <= SEED_RING && tot - h0 <= 65) ? 5u : 2u;
-            }
-            u32 nq = 64u >> lsh;
+            u32 nq = sc + tot <= SEED_RING ? 1u : 8u;                       // (8 lanes hold at most 128 survivors; sc < 64 here)
             for (u32 qt = 0; qt < nq; qt++) {
                 u32 qb = 0, qn = tot;
                 if (nq > 1) {
-                    qb = qt ? (u32)__builtin_amdgcn_readlane((int)incl, (int)((qt << lsh) - 1)) : 0u;
-                    qn = (u32)__builtin_amdgcn_readlane((int)incl, (int)(((qt + 1) << lsh) - 1)) - qb;
+                    qb = qt ? (u32)__builtin_amdgcn_readlane((int)incl, (int)(8 * qt - 1)) : 0u;
+                    qn = (u32)__builtin_amdgcn_readlane((int)incl, (int)(8 * qt + 7)) - qb;
                 }
-                bool mine = nq == 1 || ((u32)lane >> lsh) == qt;
+                bool mine = nq == 1 || (u32)(lane >> 3) == qt;
                 u32 pr = sh + sc + pos - qb;
                 u32 mk = mine ? mm : 0u;
                 while (__ballot(mk != 0)) {
