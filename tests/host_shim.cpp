@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstring>
 #include "../linear_amd/csrc/lnr_hd.h"
+#include "../linear_amd/csrc/lnr_gap_hd.h"
 
 using namespace lnr;
 
@@ -249,6 +250,57 @@ u64 hs_debug_get(void *h, int stage, u64 *out, u64 cap) {
     return c->dbg[stage].size();
 }
 void hs_get_stats(void *h, u64 *out5) { memcpy(out5, ((Shim *)h)->stats, 40); }
+
+
+// ---- the product's gap path (lnr_gap_hd.h) on the host, hook for hook like the oracle's orc_gap_* (tests/test_gap_shim_cpu.py)
+namespace {
+struct GapHost {
+    std::vector<char> mem; GArena ar; LeaderScratch ls; std::vector<u8> g, r, c; GapCtx X;
+    GapHost(const u8 *gp_, u64 glen, const u8 *rp, u64 rlen) : mem((size_t)256 << 20), g(glen + PAD, 0), r(rlen + PAD, 0), c(rlen + PAD, 0) {
+        memcpy(g.data(), gp_, glen); memcpy(r.data(), rp, rlen);
+        static const u8 cpl[5] = {3, 2, 1, 0, 4};
+        for (u64 k = 0; k < rlen; k++) c[k] = cpl[r[rlen - k - 1] > 4 ? 4 : r[rlen - k - 1]];
+        ar.init(mem.data(), mem.size());
+        X.ar = &ar; X.ls = &ls; X.read.p = r.data(); X.read.len = rlen; X.com.p = c.data(); X.com.len = rlen;
+        X.g = g.data(); so = 0; sl = glen; X.seq_off = &so; X.seq_len = &sl;
+    }
+    u64 so, sl;
+};
+u64 out64(const GVec<u64> &v, u64 *out, u64 cap) { for (u32 i = 0; i < v.n && i < cap; i++) out[i] = v[i]; return v.n; }
+}
+u64 hs_gap_anchors(const u8 *g, u64 glen, const u8 *r, u64 rlen, u64 gap_str, u64 gap_end, int shape_len, int step1, int step2, int direction, i64 lower, i64 upper, u64 rvcp, u64 *out, u64 cap) {
+    GapHost H(g, glen, r, rlen);
+    GVec<u64> g_hs, anc; g_hs.init(&H.ar); anc.init(&H.ar);
+    g_stream(H.X.ref(0), H.X.read, g_hs, gap_str, gap_end, (u32)shape_len, step1, step2);
+    g_create_anchors(g_hs, anc, shape_len, direction, lower, upper, rvcp, gap_str, gap_end, H.X);
+    return H.ar.ovf ? ~0ULL : out64(anc, out, cap);
+}
+u64 hs_gap_anchor_pair(const u8 *g, u64 glen, const u8 *r, u64 rlen, u64 gs, u64 ge, int shape_len, int step1, int step2, u64 rvcp, u64 gs1, u64 ge1, u64 gs2, u64 ge2, u64 *out1, u64 *n1, u64 *out2,
+                       u64 cap) {
+    GapHost H(g, glen, r, rlen);
+    GVec<u64> g_hs, a1, a2; g_hs.init(&H.ar); a1.init(&H.ar); a2.init(&H.ar);
+    g_stream(H.X.ref(0), H.X.read, g_hs, gs, ge, (u32)shape_len, step1, step2);
+    g_create_anchor_pair(g_hs, a1, a2, shape_len, rvcp, gs1, ge1, gs2, ge2, H.X);
+    *n1 = out64(a1, out1, cap);
+    return out64(a2, out2, cap);
+}
+u64 hs_gap_canchors(const u8 *g, u64 glen, const u8 *r, u64 rlen, u64 s1s, u64 s1e, u64 s2s, u64 s2e, int step1, int step2, int shape_len, i64 lower, i64 upper, u64 *out, u64 cap) {
+    GapHost H(g, glen, r, rlen);
+    GVec<u64> g_hs, anc; g_hs.init(&H.ar); anc.init(&H.ar);
+    c_stream(H.X.ref(0), g_hs, s1s, s1e, step1, shape_len, 0);
+    c_stream(H.X.read, g_hs, s2s, s2e, step2, shape_len, 1);
+    c_create_anchors2(g_hs, anc, lower, upper, H.ls.st);
+    return out64(anc, out, cap);
+}
+int hs_gap_score(int which, u64 a, u64 b, u64 c, u64 d, u64 read_len, int strand) {
+    switch (which) {
+        case 1: return gap_anchor_score1(a, b);
+        case 2: return gap_anchor_score2(a, b);
+        case 3: return gap_block_score2(a, b, c, d, read_len, strand);
+        case 5: return gap_clip_score(a, b);
+        default: return gap_block_score3(a, b, c, d, read_len, strand);
+    }
+}
 
 // packed-read form of the minimizer sample against the byte form: returns the number of samples that disagree
 // (samples where the packed form declines are counted separately in *n_fallback)

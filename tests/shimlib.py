@@ -14,7 +14,7 @@ _u8p, _u64p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_
 def build():
     os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
     srcs = [os.path.join(HERE, "host_shim.cpp"), os.path.join(HERE, "..", "linear_amd", "csrc", "lnr_hd.h"),
-            os.path.join(HERE, "..", "linear_amd", "csrc", "ref_sort.h")]
+            os.path.join(HERE, "..", "linear_amd", "csrc", "ref_sort.h"), os.path.join(HERE, "..", "linear_amd", "csrc", "lnr_gap_hd.h")]
     if os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", SO, srcs[0]])

@@ -1,0 +1,101 @@
+"""CPU: the product's gap path (linear_amd/csrc/lnr_gap_hd.h, SURVEY 8 f1 -- work in progress), compiled for the host by the test
+shim, against the oracle's restatement (oracle/lnr_gap.inc), layer by layer through matching hooks."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from linear_amd import synth
+from tests import shimlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+u8p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
+SIGS = {
+    "gap_anchors": (C.c_uint64, [u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_uint64, u64p, C.c_uint64]),
+    "gap_anchor_pair": (C.c_uint64, [u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p, u64p,
+                                     C.c_uint64]),
+    "gap_canchors": (C.c_uint64, [u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, u64p, C.c_uint64]),
+    "gap_score": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]),
+}
+
+
+def libs():
+    from oracle import pyorc
+    pyorc.build(ref=False)
+    shimlib.build()
+    o = C.CDLL(os.path.join(HERE, "..", "oracle", "liblnr_oracle.so"))
+    s = C.CDLL(shimlib.SO)
+    for lib, pfx in ((o, "orc_"), (s, "hs_")):
+        for name, (res, args) in SIGS.items():
+            f = getattr(lib, pfx + name, None)
+            if f is not None:
+                f.restype, f.argtypes = res, args
+    return o, s
+
+
+def cord(idx, x, y, strand=0):
+    return (idx << 50) | (x << 20) | y | (strand << 61)
+
+
+def p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def make_pair(seed, glen=6000, rlen=5000, err=0.08, with_n=False):
+    rng = np.random.default_rng(seed)
+    g = synth.random_ref(glen, seed)
+    if with_n:
+        g = synth.add_n_runs(g, seed + 1, n_runs=2, max_run=40)
+    x0 = int(rng.integers(0, glen - rlen))
+    reads, off, _ = synth.sample_reads([g[x0:x0 + rlen + 200]], 1, rlen, err, seed + 2, "none")
+    return np.ascontiguousarray(g), np.ascontiguousarray(reads[: int(off[1])]), x0
+
+
+def test_product_gap_anchors_and_scores_match_oracle():
+    o, s = libs()
+    cap = 1 << 20
+    for seed in range(10):
+        g, rd, x0 = make_pair(900 + seed, with_n=seed % 3 == 0)
+        rng = np.random.default_rng(seed)
+        for shape_len, s1, s2 in ((9, 5, 1), (5, 3, 1), (13, 4, 2)):
+            xs, ys = x0 + int(rng.integers(0, 300)), int(rng.integers(0, 300))
+            xe, ye = min(xs + int(rng.integers(500, 3000)), g.size - 1), min(ys + int(rng.integers(500, 3000)), rd.size - 1)
+            for strand in (0, 1):
+                gs, ge = cord(0, xs, ys, strand), cord(0, xe, ye, strand)
+                for direction, lo, hi in ((0, xs - ys - 150, xs - ys + 150), (1, 0, 0), (-1, 0, 0)):
+                    a, b = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+                    args = (p(g, u8p), g.size, p(rd, u8p), rd.size, gs, ge, shape_len, s1, s2, direction, lo, hi, rd.size - 1)
+                    na, nb = o.orc_gap_anchors(*args, p(a, u64p), cap), s.hs_gap_anchors(*args, p(b, u64p), cap)
+                    assert na == nb and np.array_equal(a[:na], b[:nb]), (seed, shape_len, strand, direction, na, nb)
+            gs1, ge1, gs2, ge2 = cord(0, xs, ys), cord(0, xs + 800, ys + 800), cord(0, xe - 800, ye - 800), cord(0, xe, ye)
+            a1, a2, b1, b2 = (np.zeros(cap, np.uint64) for _ in range(4))
+            n1a, n1b = C.c_uint64(), C.c_uint64()
+            args = (p(g, u8p), g.size, p(rd, u8p), rd.size, gs1, ge2, shape_len, s1, s2, rd.size - 1, gs1, ge1, gs2, ge2)
+            n2a = o.orc_gap_anchor_pair(*args, p(a1, u64p), C.byref(n1a), p(a2, u64p), cap)
+            n2b = s.hs_gap_anchor_pair(*args, p(b1, u64p), C.byref(n1b), p(b2, u64p), cap)
+            assert n1a.value == n1b.value and n2a == n2b and np.array_equal(a1[: n1a.value], b1[: n1b.value]) and np.array_equal(a2[:n2a], b2[:n2b])
+        for shape_len, step in ((4, 1), (8, 2), (3, 1)):
+            a, b = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+            args = (p(g, u8p), g.size, p(rd, u8p), rd.size, x0 + 100, x0 + 900, 100, 900, step, 1, shape_len, x0 - 60, x0 + 60)
+            na, nb = o.orc_gap_canchors(*args, p(a, u64p), cap), s.hs_gap_canchors(*args, p(b, u64p), cap)
+            assert na == nb and np.array_equal(a[:na], b[:nb]), ("c", seed, shape_len)
+    rng = np.random.default_rng(5)
+
+    def anchor(x, y, st):
+        return (st << 50) | (((x - y + (1 << 20)) & ((1 << 30) - 1)) << 20) | y
+
+    for _ in range(20000):
+        x1, y1 = int(rng.integers(2000, 60000)), int(rng.integers(0, 9000))
+        dx, dy = int(rng.integers(-400, 1500)), int(rng.integers(-400, 1500))
+        if rng.random() < 0.3:
+            dx = dy + int(rng.integers(-20, 20))
+        a1, a2 = anchor(x1 + dx, min(max(y1 + dy, 0), (1 << 20) - 1), int(rng.integers(0, 2))), anchor(x1, y1, int(rng.integers(0, 2)))
+        for w in (1, 2):
+            assert o.orc_gap_score(w, a1, a2, 0, 0, 0, 0) == s.hs_gap_score(w, a1, a2, 0, 0, 0, 0)
+        s1, s2 = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        c11 = cord(0, x1, y1, s1); c12 = cord(0, x1 + 96, y1 + 96, s1)
+        c21 = cord(0, max(x1 + dx, 0), max(y1 + dy, 0), s2); c22 = cord(0, max(x1 + dx, 0) + 96, max(y1 + dy, 0) + 96, s2)
+        for w in (3, 4):
+            for cs in (0, 1):
+                assert o.orc_gap_score(w, c11, c12, c21, c22, 10000, cs) == s.hs_gap_score(w, c11, c12, c21, c22, 10000, cs)
