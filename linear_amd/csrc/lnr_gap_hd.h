@@ -296,4 +296,163 @@ LNR_HD inline void drop_chain_gap_x(GVec<u64> &ch, int direction, const GapParms
     }
 }
 
+// =================================================================== chains and tiles ====
+// chainAnchorsBase (cluster_util.cpp:445-462) = getBestChains (:53-111) + the traceback of lnr_hd.h; every chain becomes tiles, the
+// last tile of a chain carries the end sign (g_CreateChainsFromAnchors_ gap_util.cpp:1207-1216)
+struct TileSink {
+    const u64 *anchors; GVec<u64> *tiles; u32 first_len, nchains; bool to_tiles;
+    LNR_HD void emit(const i32 *idx, const i32 *sc, u32 n) {
+        (void)sc;
+        for (u32 k = 0; k < n; k++) tiles->push(to_tiles ? ganc_tile(anchors[idx[k]]) : anchors[idx[k]]);
+        if (to_tiles) set_tile_end(tiles->back());
+        if (nchains == 0) first_len = n;
+        nchains++;
+    }
+};
+template <class Score>
+LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, bool to_tiles, u32 depth, u64 dx_depth, int bestn, int min_len, int abort_score, Score score, GapCtx &X, bool first_only = false) {
+    if (n < 2) return;
+    u64 m0 = X.ar->mark();
+    Rec r;
+    i32 *blk = (i32 *)X.ar->get((u64)n * 9 * sizeof(i32));
+    r.score = blk; r.score2 = blk + n; r.len = blk + 2 * n; r.p2 = blk + 3 * n; r.root = blk + 4 * n; r.leaf = blk + 5 * n;
+    i32 *chain = blk + 6 * n, *chain_sc = blk + 7 * n, *cnt = blk + 8 * n;
+    if (X.ar->ovf) return;
+    // (the reference sizes the records without clearing them and sets only record 0's score, length and predecessor: root and leaf of
+    // record 0 are whatever the allocator left -- 0 in practice, as here)
+    for (u32 i = 0; i < n; i++) { r.score[i] = 0; r.score2[i] = 0; r.len[i] = 0; r.p2[i] = 0; r.root[i] = 0; r.leaf[i] = 0; }
+    r.score[0] = 0; r.len[0] = 1; r.p2[0] = -1;
+    for (int i = 0; i < (int)n; i++) {
+        int j_str = i - (int)depth < 0 ? 0 : i - (int)depth, max_j = i, best = -1;
+        for (int j = i - 1; j >= 0 && (j >= j_str || ganc_x(anchors[j]) - ganc_x(anchors[i]) < dx_depth); j--) {
+            int sc = score(anchors[j], anchors[i]);
+            if (sc > 0 && sc + r.score[j] >= best) { max_j = j; best = sc + r.score[j]; }
+        }
+        if (best > 0) { r.p2[i] = max_j; r.score[i] = best; r.len[i] = r.len[max_j] + 1; r.score2[i] = best; r.root[i] = r.root[max_j]; r.leaf[i] = 1; r.leaf[max_j] = 0; }
+        else { r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = i; r.leaf[i] = 1; }
+    }
+    // the output may grow while the records live above it in the arena: collect into a vector allocated before them
+    TileSink sink; sink.anchors = anchors; sink.tiles = &out; sink.first_len = 0; sink.nchains = 0; sink.to_tiles = to_tiles;
+    out.reserve(out.n + n);
+    traceback(r, n, sink, chain, chain_sc, cnt, min_len, abort_score, bestn, 0.7f, *X.ls);
+    (void)first_only;
+    (void)m0;   // (not released: `out` may have been re-allocated above the mark)
+}
+// gather_blocks_ (pmpfinder.cpp:1484-1530) on tiles: a block ends at the tile-end sign (chainTiles gap_util.cpp:1177-1189, f_set_end 0)
+LNR_HD inline void gap_gather_tile_blocks(const u64 *t, u32 n, GVec<UP> &sep, u64 L, u64 large_gap) {
+    if (n < 2) return;
+    u32 p_str = 0;
+    for (u32 i = 1; i < n; i++)
+        if (is_tile_end(t[i - 1]) || !consecutive(t[i - 1], t[i], large_gap)) { UP q; q.first = p_str; q.second = i; sep.push(q); p_str = i; }
+    UP q; q.first = p_str; q.second = n; sep.push(q);
+    (void)L;
+}
+LNR_HD inline void gap_best_chains2(const u64 *rec_, const UP *sep, const i32 *sep_score, u32 nb, Rec r, u64 L, int fn, int strand) {   // getBestChains2 cluster_util.cpp:469-526
+    for (u32 i = 0; i < nb; i++) {
+        int j_str = (int)i - 20 < 0 ? 0 : (int)i - 20, max_j = (int)i, best = -1;
+        for (u32 j = (u32)j_str; j < i; j++) {
+            int sc = fn == 3 ? gap_block_score3(rec_[sep[j].first], rec_[sep[j].second - 1], rec_[sep[i].first], rec_[sep[i].second - 1], L, strand)
+                             : gap_block_score2(rec_[sep[j].first], rec_[sep[j].second - 1], rec_[sep[i].first], rec_[sep[i].second - 1], L, strand);
+            if (sc > 0 && sc + r.score[j] + sep_score[i] >= best) { max_j = (int)j; best = sc + r.score[j] + sep_score[i]; }
+        }
+        if (best > 0) { r.p2[i] = max_j; r.score[i] = best; r.len[i] = (i32)(sep[i].second - sep[i].first) + r.len[max_j]; r.score2[i] = best; r.root[i] = r.root[max_j]; r.leaf[i] = 1; r.leaf[max_j] = 0; }
+        else { r.p2[i] = -1; r.score[i] = sep_score[i]; r.len[i] = (i32)(sep[i].second - sep[i].first); r.score2[i] = r.score[i]; r.root[i] = (i32)i; r.leaf[i] = 1; }
+    }
+}
+// chainBlocksCords (cluster_util.cpp:1068-1102) for tiles: both strands, the better one, its major chains (_filterBlocksCords :865-931 without
+// header, the tile-end sign as the block end)
+LNR_HD inline void gap_chain_blocks_cords(GVec<u64> &tiles, GVec<UP> &sep, u64 L, u32 init_score, u64 major_limit, GapCtx &X) {
+    u32 nb = sep.n;
+    UP *sp[2]; BlockSink cc[2];
+    for (int strand = 0; strand < 2; strand++) {
+        sp[strand] = (UP *)X.ar->get((u64)(nb + 1) * sizeof(UP));
+        i32 *ib = (i32 *)X.ar->get((u64)(nb + 1) * 12 * sizeof(i32));
+        UP *el = (UP *)X.ar->get((u64)(nb + 2) * 2 * sizeof(UP));
+        if (X.ar->ovf) return;
+        for (u32 i = 0; i < nb; i++) sp[strand][i] = sep[i];
+        UP *s = sp[strand];
+        const u64 *cords = tiles.p;
+        if (strand)
+            ref_sort(s, (long)nb, [cords, L](const UP &a, const UP &b) {
+                u64 y1 = !cord_strand(cords[a.first]) ? L - 1 - cord_y(cords[a.second - 1]) : cord_y(cords[a.first]);
+                u64 y2 = !cord_strand(cords[b.first]) ? L - 1 - cord_y(cords[b.second - 1]) : cord_y(cords[b.first]);
+                return y1 > y2;
+            }, X.ls->st);
+        else
+            ref_sort(s, (long)nb, [cords, L](const UP &a, const UP &b) {
+                u64 y1 = cord_strand(cords[a.first]) ? L - 1 - cord_y(cords[a.second - 1]) : cord_y(cords[a.first]);
+                u64 y2 = cord_strand(cords[b.first]) ? L - 1 - cord_y(cords[b.second - 1]) : cord_y(cords[b.first]);
+                return y1 > y2;
+            }, X.ls->st);
+        i32 *sc = ib;
+        for (u32 i = 0; i < nb; i++) sc[i] = (i32)((s[i].second - s[i].first) * init_score);
+        BlockSink &k = cc[strand];
+        k.el = el; k.off = ib + (nb + 1); k.nchains = 0; k.nel = 0; k.cap = (nb + 2) * 2; k.ovf = &X.ar->ovf; k.first_len = 0; k.off[0] = 0; k.elements = s;
+        if (nb >= 2) {                                                                      // chainBlocksBase :533-577 (f_sort 0)
+            Rec r; i32 *q = ib + 2 * (nb + 1);
+            r.score = q; r.score2 = q + (nb + 1); r.len = q + 2 * (nb + 1); r.p2 = q + 3 * (nb + 1); r.root = q + 4 * (nb + 1); r.leaf = q + 5 * (nb + 1);
+            i32 *chain = q + 6 * (nb + 1), *chain_sc = q + 7 * (nb + 1), *cnt = q + 8 * (nb + 1);
+            for (u32 i = 0; i < nb; i++) { r.score[i] = 0; r.score2[i] = 0; r.len[i] = 0; r.p2[i] = 0; r.root[i] = 0; r.leaf[i] = 0; }
+            gap_best_chains2(cords, s, sc, nb, r, L, X.gp.chn2_fn, strand);
+            traceback(r, nb, k, chain, chain_sc, cnt, X.gp.chn2_min_len, X.gp.chn2_abort, 3, 0.7f, *X.ls);
+        }
+    }
+    int best = best_strand(cc[0], cc[1]);
+    for (u32 i = 0; i < nb; i++) sep[i] = sp[best][i];
+    BlockSink &ch = cc[best];
+    revert_chain_block_strand(ch, tiles.p, best);
+    if (ch.nchains == 0) return;
+    u64 *out = (u64 *)X.ar->get((u64)(tiles.n + 1) * 8);
+    if (X.ar->ovf) return;
+    u32 n = 0; u64 len_current = 0;
+    for (i32 i = ch.off[0]; i < ch.off[1]; i++) {
+        for (u64 j = ch.el[i].first; j < ch.el[i].second; j++) out[n++] = tiles[(u32)j] & ~TILE_END;
+        len_current += ch.el[i].second - ch.el[i].first;
+    }
+    out[n - 1] |= TILE_END;
+    float bound = 0.8 * len_current;
+    u32 major_n = 1;
+    for (u32 c = 1; c < ch.nchains && major_n < major_limit; c++) {
+        len_current = 0;
+        for (i32 j = ch.off[c]; j < ch.off[c + 1]; j++) len_current += ch.el[j].second - ch.el[j].first;
+        if ((float)len_current > bound) {
+            ++major_n;
+            for (i32 j = ch.off[c]; j < ch.off[c + 1]; j++) for (u64 k2 = ch.el[j].first; k2 < ch.el[j].second; k2++) out[n++] = tiles[(u32)k2] & ~TILE_END;
+            out[n - 1] |= TILE_END;
+        }
+    }
+    for (u32 i = 0; i < n; i++) tiles[i] = out[i];
+    tiles.n = n;
+}
+LNR_HD inline void gap_chain_tiles(GVec<u64> &tiles, u64 L, u64 gap_size, GapCtx &X) {       // chainTiles gap_util.cpp:1177-1189
+    GVec<UP> sep; sep.init(X.ar);
+    gap_gather_tile_blocks(tiles.p, tiles.n, sep, L, gap_size);
+    gap_chain_blocks_cords(tiles, sep, L, 64, X.gp.thd_cts_major_limit, X);
+}
+LNR_HD inline void g_chains_from_anchors(GVec<u64> &anchors, GVec<u64> &tiles, u64 L, GapCtx &X) {   // g_CreateChainsFromAnchors_ gap_util.cpp:1191-1222
+    ref_sort(anchors.p, (long)anchors.n, [](const u64 &a, const u64 &b) { return ganc_x(a) > ganc_x(b); }, X.ls->st);
+    int fn = X.gp.chn1_fn;
+    gap_chain_anchors(anchors.p, anchors.n, tiles, true, 20, 80, 20, X.gp.chn1_min_len, X.gp.chn1_abort, [fn](u64 a, u64 b) { return fn == 2 ? gap_anchor_score2(a, b) : gap_anchor_score1(a, b); }, X);
+    gap_chain_tiles(tiles, L, 100, X);
+}
+struct IPair { int first, second; };
+LNR_HD inline IPair closest_extension_chain(GVec<u64> &t, u64 gap_str, u64 gap_end, bool f_erase, const GapParms &gp) {   // getClosestExtensionChain_ gap_util.cpp:1227-1270
+    int pre_i = 0;
+    IPair z; z.first = 0; z.second = 0;
+    for (int i = 0; i < (int)t.n; i++) {
+        if (!is_tile_end(t[(u32)i])) continue;
+        i64 danchor = 0, dx = 0, dy = 0;
+        if (gp.direction < 0) { dy = (i64)cord_y(gap_end) - (i64)cord_y(t[(u32)i]); dx = (i64)cord_x(gap_end) - (i64)cord_x(t[(u32)i]); danchor = dx - dy; }
+        else if (gp.direction > 0) { dy = (i64)cord_y(t[(u32)pre_i]) - (i64)cord_y(gap_str); dx = (i64)cord_x(t[(u32)pre_i]) - (i64)cord_x(gap_str); danchor = dx - dy; }
+        i64 m = gabs(dy) > gabs(dx) ? gabs(dy) : gabs(dx);
+        if (gabs(danchor) < gp.thd_ctfas2_connect_danchor && m < gp.thd_ctfas2_connect_dy_dx) {
+            if (f_erase) { t.erase(0, (u32)pre_i); t.n = (u32)(i + 1 - pre_i); z.second = (int)t.n; return z; }
+            z.first = pre_i; z.second = i + 1; return z;
+        }
+        pre_i = i + 1;
+    }
+    if (f_erase) t.clear();
+    return z;
+}
+
 }  // namespace lnr

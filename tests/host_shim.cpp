@@ -256,7 +256,7 @@ void hs_get_stats(void *h, u64 *out5) { memcpy(out5, ((Shim *)h)->stats, 40); }
 namespace {
 struct GapHost {
     std::vector<char> mem; GArena ar; LeaderScratch ls; std::vector<u8> g, r, c; GapCtx X;
-    GapHost(const u8 *gp_, u64 glen, const u8 *rp, u64 rlen) : mem((size_t)256 << 20), g(glen + PAD, 0), r(rlen + PAD, 0), c(rlen + PAD, 0) {
+    GapHost(const u8 *gp_, u64 glen, const u8 *rp, u64 rlen) : mem((size_t)64 << 20), g(glen + PAD, 0), r(rlen + PAD, 0), c(rlen + PAD, 0) {
         memcpy(g.data(), gp_, glen); memcpy(r.data(), rp, rlen);
         static const u8 cpl[5] = {3, 2, 1, 0, 4};
         for (u64 k = 0; k < rlen; k++) c[k] = cpl[r[rlen - k - 1] > 4 ? 4 : r[rlen - k - 1]];
@@ -291,6 +291,17 @@ u64 hs_gap_canchors(const u8 *g, u64 glen, const u8 *r, u64 rlen, u64 s1s, u64 s
     c_stream(H.X.read, g_hs, s2s, s2e, step2, shape_len, 1);
     c_create_anchors2(g_hs, anc, lower, upper, H.ls.st);
     return out64(anc, out, cap);
+}
+u64 hs_gap_chains(const u64 *anchors, u64 n, u64 read_len, int alt, int direction, u64 gap_str, u64 gap_end, int closest, u64 *out, u64 cap, int *pr) {
+    u8 z = 0;
+    GapHost H(&z, 1, &z, 1);
+    if (alt) { H.X.gp.chn1_min_len = 1; H.X.gp.chn1_abort = 0; H.X.gp.chn1_fn = 2; H.X.gp.chn2_abort = 0; H.X.gp.chn2_fn = 3; }
+    H.X.gp.direction = direction;
+    GVec<u64> a, tiles; a.init(&H.ar, (u32)n + 16); tiles.init(&H.ar, (u32)n + 16);
+    for (u64 i = 0; i < n; i++) a.push(anchors[i]);
+    g_chains_from_anchors(a, tiles, read_len, H.X);
+    if (closest) { IPair r = closest_extension_chain(tiles, gap_str, gap_end, closest == 2, H.X.gp); pr[0] = r.first; pr[1] = r.second; }
+    return H.ar.ovf ? ~0ULL : out64(tiles, out, cap);
 }
 int hs_gap_score(int which, u64 a, u64 b, u64 c, u64 d, u64 read_len, int strand) {
     switch (which) {

@@ -99,3 +99,35 @@ def test_product_gap_anchors_and_scores_match_oracle():
         for w in (3, 4):
             for cs in (0, 1):
                 assert o.orc_gap_score(w, c11, c12, c21, c22, 10000, cs) == s.hs_gap_score(w, c11, c12, c21, c22, 10000, cs)
+
+
+def test_product_gap_chains_match_oracle():
+    o, s = libs()
+    for lib, pfx in ((o, "orc_"), (s, "hs_")):
+        f = getattr(lib, pfx + "gap_chains")
+        f.restype = C.c_uint64
+        f.argtypes = [u64p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, u64p, C.c_uint64, C.POINTER(C.c_int)]
+    cap = 1 << 20
+    n_nonempty = 0
+    for seed in range(16):
+        g, rd, x0 = make_pair(300 + seed, err=0.05 + 0.01 * (seed % 8))
+        if seed % 4 == 1:
+            g = np.ascontiguousarray(np.concatenate([g[:3000], g[2200:3000], g[3000:]]))
+        xs, ys = x0 + 50, 50
+        xe, ye = min(xs + 2500, g.size - 1), min(ys + 2500, rd.size - 1)
+        gs, ge = cord(0, xs, ys), cord(0, xe, ye)
+        for shape_len, s1, s2, direction in ((9, 5, 1, 0), (5, 3, 1, 1), (9, 5, 1, -1)):
+            a = np.zeros(cap, np.uint64)
+            lo, hi = xs - ys - 200, xs - ys + 200
+            na = o.orc_gap_anchors(p(g, u8p), g.size, p(rd, u8p), rd.size, gs, ge, shape_len, s1, s2, direction, lo, hi, rd.size - 1, p(a, u64p), cap)
+            anc = np.ascontiguousarray(a[:na])
+            for alt in (0, 1):
+                for closest in (0, 1, 2):
+                    ta, tb = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+                    pa, pb = (C.c_int * 2)(), (C.c_int * 2)()
+                    d = direction if direction else 1
+                    n1 = o.orc_gap_chains(p(anc, u64p), na, rd.size, alt, d, gs, ge, closest, p(ta, u64p), cap, pa)
+                    n2 = s.hs_gap_chains(p(anc, u64p), na, rd.size, alt, d, gs, ge, closest, p(tb, u64p), cap, pb)
+                    assert n1 == n2 and np.array_equal(ta[:n1], tb[:n2]) and (not closest or (pa[0], pa[1]) == (pb[0], pb[1])), (seed, shape_len, direction, alt, closest, n1, n2)
+                    n_nonempty += n1 > 0
+    assert n_nonempty > 50
