@@ -455,4 +455,815 @@ LNR_HD inline IPair closest_extension_chain(GVec<u64> &t, u64 gap_str, u64 gap_e
     return z;
 }
 
+// ---- tiles along a chain, scored by the window features (gap_util.cpp:805-905, 1275-1470)
+LNR_HD inline u32 tile_fscore(u64 tile, const GapCtx &X) {                                   // _get_tile_f_
+    u64 n1 = tile_strand(tile), n2 = cord_id(tile);
+    if (n2 < X.gf.nseq) return wdist_checked(X.f1[n1], f2_view(X.gf, n2), cord_y(tile) >> 4, cord_x(tile) >> 4);
+    return ~0u;
+}
+LNR_HD inline u32 tile_fscore_tri(u64 &t, const GapCtx &X, u64 lower_x, u64 lower_y, u64 upper_x, u64 upper_y) {   // _get_tile_f_tri_
+    u64 x = cord_x(t), y = cord_y(t);
+    int ts4 = X.gp.thd_tile_size / 4;
+    int shift = gmin3(ts4, int(x - lower_x), int(y - lower_y));
+    u32 f1 = tile_fscore(t, X), mn = f1;
+    u64 tl = shift_cord(t, -shift, -shift);
+    u32 f2 = tile_fscore(tl, X);
+    if (f2 < f1) { t = tl; mn = f2; }
+    shift = gmin3(ts4, int(upper_x - x - 1), int(upper_y - y - 1));
+    u64 tr = shift_cord(t, shift, shift);
+    u32 f3 = tile_fscore(tr, X);
+    if (f3 < mn) { t = tr; mn = f3; }
+    return mn;
+}
+LNR_HD inline void tiles_from_chain(const GVec<u64> &ch, GVec<u64> &tiles, u64 gap_str, u64 gap_end, int it_str, int it_end, GapCtx &X) {   // g_CreateTilesFromChains_ :1275-1359 (chain = tiles)
+    if (it_end - it_str == 0) return;
+    u64 pre_chain = ch[(u32)it_str], pre_tile = 0;
+    i64 tmp_shift = X.gp.thd_tile_size / 2;
+    u64 step = (u64)(X.gp.thd_tile_size / 3);
+    int kcount = 0, scan_str = it_str, scan_end = it_str;
+    for (int i = it_str; i <= it_end; i++) {
+        if (i == it_end || tile_strand(ch[(u32)i] ^ pre_chain) || cord_x(ch[(u32)i]) > cord_x(pre_chain) + step || cord_y(ch[(u32)i]) > cord_y(pre_chain) + step) {
+            if (i == it_end) scan_end = it_end;
+            for (int j = scan_end - 1; j >= scan_str; j--) {
+                u64 c = ch[(u32)j];
+                u64 nt = create_cord(cord_id(gap_str), cord_x(c) - (u64)tmp_shift, cord_y(c) - (u64)tmp_shift, tile_strand(c));
+                u64 lower = tiles.empty() ? gap_str : tiles.back();
+                u32 score = tile_fscore_tri(nt, X, cord_x(lower), cord_y(lower), cord_x(gap_end), cord_y(gap_end));
+                if (kcount >= (int)X.gp.thd_ctfcs_pattern_in_window && score <= 32 && cord_y(nt) > cord_y(pre_tile)) {
+                    if (tiles.empty() || is_tile_end(tiles.back())) set_tile_start(nt);
+                    tiles.push(nt);
+                    pre_tile = nt; kcount = i - j; pre_chain = c;
+                    break;
+                }
+            }
+            scan_str = i; scan_end = i + 1;
+        } else { scan_end++; kcount++; }
+    }
+    if (!tiles.empty()) set_tile_end(tiles.back());
+}
+LNR_HD inline void tiles_from_chain2(const GVec<u64> &ch, GVec<u64> &tiles_str, GVec<u64> &tiles_end, u64 gap_str, u64 gap_end, int it_str, int it_end, GapCtx &X) {   // :1364-1470
+    GVec<u64> ts, te; ts.init(X.ar); te.init(X.ar);
+    tiles_from_chain(ch, ts, gap_str, gap_end, it_str, it_end, X);
+    if (ts.empty()) return;
+    i64 tile_size = X.gp.thd_tile_size;
+    u64 c0 = ch[(u32)it_str], c1 = ch[(u32)it_end - 1];
+    for (u32 i = 0; i < ts.n; i++) {
+        i64 dx1 = (i64)cord_x(c0) - (i64)cord_x(ts[i]), dy1 = (i64)cord_y(c0) - (i64)cord_y(ts[i]);
+        if (dx1 <= 0 && dy1 <= 0) {
+            if (dx1 == 0 && dy1 == 0) break;
+            u64 head = create_cord(cord_id(gap_str), cord_x(c0), cord_y(c0), tile_strand(c0));
+            remove_tile_sgn(head);
+            if (i == 0) ts.insert(0, &head, 1);
+            else { ts[i - 1] = head; ts.erase(0, i - 1); }
+            break;
+        }
+        if (i == ts.n - 1) { ts.clear(); ts.push(create_cord(cord_id(gap_str), cord_x(c0), cord_y(c0), tile_strand(c0))); }
+    }
+    te.resize(ts.n);
+    for (u32 i = 0; i < ts.n; i++) te[i] = shift_cord(ts[i], tile_size, tile_size);
+    for (int i = (int)te.n - 1; i >= 0; i--) {
+        i64 dx1 = (i64)cord_x(c1) - (i64)cord_x(te[(u32)i]), dy1 = (i64)cord_y(c1) - (i64)cord_y(te[(u32)i]);
+        if (dx1 >= 0 && dy1 >= 0) {
+            if (dx1 == 0 && dy1 == 0) break;
+            ts.n = (u32)i + 1; te.n = (u32)i + 1;
+            u64 tail_end = create_cord(cord_id(gap_str), cord_x(c1), cord_y(c1), tile_strand(c1));
+            u64 tail_str = shift_cord(tail_end, -tile_size, -tile_size);
+            if (is_tile_end(ts[(u32)i])) { remove_tile_sgn(ts[(u32)i]); remove_tile_sgn(te[(u32)i]); set_tile_end(tail_str); set_tile_end(tail_end); }
+            ts.push(tail_str); te.push(tail_end);
+            break;
+        }
+        if (i == 0) { ts.n = 1; te.n = 1; te[0] = shift_cord(te[0], dx1, dy1); }
+    }
+    tiles_str.append(ts);
+    tiles_end.append(te);
+}
+// window walks that also return the window's distance (pmpfinder.cpp:838-880, 995-1045) and extendPatch (:2881-2963)
+LNR_HD inline u64 gap_next_window(FeatView f1, FeatView f2, u64 cord, float &score) {
+    u64 gid = cord_id(cord), strand = cord_strand(cord), x_pre = cord_x(cord) >> 4, y_pre = cord_y(cord) >> 4, x_min = 0;
+    if (y_pre + 12 > f1.n || x_pre + 12 > f2.n) return 0;
+    u64 y = y_pre + 5;
+    u32 mn = window_best3<false>(f1, f2, y, x_pre + 3, x_min);
+    if (mn > 36) return 0;
+    score += (float)mn;
+    if (x_min - x_pre > 5) return mk_cord((gid << 30) + ((x_pre + 5) << 4), (x_pre + 5 - x_min + y) << 4, strand);
+    return mk_cord((gid << 30) + (x_min << 4), y << 4, strand);
+}
+LNR_HD inline u64 gap_previous_window(FeatView f1, FeatView f2, u64 cord, float &score) {
+    u64 gid = cord_id(cord), strand = cord_strand(cord), x_suf = cord_x(cord) >> 4, y_suf = cord_y(cord) >> 4, x_min = 0;
+    if (y_suf < 5 || x_suf < 6) return 0;
+    u64 y = y_suf - 5;
+    u32 mn = window_best3<false>(f1, f2, y, x_suf - 6, x_min);
+    if (mn > 36) return 0;
+    score += (float)mn;
+    if (x_suf - x_min > 5) return mk_cord((gid << 30) + ((x_suf - 5) << 4), (x_suf - x_min - 5 + y) << 4, strand);
+    return mk_cord((gid << 30) + (x_min << 4), y << 4, strand);
+}
+LNR_HD inline int gap_extend_patch(GVec<u64> &cords, int kk, u64 cord1, u64 cord2, int overlap_size, int gap_size, u32 thd_accept_score, GapCtx &X) {
+    float score = 0;
+    {
+        i64 x1 = (i64)cord_x40(cord1), y1 = (i64)cord_y(cord1), x2 = (i64)cord_x40(cord2), y2 = (i64)cord_y(cord2);
+        if (gabs(x1 - x2) < overlap_size && gabs(y1 - y2) < overlap_size && !(cord_strand(cord1) ^ cord_strand(cord2))) return 0;
+    }
+    u64 strand1 = cord_strand(cord1), strand2 = cord_strand(cord2), gid1 = cord_id(cord1), gid2 = cord_id(cord2);
+    int len = 0;
+    u64 cord = cord1;
+    GVec<u64> tmp; tmp.init(X.ar);
+    u64 x_bound = cord_x(cord2), y_bound = cord_y(cord2);
+    while ((i64)cord_x40(cord) + gap_size <= (i64)cord_x40(cord2)) {
+        cord = gap_next_window(X.f1[strand1], f2_view(X.gf, gid1), cord, score);
+        if (cord && cord_y(cord) < y_bound && cord_x(cord) < x_bound && score < (float)thd_accept_score) tmp.push(cord);
+        else break;
+    }
+    u64 nw = cord1;
+    if (!tmp.empty()) {
+        len += (int)tmp.n; nw = tmp.back();
+        cords.insert((u32)kk, tmp.p, tmp.n);
+        x_bound = cord_x(tmp.back()); y_bound = cord_y(tmp.back());
+        tmp.clear();
+    } else { x_bound = cord_x(cord1); y_bound = cord_y(cord1); }
+    cord = cord2;
+    while ((i64)cord_x40(nw) + gap_size <= (i64)cord_x40(cord)) {
+        cord = gap_previous_window(X.f1[strand2], f2_view(X.gf, gid2), cord, score);
+        if (cord && cord_y(cord) > y_bound && cord_x(cord) > x_bound && score < (float)thd_accept_score) tmp.push(cord);
+        else break;
+    }
+    if (!tmp.empty()) {
+        for (u32 i = 0; i < tmp.n / 2; i++) rs_swap(tmp[i], tmp[tmp.n - 1 - i]);
+        cords.insert((u32)(kk + len), tmp.p, tmp.n);
+        len += (int)tmp.n;
+    }
+    return len;
+}
+LNR_HD inline void gap_trim_tiles(GVec<u64> &t, u64 gap_str, u64 gap_end, u64 rvcp, int direction, GapCtx &X) {   // trimTiles gap_util.cpp:1498-1594
+    const GapParms &gp = X.gp;
+    u64 ts = (u64)gp.thd_tile_size;
+    i64 sx = (i64)(cord_x(gap_end) - cord_x(gap_str)), sy = (i64)(cord_y(gap_end) - cord_y(gap_str));
+    if (sx > (i64)ts) sx = (i64)ts;
+    if (sy > (i64)ts) sy = (i64)ts;
+    u64 cord_end_ = shift_cord(gap_end, -sx, -sy);
+    for (int i = 0; i < (int)t.n; i++) {
+        if (is_tile_start(t[(u32)i]) && direction >= 0) {
+            int nn = gap_extend_patch(t, i, gap_str, t[(u32)i], gp.thd_tts_overlap_size, gp.thd_tts_gap_size, gp.thd_accept_score, X);
+            if (nn) { set_tile_start(t[(u32)i]); i += nn; t[(u32)i] &= ~TILE_STR; }
+        }
+        if (is_tile_end(t[(u32)i]) && direction <= 0) {
+            int nn = gap_extend_patch(t, i + 1, t[(u32)i], cord_end_, gp.thd_tts_overlap_size, gp.thd_tts_gap_size, gp.thd_accept_score, X);
+            if (nn) { t[(u32)i] &= ~TILE_END; i += nn; set_tile_end(t[(u32)i]); }
+        }
+        if (i >= 1 && !is_tile_end(t[(u32)i - 1]) && !is_tile_start(t[(u32)i])) i += gap_extend_patch(t, i, t[(u32)i - 1], t[(u32)i], gp.thd_tts_overlap_size, gp.thd_tts_gap_size, gp.thd_accept_score, X);
+    }
+    i64 x_str = (i64)cord_x(gap_str), y_str = (i64)cord_y(gap_str), x_end = (i64)cord_x(gap_end), y_end = (i64)cord_y(gap_end);
+    int di = 0;
+    for (int i = 0; i < (int)t.n; i++) {
+        u64 v = t[(u32)i];
+        i64 x_t = (i64)cord_x(v);
+        i64 y_t = tile_strand(v ^ gap_str) ? (i64)(rvcp - 1 - cord_y(v) - ts) : (i64)cord_y(v);
+        if (x_t < x_str || x_t + (i64)ts > x_end || y_t < y_str || y_t + (i64)ts > y_end) {
+            if (is_tile_start(v) && is_tile_end(v)) {}
+            else if (is_tile_start(v)) { if (i + 1 < (int)t.n) set_tile_start(t[(u32)i + 1]); }
+            else if (is_tile_end(v)) { if (i - di - 1 > 0) set_tile_end(t[(u32)(i - di - 1)]); }
+            di++;
+        } else t[(u32)(i - di)] = v;
+    }
+    if (di) t.n -= (u32)di;
+}
+
+// ---- clipping (gap_util.cpp:2169-2330)
+template <class GX> LNR_HD inline void gap_accumulate_score(const GVec<u64> &ch, GVec<int> &gs, int shape_len, GX getx, const GapParms &gp) {
+    gs.resize(ch.n); for (u32 i = 0; i < ch.n; i++) gs[i] = 0;
+    if (ch.empty()) return;
+    u64 pre = getx(ch[0]);
+    for (u32 i = 1; i < ch.n; i++) {
+        u64 x = getx(ch[i]);
+        int ng = int(x - pre) > shape_len ? (int)(x - pre - (u64)shape_len) : 0;
+        gs[i] += gs[i - 1] + ng * gp.int_precision;
+        pre = x;
+    }
+}
+LNR_HD inline int gap_clip_chain_(GVec<u64> &ch, const GVec<int> &gsx, const GVec<int> &gsy, int direction, bool f_clip, const GapParms &gp) {
+    if (ch.empty()) return -1;
+    bool left = direction <= 0;
+    int n = (int)ch.n, clip_i = left ? -1 : n - 1, w = gp.thd_ccps_window_size, best = (int)0x80000000, found = 0;
+    for (int i = 1; i < n - 1; i++) {
+        int i_str = i - w > 0 ? i - w : 0, i_end = i + w < n - 1 ? i + w : n - 1, d1 = i - i_str, d2 = i_end - i;
+        int cx1 = (gsx[(u32)i] - gsx[(u32)i_str]) / d1, cx2 = (gsx[(u32)i_end] - gsx[(u32)i]) / d2, cy1 = (gsy[(u32)i] - gsy[(u32)i_str]) / d1, cy2 = (gsy[(u32)i_end] - gsy[(u32)i]) / d2;
+        if (left) { rs_swap(cx1, cx2); rs_swap(cy1, cy2); }
+        int d = cx2 - cx1 + cy2 - cy1;
+        if (d > best && cx1 < gp.thd_ccps_clip1_upper && cy1 < gp.thd_ccps_clip1_upper && (cx2 > gp.thd_ccps_clip2_lower || cy2 > gp.thd_ccps_clip2_lower)) { best = d; clip_i = i; found = 1; }
+    }
+    if (f_clip && found) { if (left) ch.erase(0, (u32)clip_i + 1); else ch.n = (u32)clip_i + 1; }
+    return clip_i + 1;
+}
+template <class GX, class GY> LNR_HD inline int gap_clip_chain(GVec<u64> &ch, int shape_len, int direction, bool f_clip, GX getx, GY gety, GapCtx &X) {
+    GVec<int> gsx, gsy; gsx.init(X.ar); gsy.init(X.ar);
+    gap_accumulate_score(ch, gsx, shape_len, getx, X.gp);
+    gap_accumulate_score(ch, gsy, shape_len, gety, X.gp);
+    return gap_clip_chain_(ch, gsx, gsy, direction, f_clip, X.gp);
+}
+LNR_HD inline void stick_main_chain(GVec<u64> &c1, const GVec<u64> &c2, i64 thd) {          // stickMainChain :2276-2330 (chain1: gap anchors, chain2: tiles)
+    if (c1.empty() || c2.empty()) return;
+    int di = 0, jj = (int)c2.n - 1;
+    u64 x1, x2 = cord_x(c2[(u32)jj]);
+    for (int i = 0; i < (int)c1.n; i++) {
+        x1 = ganc_x(c1[(u32)i]);
+        if (x1 < x2) for (int j = jj - 1; j >= 0; j--) { x2 = cord_x(c2[(u32)j]); if (x1 >= x2) { jj = j; break; } }
+        if (x1 < x2) jj = 0;
+        i64 a1 = (i64)(x1 - ganc_y(c1[(u32)i])), a2 = (i64)(cord_x(c2[(u32)jj]) - cord_y(c2[(u32)jj]));
+        if (a1 >= a2 + thd || a1 < a2 - thd) di++;
+        else c1[(u32)(i - di)] = c1[(u32)i];
+    }
+    c1.n -= (u32)di;
+}
+
+// =================================================================== tiles <-> cords, overlaps, extension ====
+LNR_HD inline void gap_reform_tiles(GVec<u64> &ts, GVec<u64> &te, u64 gap_str, u64 gap_end, int direction, const GapParms &gp) {   // reform_tiles gap_util.cpp:3042-3128
+    i64 x1 = (i64)cord_x(gap_str), x2 = (i64)cord_x(gap_end), y1 = (i64)cord_y(gap_str), y2 = (i64)cord_y(gap_end), d1, d2, T = gp.thd_tile_size;
+    if (!ts.empty()) {
+        d1 = gmin3((i64)cord_x(ts.back()) - x1, (i64)cord_y(ts.back()) - y1, T);
+        d2 = gmin3(x2 - (i64)cord_x(ts.back()), y2 - (i64)cord_y(ts.back()), T);
+    } else d1 = d2 = gmin3(x2 - x1, y2 - y1, T);
+    u64 head_str = gap_str, tail_end = gap_end, head_end = shift_cord(head_str, d1, d1), tail_str = shift_cord(tail_end, -d2, -d2);
+    remove_tile_sgn(head_str); remove_tile_sgn(tail_str); remove_tile_sgn(head_end);
+    set_tile_end(tail_str); set_tile_end(tail_end);
+    if (!ts.empty()) { copy_tile_sgn(ts.back(), tail_str); copy_tile_sgn(ts[0], head_str); remove_tile_sgn(ts.back()); remove_tile_sgn(ts[0]); }
+    if (direction != -1) ts.insert(0, &head_str, 1);
+    if (direction != 1) ts.push(tail_str);
+    if (te.empty()) {
+        te.resize(ts.n);
+        for (u32 i = 0; i < ts.n; i++) { i64 d = gmin3(x2 - (i64)cord_x(ts[i]), y2 - (i64)cord_y(ts[i]), T); te[i] = shift_cord(ts[i], d, d); }
+    } else {
+        if (direction != -1) te.insert(0, &head_end, 1);
+        if (direction != 1) te.push(tail_end);
+    }
+}
+LNR_HD inline int gap_insert_tiles1(GVec<u64> &cords, u32 &pos, GVec<u64> &tiles, int direction, int max_segs) {   // insert_tiles2Cords_ :3148-3238
+    if ((tiles.n < 2 && direction == 0) || tiles.empty()) return 1;
+    int segs = 0;
+    for (u32 i = 0; i < tiles.n; i++) if (is_tile_end(tiles[i])) { tiles[i] |= F_END; ++segs; }
+    if (segs > max_segs) return segs | (1 << 30);
+    u64 recd = cords[pos] & F_RECD;
+    for (u32 i = 0; i < tiles.n; i++) { u64 &t = tiles[i]; remove_tile_sgn(t); t &= ~F_MAIN; if (recd) t |= F_RECD; else t &= ~F_RECD; }   // set_tiles_cords_sgns :619-627
+    if (direction == -1) {
+        if (is_end(cords[pos])) tiles.back() |= F_END; else tiles.back() &= ~F_END;
+        cords[pos] = tiles.back(); tiles.n--;
+        cords.insert(pos, tiles.p, tiles.n);
+        pos += tiles.n;
+    } else if (direction == 1) {
+        u64 tmp = cords[pos];
+        cords[pos] = tiles[0];
+        cords.insert(pos + 1, tiles.p + 1, tiles.n - 1);
+        pos += tiles.n - 1;
+        if (is_end(tmp)) cords[pos] |= F_END; else cords[pos] &= ~F_END;
+    } else {
+        u64 tmp = cords[pos];
+        cords[pos - 1] = tiles[0];
+        cords[pos] = tiles.back();
+        if (is_end(tmp)) cords[pos] |= F_END; else cords[pos] &= ~F_END;
+        cords.insert(pos, tiles.p + 1, tiles.n - 2);
+        pos += tiles.n - 2;
+    }
+    tiles.clear();
+    return 0;
+}
+LNR_HD inline void gap_insert_tiles(GVec<u64> &cs, GVec<u64> &ce, u32 &pos, GVec<u64> &ts, GVec<u64> &te, int direction, int max_segs) {   // :3240-3268 (cords_end is never empty here)
+    u32 p2 = pos;
+    gap_insert_tiles1(cs, pos, ts, direction, max_segs);
+    gap_insert_tiles1(ce, p2, te, direction, max_segs);
+}
+template <class GX, class GY>
+LNR_HD inline IPair gap_chain_overlaps(const GVec<u64> &c1, const GVec<u64> &c2, GX getX, GY getY, const GapParms &gp) {   // getExtendsIntervalChainsOverlaps :3272-3315
+    IPair r;
+    if (c1.empty() || c2.empty()) { r.first = (int)c1.n; r.second = 0; return r; }
+    u64 x2 = getX(c2[0]), y2 = getY(c2[0]);
+    x2 = x2 > gp.thd_dcomx_err_dx ? x2 - gp.thd_dcomx_err_dx : 0;
+    y2 = y2 > gp.thd_dcomx_err_dy ? y2 - gp.thd_dcomx_err_dy : 0;
+    int i1 = 0;
+    for (int i = (int)c1.n - 1; i >= 0; i--) if (getX(c1[(u32)i]) < x2 && getY(c1[(u32)i]) < y2) { i1 = i + 1; break; }
+    u64 x1 = getX(c1[c1.n - 1]) + gp.thd_dcomx_err_dx, y1 = getY(c1[c1.n - 1]) + gp.thd_dcomx_err_dy;
+    x1 = (gp.ref_len - x1 > gp.thd_dcomx_err_dx) ? x1 + gp.thd_dcomx_err_dx : gp.ref_len;
+    y1 = (gp.read_len - y1 > gp.thd_dcomx_err_dy) ? y1 + gp.thd_dcomx_err_dy : gp.read_len;
+    int i2 = (int)c2.n;
+    for (int i = 0; i < (int)c2.n; i++) if (getX(c2[(u32)i]) > x1 && getY(c2[(u32)i]) > y1) { i2 = i; break; }
+    r.first = i1; r.second = i2;
+    return r;
+}
+// re-map with the small pattern along tiles[i_str, i_end) (mapAlongChain :3320-3377): the first resulting chain, as tiles
+LNR_HD inline int gap_map_along_chain(const GSeq &ref, const GSeq &seq2, const GVec<u64> &ch, GVec<u64> &tiles, int i_str, int i_end, int shape_len, int step1, int step2, GapCtx &X) {
+    if (ch.empty() || i_str < 0 || i_end > (int)ch.n || i_end <= i_str) return -1;
+    GVec<u64> hs, anc; hs.init(X.ar, 1024); anc.init(X.ar, 1024);
+    u64 a = ch[(u32)i_str], b = ch[(u32)i_end - 1];
+    i64 as = (i64)(cord_x(a) - cord_y(a)), ae = (i64)(cord_x(b) - cord_y(b));
+    c_stream(ref, hs, cord_x(a), cord_x(b), step1, shape_len, 0);
+    c_stream(seq2, hs, cord_y(a), cord_y(b), step2, shape_len, 1);
+    c_create_anchors2(hs, anc, (as < ae ? as : ae) - 30, (as > ae ? as : ae) + 30, X.ls->st);
+    ref_sort(anc.p, (long)anc.n, [](const u64 &p, const u64 &q) { return ganc_x(p) > ganc_x(q); }, X.ls->st);
+    stick_main_chain(anc, ch, X.gp.thd_smcn_danchor);
+    GVec<u64> first; first.init(X.ar, anc.n + 16);
+    // bestn 1: only the first chain is wanted; it is collected as anchors and turned into tiles below (chn_ext_clip_metric1: min length 1, abort 0)
+    gap_chain_anchors(anc.p, anc.n, first, false, 15, 30, 1, 1, 0, [](u64 p, u64 q) { return gap_clip_score(p, q); }, X);
+    int f_strand = (int)tile_strand(ch[0]);
+    for (u32 i = 0; i < first.n; i++) { u64 t = ganc_tile(first[i]); if (f_strand) t |= 1ULL << 61; tiles.push(t); }
+    return 0;
+}
+template <class GX, class GY>
+LNR_HD inline void gap_clip_overlaps_insdel2(GVec<u64> &c1, GVec<u64> &c2, int shape_len, GX getX, GY getY, GapCtx &X) {   // __extendsIntervalClipOverlapsInsDel_ :3382-3489
+    if (c1.empty() || c2.empty()) return;
+    const GapParms &gp = X.gp;
+    GVec<int> g11, g12, g21, g22; g11.init(X.ar); g12.init(X.ar); g21.init(X.ar); g22.init(X.ar);
+    gap_accumulate_score(c1, g11, shape_len, getX, gp); gap_accumulate_score(c1, g12, shape_len, getY, gp);
+    gap_accumulate_score(c2, g21, shape_len, getX, gp); gap_accumulate_score(c2, g22, shape_len, getY, gp);
+    gap_clip_chain_(c1, g11, g12, 1, true, gp);
+    gap_clip_chain_(c2, g21, g22, -1, true, gp);
+    int j1 = 0, j2 = 0, i_clip = 0, j_clip = -1, j1_pre = 0, j2_pre = 0, min_score = 0x7fffffff;
+    u64 x21 = getX(c2[0]), x22 = getX(c2[0]);
+    for (int i = 0; i < (int)c1.n; i++) {
+        u64 x1 = getX(c1[(u32)i]), lo = x1, up = x1 + gp.thd_eicos_clip_dxy;
+        for (int j = j1_pre; j < (int)c2.n && x21 < lo; j++) { x21 = getX(c2[(u32)j]); j1 = j; }
+        if (x21 > up) continue;
+        if (x21 < lo) break;
+        for (int j = j2_pre; j < (int)c2.n && x22 <= up; j++) { x22 = getX(c2[(u32)j]); j2 = j; }
+        if (x22 < lo) break;
+        if (j1 > j_clip || j2_pre != j2) {
+            int s11 = g11[(u32)i], s12 = g12[(u32)i];
+            for (int j = (j1 > j2_pre ? j1 : j2_pre); j < j2; j++) {
+                int s21 = g21[g21.n - 1] - g21[(u32)j], s22 = g22[g22.n - 1] - g22[(u32)j];
+                int s_con = (i64)(getX(c2[(u32)j]) - getX(c1[(u32)i])) > shape_len ? (int)((getX(c2[(u32)j]) - getX(c1[(u32)i]) - (u64)shape_len) * (u64)gp.int_precision) : 0;
+                int score = s11 + s12 + s21 + s22 + s_con;
+                if (score < min_score) { min_score = score; i_clip = i; j_clip = j; }
+            }
+        }
+        j1_pre = j1; j2_pre = j2;
+    }
+    c1.n = (u32)i_clip;
+    c2.erase(0, (u32)(j_clip < 0 ? 0 : j_clip));
+}
+template <class GX, class GY>
+LNR_HD inline void gap_clip_overlaps_insdel(GVec<u64> &c1, GVec<u64> &c2, int shape_len, GX getX, GY getY, GapCtx &X) {   // :3492-3522
+    if (c1.empty() && c2.empty()) return;
+    if (c1.empty()) gap_clip_chain(c2, shape_len, -1, true, getX, getY, X);
+    else if (c2.empty()) gap_clip_chain(c1, shape_len, 1, true, getX, getY, X);
+    else if (!X.gp.thd_eicos_f_as_ins) { gap_clip_chain(c1, shape_len, 1, true, getX, getY, X); gap_clip_chain(c2, shape_len, -1, true, getX, getY, X); }
+    else gap_clip_overlaps_insdel2(c1, c2, shape_len, getX, getY, X);
+}
+LNR_HD inline u64 gtx(u64 v) { return cord_x(v); }
+LNR_HD inline u64 gty(u64 v) { return cord_y(v); }
+LNR_HD inline void gap_map_overlaps(const GSeq &ref, GVec<u64> &t1, GVec<u64> &t2, u64 gap_str1, u64 gap_end2, int shape_len, int step1, int step2, GapCtx &X) {   // extendsIntervalMapOverlaps_ :3577-3639
+    drop_chain_gap_x(t1, 1, X.gp);
+    drop_chain_gap_x(t2, -1, X.gp);
+    GVec<u64> o1, o2; o1.init(X.ar); o2.init(X.ar);
+    IPair ov = gap_chain_overlaps(t1, t2, gtx, gty, X.gp);
+    if (!t1.empty()) gap_map_along_chain(ref, tile_strand(t1[0]) ? X.com : X.read, t1, o1, ov.first, (int)t1.n, shape_len, step1, step2, X);
+    if (!t2.empty()) gap_map_along_chain(ref, tile_strand(t2[0]) ? X.com : X.read, t2, o2, 0, ov.second, shape_len, step1, step2, X);
+    if (cord_x(gap_str1) - cord_y(gap_str1) > cord_x(gap_end2) - cord_y(gap_end2)) gap_clip_overlaps_insdel(o1, o2, shape_len, gtx, gty, X);
+    else gap_clip_overlaps_insdel(o1, o2, shape_len, gty, gtx, X);
+    t1.n = (u32)ov.first;
+    t1.append(o1);
+    t2.erase(0, (u32)ov.second);
+    t2.insert(0, o2.p, o2.n);
+}
+LNR_HD inline void gap_remap_chain_one_end(const GSeq &ref, GVec<u64> &ch, int shape_len, int step1, int step2, int remap_num, int direction, GapCtx &X) {   // remapChainOneEnd :3761-3812
+    if (!direction || ch.empty()) return;
+    const GSeq &seq2 = tile_strand(ch[0]) ? X.com : X.read;
+    GVec<u64> re; re.init(X.ar);
+    int i_str, i_end;
+    if (direction <= 0) { i_str = (int)ch.n - remap_num > 0 ? (int)ch.n - remap_num : 0; i_end = (int)ch.n; }
+    else { i_str = 0; i_end = (int)ch.n < remap_num ? (int)ch.n : remap_num; }
+    gap_map_along_chain(ref, seq2, ch, re, i_str, i_end, shape_len, step1, step2, X);
+    gap_clip_chain(re, shape_len, direction, true, gtx, gty, X);
+    if (direction <= 0) { ch.erase(0, (u32)i_end); ch.insert(0, re.p, re.n); }
+    else if (!re.empty()) { ch.n = (u32)i_str; ch.append(re); }
+}
+LNR_HD inline int gap_reextend_chain_one_side(const GSeq &ref, GVec<u64> &ch, int ips, int ipe, int lower, int upper, int shape_len, int step1, int step2, int direction, GapCtx &X) {   // :3832-3916
+    if (ch.empty() || ips < 0 || ipe < 0) return 0;
+    int ii, i_str, i_end, len = (int)ch.n;
+    GVec<u64> re; re.init(X.ar);
+    if (direction <= 0) {
+        i64 d = -gmin3((i64)cord_x(ch[(u32)ips]), (i64)cord_y(ch[(u32)ips]), (i64)lower);
+        for (ii = ips; ii < ipe; ii++) if ((i64)(cord_x(ch[(u32)ii]) - cord_x(ch[(u32)ips])) >= upper) break;
+        re.resize((u32)(ii - ips + 2));
+        re[0] = shift_cord(ch[(u32)ips], d, d);
+        for (int i = 0; i < ii - ips + 1; i++) re[(u32)i + 1] = ch[(u32)(ips + i)];
+        i_str = ips; i_end = ii + 1;
+    } else {
+        int d = (int)gmin3((i64)(ref.len - cord_x(ch[(u32)ipe]) - 1), (i64)(X.read.len - cord_y(ch[(u32)ipe]) - 1), (i64)upper);
+        for (ii = ipe; ii > ips; ii--) if ((i64)(cord_x(ch[(u32)ipe]) - cord_x(ch[(u32)ii])) >= lower) break;
+        re.resize((u32)(ipe - ii + 2));
+        for (int i = 0; i < ipe - ii + 1; i++) re[(u32)i] = ch[(u32)(ii + i)];
+        re.back() = shift_cord(ch[(u32)ipe], d, d);
+        i_str = ii; i_end = ipe + 1;
+    }
+    gap_remap_chain_one_end(ref, re, shape_len, step1, step2, (int)re.n, direction, X);
+    ch.erase((u32)i_str, (u32)i_end);
+    ch.insert((u32)i_str, re.p, re.n);
+    return (int)ch.n - len;
+}
+LNR_HD inline void gap_extend_interval_one_side(const GSeq &ref, GVec<u64> &tiles, u64 gap_str, u64 gap_end, int direction, GapCtx &X) {   // extendIntervalOneSide :3953-3983 + extendTilesOneSide :3920-3950
+    if (cord_strand(gap_str ^ gap_end)) return;
+    GapParms &gp = X.gp;
+    int od = gp.direction;
+    gp.direction = direction;
+    GVec<u64> g_hs, anc, chain; g_hs.init(X.ar, 2048); anc.init(X.ar, 2048); chain.init(X.ar, 256);
+    g_stream(ref, X.read, g_hs, gap_str, gap_end, (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2);
+    g_create_anchors(g_hs, anc, gp.thd_eis_shape_len, direction, 0, 0, X.read.len - 1, gap_str, gap_end, X);
+    g_chains_from_anchors(anc, chain, X.read.len, X);
+    closest_extension_chain(chain, gap_str, gap_end, true, gp);
+    gap_remap_chain_one_end(ref, chain, gp.thd_etfas_shape_len, gp.thd_etfas_step1, gp.thd_etfas_step2, 50, direction, X);
+    tiles_from_chain(chain, tiles, gap_str, gap_end, 0, (int)chain.n, X);
+    gap_trim_tiles(tiles, gap_str, gap_end, X.read.len - 1, direction, X);
+    gp.direction = od;
+}
+LNR_HD inline void gap_extend_result_filter(GVec<u64> &ts, GVec<u64> &te, u64 gap_str, u64 gap_end, int direction, const GapParms &gp) {   // mapExtendResultFilter_ :3986-4031
+    if (direction >= 0) {
+        u64 pre = gap_str;
+        for (int i = 0; i < (int)ts.n; i++) {
+            i64 dy = (i64)(cord_y(ts[(u32)i]) - cord_y(pre)), dx = (i64)(cord_y(ts[(u32)i]) - cord_x(pre));   // (y - x: as in the reference)
+            if (dy > gp.thd_me_reject_gap || dx > gp.thd_me_reject_gap) { ts.n = (u32)i; if (!te.empty()) te.erase((u32)i, te.n); break; }
+            pre = ts[(u32)i];
+        }
+    }
+    if (direction <= 0) {
+        u64 pre = gap_end;
+        for (int i = (int)ts.n - 1; i >= 0; i--) {
+            i64 dy = (i64)(cord_y(pre) - cord_y(ts[(u32)i])), dx = (i64)(cord_y(pre) - cord_x(ts[(u32)i]));
+            if (dy > gp.thd_me_reject_gap || dx > gp.thd_me_reject_gap) { ts.erase(0, (u32)i + 1); if (!te.empty()) te.erase(0, (u32)i + 1); break; }
+            pre = ts[(u32)i];
+        }
+    }
+}
+LNR_HD inline void gap_map_extend(const GSeq &ref, GVec<u64> &ts, GVec<u64> &te, u64 gap_str, u64 gap_end, int direction, GapCtx &X) {   // mapExtend :4035-4069
+    GapParms &gp = X.gp;
+    float rate0 = gp.thd_gmsa_d_anchor_rate;
+    gp.direction = direction; gp.thd_ctfas2_connect_danchor = 50; gp.thd_ctfas2_connect_dy_dx = 150; gp.thd_cts_major_limit = 3; gp.thd_gmsa_d_anchor_rate = 0.25f;
+    gap_extend_interval_one_side(ref, ts, gap_str, gap_end, direction, X);
+    gap_extend_result_filter(ts, te, gap_str, gap_end, direction, gp);
+    if (!ts.empty() && direction >= 0) ts.back() &= ~TILE_END;
+    gap_reform_tiles(ts, te, gap_str, gap_end, direction, gp);
+    gp.thd_gmsa_d_anchor_rate = rate0;
+}
+LNR_HD inline void gap_map_extends(const GSeq &ref, GVec<u64> &ts1, GVec<u64> &te1, GVec<u64> &ts2, GVec<u64> &te2, u64 gs1, u64 ge1, u64 gs2, u64 ge2, GapCtx &X) {   // mapExtends :4073-4125 + extendsInterval :3696-3757
+    GapParms &gp = X.gp;
+    gp.thd_ctfas2_connect_danchor = 50; gp.thd_ctfas2_connect_dy_dx = 150; gp.thd_cts_major_limit = 3;
+    int od = gp.direction, oclip = gp.f_rfts_clip;
+    gp.f_rfts_clip = 0;
+    if (!(cord_strand(gs1 ^ ge1) || cord_strand(gs2 ^ ge2) || cord_strand(gs1 ^ gs2))) {
+        GVec<u64> g_hs, a1, a2, tmp1, tmp2; g_hs.init(X.ar, 2048); a1.init(X.ar, 2048); a2.init(X.ar, 2048); tmp1.init(X.ar, 256); tmp2.init(X.ar, 256);
+        u64 id = cord_id(gs1), strand = cord_strand(gs1);
+        u64 x1 = cord_x(gs1) < cord_x(gs2) ? cord_x(gs1) : cord_x(gs2), y1 = cord_y(gs1) < cord_y(gs2) ? cord_y(gs1) : cord_y(gs2);
+        u64 x2 = cord_x(ge1), y2 = cord_y(ge1) > cord_y(ge2) ? cord_y(ge1) : cord_y(ge2);                   // (x of gap_end1 twice in the reference)
+        g_stream(ref, X.read, g_hs, create_cord(id, x1, y1, strand), create_cord(id, x2, y2, strand), (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2);
+        g_create_anchor_pair(g_hs, a1, a2, gp.thd_eis_shape_len, X.read.len - 1, gs1, ge1, gs2, ge2, X);
+        int od2 = gp.direction;                                                                             // extendsTilesFromAnchors :3643-3692
+        gp.direction = 1;
+        g_chains_from_anchors(a1, tmp1, X.read.len, X);
+        closest_extension_chain(tmp1, gs1, ge1, true, gp);
+        gp.direction = -1;
+        g_chains_from_anchors(a2, tmp2, X.read.len, X);
+        closest_extension_chain(tmp2, gs2, ge2, true, gp);
+        gap_map_overlaps(ref, tmp1, tmp2, gs1, ge2, gp.thd_etfas_shape_len, gp.thd_etfas_step1, gp.thd_etfas_step2, X);
+        tiles_from_chain2(tmp1, ts1, te1, gs1, ge1, 0, (int)tmp1.n, X);
+        tiles_from_chain2(tmp2, ts2, te2, gs2, ge2, 0, (int)tmp2.n, X);
+        gp.direction = od2;
+    }
+    gp.direction = 1;
+    gap_extend_result_filter(ts1, te1, gs1, ge1, 1, gp);
+    if (!ts1.empty()) ts1.back() &= ~TILE_END;
+    gap_reform_tiles(ts1, te1, gs1, ge1, 1, gp);
+    gp.direction = -1;
+    gap_extend_result_filter(ts2, te2, gs2, ge2, -1, gp);
+    gap_reform_tiles(ts2, te2, gs2, ge2, -1, gp);
+    gp.direction = od;
+    gp.f_rfts_clip = oclip;
+}
+LNR_HD inline int gap_reextend_clip_one_side(const GSeq &ref, GVec<u64> &ch, u64 lo_c, u64 up_c, int ips, int ipe, int direction, GapCtx &X) {   // reExtendClipOneSide :4129-4168
+    if (ch.empty() || ips < 0 || ipe < 0) return 0;
+    int lower = 60, upper = 60;
+    if (direction <= 0) {
+        int dx = (int)(cord_x(ch[(u32)ips]) - cord_x(lo_c));
+        int dy = (tile_strand(ch[(u32)ips]) ^ tile_strand(lo_c)) ? (int)(cord_y(up_c) - X.read.len + cord_y(ch[(u32)ips])) : (int)(cord_y(ch[(u32)ips]) - cord_y(lo_c));
+        lower = gmin3(dx, dy, lower);
+    } else {
+        int dx = (int)(cord_x(up_c) - 1 - cord_x(ch[(u32)ipe]));
+        int dy = (tile_strand(ch[(u32)ipe]) ^ tile_strand(up_c)) ? (int)(X.read.len - 1 - cord_y(ch[(u32)ipe]) - cord_y(lo_c)) : (int)(cord_y(up_c) - cord_y(ch[(u32)ipe]));
+        upper = gmin3(dx, dy, upper);
+    }
+    return gap_reextend_chain_one_side(ref, ch, ips, ipe, lower, upper, X.gp.thd_etfas_shape_len, X.gp.thd_etfas_step1, X.gp.thd_etfas_step2, direction, X);
+}
+LNR_HD inline void gap_tiles_from_anchors2(const GSeq &ref, GVec<u64> &anchors, GVec<u64> &ts, GVec<u64> &te, u64 gap_str, u64 gap_end, u64 read_len, GapCtx &X) {   // createTilesFromAnchors2_ :4171-4247
+    GVec<u64> tmp; tmp.init(X.ar, 256);
+    g_chains_from_anchors(anchors, tmp, read_len, X);
+    int pre_i = 0;
+    for (int i = 0; i < (int)tmp.n; i++) {
+        bool blk_end = is_tile_end(tmp[(u32)i]) != 0;
+        bool flip = !blk_end && i < int(tmp.n - 1) && tile_strand(tmp[(u32)i] ^ tmp[(u32)i + 1]);
+        if (!blk_end && !flip) continue;
+        u32 len0 = ts.n;
+        u64 head = tmp[(u32)pre_i], tail = tmp[(u32)i];
+        i += gap_reextend_clip_one_side(ref, tmp, gap_str, gap_end, pre_i, i, -1, X);
+        i += gap_reextend_clip_one_side(ref, tmp, gap_str, gap_end, pre_i, i, 1, X);
+        if (!(tmp.empty() || pre_i < 0 || i < 0)) {
+            copy_tile_sgn(head, tmp[(u32)pre_i]);
+            copy_tile_sgn(tail, tmp[(u32)i]);
+            tiles_from_chain2(tmp, ts, te, gap_str, gap_end, pre_i, i + 1, X);
+            if (flip && len0 != ts.n) { ts.back() &= ~TILE_END; te.back() &= ~TILE_END; }
+        }
+        pre_i = i + 1;
+    }
+}
+LNR_HD inline void gap_filter_anchors(GVec<u64> &a, GapCtx &X) {                            // filterGapAnchors gap_util.cpp:4275-4441 (density 20, accept 20, err bit 0)
+    GVec<UP> list; list.init(X.ar);
+    if (a.n > 1) {
+        a[0] = 0;
+        ref_sort(a.p, (long)a.n, [](const u64 &p, const u64 &q) { return ganc_stranchor(p) < ganc_stranchor(q); }, X.ls->st);
+        u64 ak2 = a[1], block_str = 1, count = 0, min_y = ~0ULL, max_y = 0;
+        for (u32 i = 1; i < a.n; i++) {
+            u64 y = ganc_y(a[i]);
+            u64 dy2 = (u64)gabs((i64)(y - ganc_y(ak2)));
+            bool cont = ganc_stranchor(a[i]) - ganc_stranchor(ak2) < dy2;
+            if (cont) { if (min_y > y) min_y = y; if (max_y < y) max_y = y; ak2 = a[(u32)((block_str + i) >> 1)]; ++count; }
+            if (!cont || i == a.n - 1) {
+                u64 acc = ((max_y - min_y) * 20) >> 10; if (acc < 20) acc = 20;
+                if (count > acc) { UP e; e.first = block_str; e.second = i; list.push(e); }
+                block_str = i; ak2 = a[i]; min_y = y; max_y = y; count = 1;
+            }
+        }
+    }
+    if (!list.empty()) {
+        ref_sort(list.p, (long)list.n, [](const UP &p, const UP &q) { return (u32)(p.second - p.first) > (u32)(q.second - q.first); }, X.ls->st);
+        if (a.n > 1000 && list.n > 10) {
+            u32 im = list.n / 2, lm = (u32)(list[im].second - list[im].first), lx = (u32)(list[0].second - list[0].first);
+            if ((float)lx > (float)lm * 1.5f && lx > lm + 20) {
+                u32 it = 0, ls_ = 0, li = 0;
+                u64 brk = (u64)((float)lm * 1.5f);
+                for (u32 i = 0; i < (list.n < 5 ? list.n : 5u); i++) { it++; li = (u32)(list[i].second - list[i].first); ls_ += li; if (li < brk || ls_ > 2000) break; }
+                list.n = it;
+            } else list.clear();
+        }
+    }
+    u32 it = 0;
+    for (u32 i = 0; i < list.n; i++) for (u64 j = list[i].first; j < list[i].second; j++) a[it++] = a[(u32)j];
+    a.n = it;
+}
+LNR_HD inline void gap_map_generic(const GSeq &ref, GVec<u64> &ts, GVec<u64> &te, u64 gap_str, u64 gap_end, GapCtx &X) {   // mapGeneric :4492-4515 over mapInterval :4444-4489
+    int oclip = X.gp.f_rfts_clip;
+    X.gp.f_rfts_clip = 0;
+    if (!cord_strand(gap_str ^ gap_end)) {
+        GVec<u64> g_hs, anc; g_hs.init(X.ar, 2048); anc.init(X.ar, 2048);
+        g_stream(ref, X.read, g_hs, gap_str, gap_end, 9, 5, 1);
+        g_create_anchors(g_hs, anc, 9, 0, -(((i64)1 << 62) - 1), ((i64)1 << 62) - 1, X.read.len - 1, gap_str, gap_end, X);
+        if (anc.n > 1000) gap_filter_anchors(anc, X);
+        gap_tiles_from_anchors2(ref, anc, ts, te, gap_str, gap_end, X.read.len - 1, X);
+    }
+    gap_reform_tiles(ts, te, gap_str, gap_end, 0, X.gp);
+    X.gp.f_rfts_clip = oclip;
+}
+
+// =================================================================== mapGap_, mapGaps, reformCords ====
+LNR_HD inline void gvec_cat(GVec<u64> &d, const GVec<u64> &s) { d.insert(d.n, s.p, s.n); }
+// the addon of mapGap_: mapGeneric between two tiles, its inner tiles spliced in before tiles_str[i] (gap.cpp:232-271, :303-362)
+LNR_HD inline u32 gap_splice_generic(const GSeq &ref, GVec<u64> &ts, GVec<u64> &te, u32 i, u64 from, u64 to, bool dup_marks, GapCtx &X) {
+    u64 m = X.ar->mark();
+    GVec<u64> t1, e1; t1.init(X.ar, 64); e1.init(X.ar, 64);
+    gap_map_generic(ref, t1, e1, from, to, X);
+    u32 added = 0;
+    if (!t1.empty()) {
+        t1.erase(0, 1); e1.erase(0, 1);
+        t1.n--; e1.n--;
+        if (!t1.empty()) {
+            remove_tile_sgn(t1.back()); remove_tile_sgn(e1.back());
+            if (dup_marks) {
+                if (cord_x(t1[0]) < cord_x(ts[i - 1])) { set_tile_end(ts[i - 1]); set_tile_end(te[i - 1]); }
+                if (cord_x(t1.back()) > cord_x(ts[i])) { set_tile_end(t1.back()); set_tile_end(e1.back()); }
+            }
+            ts.insert(i, t1.p, t1.n);
+            te.insert(i, e1.p, e1.n);
+        }
+        added = t1.n;
+    }
+    X.ar->release(m);
+    return added;
+}
+// map the gap [gap_str, gap_end) (mapGap_ gap.cpp:16-395).  tiles_str / tiles_end live in an arena of their own (the caller's): the
+// temporaries of this gap are released from X.ar on return.
+LNR_HD inline int gap_map_gap(u64 gap_str, u64 gap_end, GVec<u64> &tiles_str, GVec<u64> &tiles_end, int direction, GapCtx &X) {
+    GapParms &gp = X.gp;
+    tiles_str.clear(); tiles_end.clear();
+    gap_str &= ~F_END; gap_end &= ~F_END;
+    remove_tile_sgn(gap_str); remove_tile_sgn(gap_end);
+    GSeq ref = X.ref(cord_id(gap_str));
+    i64 ref_len = (i64)ref.len, read_len = (i64)X.read.len;
+    i64 x1 = (i64)cord_x(gap_str), x2 = (i64)cord_x(gap_end), y1 = (i64)cord_y(gap_str), y2 = (i64)cord_y(gap_end), shift_x, shift_y, T = gp.thd_tile_size;
+    u64 m0 = X.ar->mark();
+    if (x1 + T > ref_len - 1 || y1 + T > read_len - 1 || x2 > ref_len - 1 || y2 > read_len - 1 || x2 < T || y2 < T) return 0;
+    else if (cord_strand(gap_str ^ gap_end)) {
+        if (direction != 0) return -1;
+        const i64 ext1 = 500, ext2 = 5000;
+        GVec<u64> ts1, ts2, te1, te2; ts1.init(X.ar, 64); ts2.init(X.ar, 64); te1.init(X.ar, 64); te2.init(X.ar, 64);
+        shift_x = (x2 - x1 > 0) ? gmin3(ext2, (i64)(ref.len - 1 - cord_x(gap_str)), x2 - x1) : ext1;
+        shift_y = (i64)((float)(x2 - x1) * (1 + gp.thd_err));
+        if (shift_y > (i64)(X.read.len - 1 - cord_y(gap_str))) shift_y = (i64)(X.read.len - 1 - cord_y(gap_str));
+        if (shift_x < 0) shift_x = 0;
+        if (shift_y < 0) shift_y = 0;
+        gap_map_extend(ref, ts1, te1, gap_str, shift_cord(gap_str, shift_x, shift_y), 1, X);
+        shift_x = (x2 - x1 > 0) ? gmin3(x2 - x1, (i64)cord_x(gap_end), ext2) : ext1;
+        shift_y = (i64)((float)(x2 - x1) * (1 + gp.thd_err));
+        if (shift_y > (i64)cord_y(gap_end)) shift_y = (i64)cord_y(gap_end);
+        if (shift_x < 0) shift_x = 0;
+        if (shift_y < 0) shift_y = 0;
+        gap_map_extend(ref, ts2, te2, shift_cord(gap_end, -shift_x, -shift_y), gap_end, -1, X);
+        if (!ts1.empty()) { gvec_cat(tiles_str, ts1); gvec_cat(tiles_end, te1); }
+        if (!ts2.empty()) { gvec_cat(tiles_str, ts2); gvec_cat(tiles_end, te2); }
+    } else if (x1 + T > x2 || y1 + T > y2) return 0;
+    else if (y1 < y2) {
+        i64 danc = x1 - x2 - y1 + y2;
+        if (gabs(danc) > gp.thd_mg1_danc_indel && direction == 0) {
+            int f_extends = 1;
+            int s1m = gp.chn1_min_len, s1a = gp.chn1_abort, s1f = gp.chn1_fn, s2m = gp.chn2_min_len, s2a = gp.chn2_abort, s2f = gp.chn2_fn;
+            gp.chn1_min_len = 1; gp.chn1_abort = 0; gp.chn1_fn = 2; gp.chn2_abort = 0; gp.chn2_fn = 3;
+            GVec<u64> ts1, ts2, te1, te2; ts1.init(X.ar, 64); ts2.init(X.ar, 64); te1.init(X.ar, 64); te2.init(X.ar, 64);
+            u64 gs1 = 0, gs2 = 0, ge1 = 0, ge2 = 0;
+            i64 dyy = y2 - y1 > 0 ? y2 - y1 : 0, dxx = x2 - x1 > 0 ? x2 - x1 : 0, E = gp.thd_max_extend2;
+            if (danc > 0) {
+                shift_y = gmin3(dyy, E, (i64)(X.read.len - y1 - 1));
+                shift_x = gmin3((i64)((float)shift_y * (1 + gp.thd_err)), E, (i64)(ref.len - x1 - 1));
+                gs1 = gap_str; ge1 = shift_cord(gap_str, shift_x, shift_y);
+                shift_y = gmin3(dyy, E, y2);
+                shift_x = gmin3((i64)((float)shift_y * (1 + gp.thd_err)), E, x2);
+                gs2 = shift_cord(gap_end, -shift_x, -shift_y); ge2 = gap_end;
+                f_extends = x1 < x2 ? 1 : 2;
+            } else if (x1 < x2) {
+                shift_x = gmin3(dxx, E, (i64)(ref.len - x1 - 1));
+                shift_y = gmin3((i64)((float)shift_x * (1 + gp.thd_err)), E, (i64)(X.read.len - y1 - 1));
+                gs1 = gap_str; ge1 = shift_cord(gap_str, shift_x, shift_y);
+                shift_x = gmin3(dxx, E, x2);
+                shift_y = gmin3((i64)((float)shift_x * (1 + gp.thd_err)), E, y2);
+                gs2 = shift_cord(gap_end, -shift_x, -shift_y); ge2 = gap_end;
+                f_extends = 1;
+            } else f_extends = 0;
+            if (f_extends) {
+                if (f_extends == 1) gap_map_extends(ref, ts1, te1, ts2, te2, gs1, ge1, gs2, ge2, X);
+                else { gap_map_extend(ref, ts1, te1, gs1, ge1, 1, X); gap_map_extend(ref, ts2, te2, gs2, ge2, -1, X); }
+                if (!ts1.empty()) { gvec_cat(tiles_str, ts1); gvec_cat(tiles_end, te1); remove_tile_sgn(tiles_str.back()); remove_tile_sgn(tiles_end.back()); }
+                if (!ts2.empty()) { remove_tile_sgn(ts2[0]); remove_tile_sgn(te2[0]); gvec_cat(tiles_str, ts2); gvec_cat(tiles_end, te2); }
+            }
+            gp.chn1_min_len = s1m; gp.chn1_abort = s1a; gp.chn1_fn = s1f; gp.chn2_min_len = s2m; gp.chn2_abort = s2a; gp.chn2_fn = s2f;
+        }
+    }
+    X.ar->release(m0);
+    u64 v = gap_str; tiles_str.insert(0, &v, 1);
+    v = shift_cord(gap_str, 1, 1); tiles_end.insert(0, &v, 1);
+    tiles_str.push(shift_cord(gap_end, -1, -1));
+    tiles_end.push(gap_end);
+    for (u32 i = 1; i < tiles_str.n; i++) {                                                     // addon 1: what is still open between consecutive tiles
+        i64 dx = (i64)(cord_x(tiles_str[i]) - cord_x(tiles_end[i - 1])), dy = (i64)(cord_y(tiles_str[i]) - cord_y(tiles_end[i - 1]));
+        if (tile_strand(tiles_str[i] ^ tiles_str[i - 1])) continue;
+        if (dx > 90 && dy > 90) i += gap_splice_generic(ref, tiles_str, tiles_end, i, tiles_str[i - 1], tiles_str[i], false, X);
+    }
+    if (gp.f_dup) {                                                                              // addon 2: duplications (-dup 1)
+        const float rate = 0.1f;
+        for (u32 i = 1; i < tiles_str.n; i++) {
+            if (tile_strand(tiles_str[i] ^ tiles_str[i - 1]) || is_tile_end(tiles_str[i - 1])) continue;
+            i64 xa = (i64)cord_x(tiles_end[i - 1]), ya = (i64)cord_y(tiles_end[i - 1]), xb = (i64)cord_x(tiles_str[i]), yb = (i64)cord_y(tiles_str[i]);
+            i64 dx = xb - xa, dy = yb - ya;
+            if (dy > 100 && dy - dx > gp.thd_mg1_danc_indel) {
+                i64 w = (i64)((float)dy * (1 + rate));
+                i64 e1 = -(w < xa ? w : xa), lim = (i64)(ref.len - (u64)xb - 1), e2 = w < lim ? w : lim;
+                i += gap_splice_generic(ref, tiles_str, tiles_end, i, shift_cord(tiles_end[i - 1], e1, 0), shift_cord(tiles_str[i], e2, 0), true, X);
+            }
+        }
+    }
+    for (int i = 1; i < (int)tiles_str.n - 1; i++) { tiles_str[(u32)i - 1] = tiles_str[(u32)i]; tiles_end[(u32)i - 1] = tiles_end[(u32)i]; }
+    tiles_str.n -= 2; tiles_end.n -= 2;
+    return 0;
+}
+LNR_HD inline i64 gap_max_gapsy_overlap(const UP *gapsy, u32 n, u64 gap_str, u64 gap_end) {   // _getMaxGapsyOverlap gap_util.cpp:343-362
+    i64 gs = (i64)cord_y(gap_str), ge = (i64)cord_y(gap_end);
+    for (u32 i = 0; i < n; i++) {
+        i64 ys = (i64)gapsy[i].first, ye = (i64)gapsy[i].second;
+        if (gs >= ys && gs <= ye) return (ge < ye ? ge : ye) - gs;
+        else if (ge >= ys && ge <= ye) return ge - (gs > ys ? gs : ys);
+    }
+    return 0;
+}
+// re-map the gaps of one read's cords, the ends of the read included (mapGaps gap.cpp:407-576).  cs / ce and the tile lists live in
+// `keep`; X.ar is the scratch of one gap.
+LNR_HD inline int gap_map_gaps(GVec<u64> &cs, GVec<u64> &ce, GArena &keep, GapCtx &X) {
+    if (cs.n <= 1) return 0;
+    GapParms &gp = X.gp;
+    GVec<u64> tiles_str, tiles_end; tiles_str.init(&keep, 256); tiles_end.init(&keep, 256);
+    const int max_segs = 1000;
+    const u64 max_extend = 2000;
+    const i64 max_gap = 3000, extend_xy = 3;
+    i64 block_size = gp.thd_tile_size, cord_gap = gp.thd_gap_len_min + block_size;
+    u64 L = X.read.len;
+    int ovf = 0;
+    u32 cap = cs.n + 2;
+    Vec<UP> str_ends, sep, gaps;
+    str_ends.init((UP *)keep.get((u64)cap * sizeof(UP)), cap, &ovf);
+    sep.init((UP *)keep.get((u64)cap * sizeof(UP)), cap, &ovf);
+    gaps.init((UP *)keep.get((u64)(cap + 2) * sizeof(UP)), cap + 2, &ovf);
+    if (keep.ovf) return 1;
+    gather_blocks(cs.p, cs.n, &str_ends, sep, 1, cs.n, L, (u64)cord_gap, (u64)block_size, 0);
+    gather_gaps_y(str_ends.p, str_ends.n, gaps, L, (u64)cord_gap, *X.ls);
+    for (u32 i = 1; i < cs.n; i++) {
+        u64 slen = X.seq_len[cord_id(cs[i])];
+        gp.read_len = L; gp.ref_len = slen;
+        if (is_end(cs[i - 1])) {                                                                 // the block's first cord: towards the read's start
+            i64 sx = (i64)(slen - 1 - cord_x(cs[i])), sy = (i64)(L - 1 - cord_y(cs[i]));
+            if (sx > block_size) sx = block_size;
+            if (sy > block_size) sy = block_size;
+            u64 gap_end = shift_cord(cs[i], sx, sy);
+            if ((i64)cord_y(gap_end) > cord_gap) {
+                sx = (i64)umin64(max_extend, cord_x(gap_end)); sy = (i64)umin64(max_extend, cord_y(gap_end));
+                if (sx > sy * extend_xy) sx = sy * extend_xy;
+                u64 gap_str = shift_cord(gap_end, -sx, -sy);
+                gap_str &= ~F_END; gap_end &= ~F_END; remove_tile_sgn(gap_str); remove_tile_sgn(gap_end);
+                if (gap_max_gapsy_overlap(gaps.p, gaps.n, gap_str, gap_end) > cord_gap) {
+                    gap_map_gap(gap_str, gap_end, tiles_str, tiles_end, -1, X);
+                    gap_insert_tiles(cs, ce, i, tiles_str, tiles_end, -1, max_segs);
+                }
+            }
+        } else if (!consecutive(cs[i - 1], cs[i], (u64)cord_gap)) {
+            i64 sx = (i64)(slen - 1 - cord_x(cs[i])), sy = (i64)(L - 1 - cord_y(cs[i]));
+            if (sx > block_size) sx = block_size;
+            if (sy > block_size) sy = block_size;
+            if (!is_end(cs[i]) && !cord_strand(cs[i] ^ cs[i + 1])) {
+                i64 a = (i64)(cord_x(cs[i + 1]) - cord_x(cs[i])), b = (i64)(cord_y(cs[i + 1]) - cord_y(cs[i]));
+                if (a < sx) sx = a;
+                if (b < sy) sy = b;
+            }
+            u64 gap_str = cs[i - 1], gap_end = shift_cord(cs[i], sx, sy);
+            if (gabs((i64)(cord_x(gap_end) - cord_x(gap_str))) < max_gap) {
+                gap_str &= ~F_END; gap_end &= ~F_END; remove_tile_sgn(gap_str); remove_tile_sgn(gap_end);
+                gap_map_gap(gap_str, gap_end, tiles_str, tiles_end, 0, X);
+                gap_insert_tiles(cs, ce, i, tiles_str, tiles_end, 0, max_segs);
+            }
+        }
+        if (is_end(cs[i])) {                                                                     // the block's last cord: towards the read's end
+            u64 gap_str = cs[i];
+            if ((i64)(L - 1 - cord_y(gap_str)) > cord_gap) {
+                i64 sx = (i64)umin64(max_extend, slen - cord_x(gap_str) - 1), sy = (i64)umin64(max_extend, L - cord_y(gap_str) - 1);
+                if (sx > sy * extend_xy) sx = sy * extend_xy;
+                u64 gap_end = shift_cord(gap_str, sx, sy);
+                gap_str &= ~F_END; gap_end &= ~F_END; remove_tile_sgn(gap_str); remove_tile_sgn(gap_end);
+                if (gap_max_gapsy_overlap(gaps.p, gaps.n, gap_str, gap_end) > cord_gap) {
+                    gap_map_gap(gap_str, gap_end, tiles_str, tiles_end, 1, X);
+                    gap_insert_tiles(cs, ce, i, tiles_str, tiles_end, 1, max_segs);
+                }
+            }
+        }
+        if (X.ar->ovf || keep.ovf) return 1;
+    }
+    return ovf;
+}
+// ---- reformCords with reformCordsDxDy1 (cords.cpp:504-687)
+LNR_HD inline int gap_scale_dxdy(i64 &dx, i64 &d1, i64 &dy, i64 &d2) {                        // :562-585
+    if (dx * dy >= 0 && d1 * d2 >= 0 && dx * d1 >= 0 && (dx || dy || d1 || d2)) {
+        i64 c1 = gabs(d1 * dy), c2 = gabs(d2 * dx);
+        if (c1 > c2) { if (dx != 0) d2 = d1 * dy / dx; }
+        else if (c1 < c2) { if (dy != 0) d1 = d2 * dx / dy; }
+        return 0;
+    }
+    return 1;
+}
+LNR_HD inline void gap_scale_region(u64 &c_str, u64 &c_end, i64 d11, i64 d12, i64 d21, i64 d22) {   // :591-603
+    i64 dx = (i64)(cord_x(c_end) - cord_x(c_str)), dy = (i64)(cord_y(c_end) - cord_y(c_str));
+    gap_scale_dxdy(dx, d11, dy, d12);
+    gap_scale_dxdy(dx, d21, dy, d22);
+    u64 ns = shift_cord(c_str, d11, d12), ne = shift_cord(c_end, d21, d22);
+    c_str = ns; c_end = ne;
+}
+LNR_HD inline void gap_reform_cords(GVec<u64> &cs, GVec<u64> &ce) {
+    if (cs.n != ce.n) return;
+    const i64 min_dx = -20, min_dy = -20;                                                        // CordsParms cords.h:45-46
+    u32 it = 1;
+    while (it < cs.n) {
+        u32 i1 = it - 1, i2 = it;
+        u64 c11 = cs[i1], c12 = ce[i1], c21 = cs[i2], c22 = ce[i2];
+        i64 dx1 = (i64)(cord_x(c21) - cord_x(c11)), dy1 = (i64)(cord_y(c21) - cord_y(c11));
+        if (cord_x(cs[it]) > cord_x(ce[it]) || cord_y(cs[it]) > cord_y(ce[it])) {
+            if (is_end(cs[it])) { cs[it - 1] |= F_END; ce[it - 1] |= F_END; }
+            cs.erase(it, it + 1);
+            ce.erase(it, it + 1);
+        } else if (cord_strand(c11 ^ c22) || is_end(c11)) ++it;
+        else if ((dx1 < 0 && dx1 > min_dx) || (dy1 < 0 && dy1 > min_dy)) {
+            u64 lower, upper;
+            if (i1 == 0 || is_end(cs[i1 - 1])) lower = 0;
+            else if (cord_strand(cs[i1] ^ cs[i1 - 1])) lower = cs[i1];
+            else lower = cs[i1 - 1];
+            if (i2 == cs.n - 1 || is_end(cs[i2])) upper = ce[i2];
+            else if (cord_strand(cs[i2] ^ cs[i2 + 1])) upper = ce[i2];
+            else upper = cs[i2 + 1];
+            i64 sx = (dx1 - 1) / 2 < 0 ? (dx1 - 1) / 2 : 0, sy = (dy1 - 1) / 2 < 0 ? (dy1 - 1) / 2 : 0;
+            gap_scale_region(c11, c12, sx, sy, 0, 0);
+            gap_scale_region(c21, c22, -sx, -sy, 0, 0);
+            u64 x11 = cord_x(c11), y11 = cord_y(c11), x21 = cord_x(c21), y21 = cord_y(c21);
+            if (x11 <= cord_x(c12) && x11 > cord_x(lower) && y11 <= cord_y(c12) && y11 > cord_y(lower) && x21 <= cord_x(c22) && x21 < cord_x(upper) && y21 <= cord_y(c22) &&
+                y21 < cord_y(upper)) {
+                cs[i1] = c11; ce[i1] = c12; cs[i2] = c21; ce[i2] = c22;
+            }
+            ++it;
+        } else ++it;
+    }
+}
+
 }  // namespace lnr

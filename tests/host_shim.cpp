@@ -3,6 +3,7 @@
 // without a GPU.  It is compiled by tests/ into tests/_build/libhost_shim.so and is never
 // part of the shipped library: the product path runs these same functions inside HIP
 // kernels only (linear_amd/csrc/lnr_kernels.hip).
+#include <memory>
 #include <vector>
 #include <algorithm>
 #include <cstring>
@@ -255,12 +256,13 @@ void hs_get_stats(void *h, u64 *out5) { memcpy(out5, ((Shim *)h)->stats, 40); }
 // ---- the product's gap path (lnr_gap_hd.h) on the host, hook for hook like the oracle's orc_gap_* (tests/test_gap_shim_cpu.py)
 namespace {
 struct GapHost {
-    std::vector<char> mem; GArena ar; LeaderScratch ls; std::vector<u8> g, r, c; GapCtx X;
-    GapHost(const u8 *gp_, u64 glen, const u8 *rp, u64 rlen) : mem((size_t)64 << 20), g(glen + PAD, 0), r(rlen + PAD, 0), c(rlen + PAD, 0) {
+    static const size_t M1 = (size_t)64 << 20;
+    std::unique_ptr<char[]> mem; GArena ar; LeaderScratch ls; std::vector<u8> g, r, c; GapCtx X;
+    GapHost(const u8 *gp_, u64 glen, const u8 *rp, u64 rlen) : mem(new char[M1]), g(glen + PAD, 0), r(rlen + PAD, 0), c(rlen + PAD, 0) {
         memcpy(g.data(), gp_, glen); memcpy(r.data(), rp, rlen);
         static const u8 cpl[5] = {3, 2, 1, 0, 4};
         for (u64 k = 0; k < rlen; k++) c[k] = cpl[r[rlen - k - 1] > 4 ? 4 : r[rlen - k - 1]];
-        ar.init(mem.data(), mem.size());
+        ar.init(mem.get(), M1);
         X.ar = &ar; X.ls = &ls; X.read.p = r.data(); X.read.len = rlen; X.com.p = c.data(); X.com.len = rlen;
         X.g = g.data(); so = 0; sl = glen; X.seq_off = &so; X.seq_len = &sl;
     }
@@ -302,6 +304,65 @@ u64 hs_gap_chains(const u64 *anchors, u64 n, u64 read_len, int alt, int directio
     g_chains_from_anchors(a, tiles, read_len, H.X);
     if (closest) { IPair r = closest_extension_chain(tiles, gap_str, gap_end, closest == 2, H.X.gp); pr[0] = r.first; pr[1] = r.second; }
     return H.ar.ovf ? ~0ULL : out64(tiles, out, cap);
+}
+// ---- the whole gap layer on a Shim context (genome + f2 from hs_create): hs_gap_map = orc_gap_map, hs_map_read_g = orc_map_read_g
+namespace {
+struct GapRead {
+    static const size_t M1 = (size_t)256 << 20, M2 = (size_t)64 << 20;
+    std::unique_ptr<char[]> mem, mem2; GArena ar, keep; LeaderScratch ls; std::vector<u8> g, r, c; std::vector<u64> so, sl; std::vector<F96> f1a, f1b; GapCtx X;
+    GapRead(Shim &S, const u8 *rp, u64 L) : mem(new char[M1]), mem2(new char[M2]), r(L + PAD, 0), c(L + PAD, 0) {
+        for (size_t i = 0; i < S.seqs.size(); i++) { so.push_back(g.size()); sl.push_back(S.lens[i]); g.insert(g.end(), S.seqs[i].begin(), S.seqs[i].begin() + S.lens[i]); g.insert(g.end(), PAD, 0); }
+        memcpy(r.data(), rp, L);
+        static const u8 cpl[5] = {3, 2, 1, 0, 4};
+        for (u64 k = 0; k < L; k++) c[k] = cpl[r[L - k - 1]];
+        u32 nf = read_feature_count(L);
+        f1a.resize(nf); f1b.resize(nf);
+        features_closed(r.data(), nf, f1a.data());
+        features_closed(c.data(), nf, f1b.data());
+        ar.init(mem.get(), M1); keep.init(mem2.get(), M2);
+        X.ar = &ar; X.ls = &ls; X.read.p = r.data(); X.read.len = L; X.com.p = c.data(); X.com.len = L;
+        X.g = g.data(); X.seq_off = so.data(); X.seq_len = sl.data();
+        X.f1[0].p = f1a.data(); X.f1[0].n = nf; X.f1[1].p = f1b.data(); X.f1[1].n = nf;
+        X.gf.base = S.f2.data(); X.gf.off = S.f2_off.data(); X.gf.nseq = (u32)S.seqs.size();
+    }
+};
+}
+u64 hs_gap_map(void *h, const u8 *read, u64 len, int which, u64 gs1, u64 ge1, u64 gs2, u64 ge2, int direction, int alt, u64 *out_str, u64 *out_end, u64 *n2, u64 cap) {
+    Shim &S = *(Shim *)h;
+    GapRead H(S, read, len);
+    GapParms &gp = H.X.gp;
+    if (alt) { gp.chn1_min_len = 1; gp.chn1_abort = 0; gp.chn1_fn = 2; gp.chn2_abort = 0; gp.chn2_fn = 3; }
+    gp.read_len = len; gp.ref_len = S.lens[cord_id(gs1)];
+    GSeq ref = H.X.ref(cord_id(gs1));
+    GVec<u64> ts1, te1, ts2, te2; ts1.init(&H.keep, 64); te1.init(&H.keep, 64); ts2.init(&H.keep, 64); te2.init(&H.keep, 64);
+    if (which == 1) gap_map_generic(ref, ts1, te1, gs1, ge1, H.X);
+    else if (which == 2) gap_map_extend(ref, ts1, te1, gs1, ge1, direction, H.X);
+    else gap_map_extends(ref, ts1, te1, ts2, te2, gs1, ge1, gs2, ge2, H.X);
+    if (H.ar.ovf || H.keep.ovf) return ~0ULL;
+    u64 n1 = ts1.n;
+    for (u64 i = 0; i < n1 && i < cap; i++) { out_str[i] = ts1[(u32)i]; out_end[i] = i < te1.n ? te1[(u32)i] : 0; }
+    *n2 = ts2.n;
+    for (u64 i = 0; i < ts2.n && n1 + i < cap; i++) { out_str[n1 + i] = ts2[(u32)i]; out_end[n1 + i] = i < te2.n ? te2[(u32)i] : 0; }
+    return n1 | ((u64)te1.n << 32);
+}
+// apxMap + mapGaps + reformCords (Mapper::p_calRecords with -g gap_len [-dup], mapper.cpp:207-231,438-453); cords through hs_get_cords
+i64 hs_map_read_g(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup) {
+    Shim &S = *(Shim *)h;
+    int rc = map_read(S, read, len, false);
+    if (rc) return rc;
+    if (len <= 200 || gap_len == 0) return (i64)S.cs.size();
+    GapRead H(S, read, len);
+    H.X.gp.f_dup = f_dup;
+    H.X.gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
+    GVec<u64> cs, ce; cs.init(&H.keep, (u32)S.cs.size() * 2 + 64); ce.init(&H.keep, (u32)S.cs.size() * 2 + 64);
+    for (u64 v : S.cs) cs.push(v);
+    for (u64 v : S.ce) ce.push(v);
+    if (gap_map_gaps(cs, ce, H.keep, H.X)) return -10;
+    gap_reform_cords(cs, ce);
+    if (H.ar.ovf || H.keep.ovf) return -11;
+    S.cs.assign(cs.p, cs.p + cs.n);
+    S.ce.assign(ce.p, ce.p + ce.n);
+    return (i64)S.cs.size();
 }
 int hs_gap_score(int which, u64 a, u64 b, u64 c, u64 d, u64 read_len, int strand) {
     switch (which) {

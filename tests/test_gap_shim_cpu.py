@@ -131,3 +131,99 @@ def test_product_gap_chains_match_oracle():
                     assert n1 == n2 and np.array_equal(ta[:n1], tb[:n2]) and (not closest or (pa[0], pa[1]) == (pb[0], pb[1])), (seed, shape_len, direction, alt, closest, n1, n2)
                     n_nonempty += n1 > 0
     assert n_nonempty > 50
+
+
+def sv_reads(refs, n, seed, L=8000):
+    """reads with planted insertions, deletions, duplications, inversions and translocated stretches"""
+    rng = np.random.default_rng(seed)
+    cpl = np.array([3, 2, 1, 0, 4], np.uint8)
+    out = []
+    for k in range(n):
+        ref = refs[k % len(refs)]
+        x0 = int(rng.integers(1000, ref.size - 12000))
+        seg = ref[x0:x0 + L + 1000].copy()
+        cut = int(rng.integers(2000, 6000)); m = int(rng.integers(60, 1500))
+        kind = k % 6
+        if kind == 1: seg = np.concatenate([seg[:cut], seg[cut + m:]])
+        elif kind == 2: seg = np.concatenate([seg[:cut], rng.integers(0, 4, m, dtype=np.uint8), seg[cut:]])
+        elif kind == 3: seg = np.concatenate([seg[:cut], seg[max(cut - m, 0):cut], seg[cut:]])
+        elif kind == 4: seg = np.concatenate([seg[:cut], cpl[seg[cut:cut + m][::-1]], seg[cut + m:]])
+        elif kind == 5: seg = np.concatenate([seg[:cut], ref[x0 + 20000 - min(20000, x0):][:m], seg[cut:]])
+        r, o_, _ = synth.sample_reads([seg], 1, min(seg.size - 50, L), float(rng.choice([0.0, 0.03, 0.1])), seed + 700 + k, "random")
+        out.append(np.ascontiguousarray(r[: int(o_[1])]))
+    return out
+
+
+def test_product_gap_map_units_match_oracle():
+    """mapGeneric / mapExtend / mapExtends of the product header against the oracle on planted indels (the same cases as
+    tests/test_gap_units_cpu.py pins the oracle to the reference with)."""
+    from oracle import pyorc
+    o, s = libs()
+    sig = (C.c_uint64, [C.c_void_p, u8p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, u64p, u64p, u64p, C.c_uint64])
+    o.orc_gap_map.restype, o.orc_gap_map.argtypes = sig
+    s.hs_gap_map.restype, s.hs_gap_map.argtypes = sig
+    rng = np.random.default_rng(11)
+    g = synth.random_ref(60000, 77)
+    co, cs_ = pyorc.Checker("oracle", [g], 1), shimlib.Shim([g], 1)
+    cap = 4096
+    nontrivial = 0
+    for k in range(40):
+        x0 = int(rng.integers(1000, 40000))
+        L = 6000
+        seg = g[x0:x0 + L + 600].copy()
+        kind = k % 4
+        cut = int(rng.integers(2000, 3500))
+        if kind == 1:
+            seg = np.concatenate([seg[:cut], seg[cut + int(rng.integers(150, 500)):]])
+        elif kind == 2:
+            seg = np.concatenate([seg[:cut], rng.integers(0, 4, int(rng.integers(150, 500)), dtype=np.uint8), seg[cut:]])
+        elif kind == 3:
+            d = int(rng.integers(150, 400)); seg = np.concatenate([seg[:cut], seg[cut - d:cut], seg[cut:]])
+        reads, off, _ = synth.sample_reads([seg], 1, L, 0.06, 500 + k, "none")
+        rd = np.ascontiguousarray(reads[: int(off[1])])
+        ys, ye = cut - int(rng.integers(300, 900)), min(cut + int(rng.integers(600, 1400)), rd.size - 200)
+        xs, xe = x0 + ys, x0 + ye + int(rng.integers(-200, 200))
+        gs, ge = cord(0, xs, ys), cord(0, xe, ye)
+        cases_ = [(1, gs, ge, 0, 0, 0, 0), (1, gs, ge, 0, 0, 0, 1), (2, gs, cord(0, xs + 1500, ys + 1500), 0, 0, 1, 0), (2, cord(0, xe - 1500, ye - 1500), ge, 0, 0, -1, 0),
+                  (3, gs, cord(0, xs + 1200, ys + 1200), cord(0, xe - 1200, ye - 1200), ge, 0, 1)]
+        for which, a, b, c2, d2, direction, alt in cases_:
+            sa, ea, sb, eb = (np.zeros(cap, np.uint64) for _ in range(4))
+            na2, nb2 = C.c_uint64(), C.c_uint64()
+            na = o.orc_gap_map(co.h, p(rd, u8p), rd.size, which, a, b, c2, d2, direction, alt, p(sa, u64p), p(ea, u64p), C.byref(na2), cap)
+            nb = s.hs_gap_map(cs_.h, p(rd, u8p), rd.size, which, a, b, c2, d2, direction, alt, p(sb, u64p), p(eb, u64p), C.byref(nb2), cap)
+            tot = (na & 0xffffffff) + na2.value
+            assert na == nb and na2.value == nb2.value and np.array_equal(sa[:tot], sb[:tot]) and np.array_equal(ea[:tot], eb[:tot]), (k, kind, which, direction, alt, na, nb)
+            nontrivial += tot > 3
+    assert nontrivial > 60
+    co.close()
+
+
+@pytest.mark.parametrize("name", ["ont", "edge"])
+def test_product_gap_path_matches_reference_golden(case_inputs, name):
+    """apxMap + mapGaps + reformCords of the product's host build against cords the real reference produced with -g 50 [-dup 1]"""
+    from tests import cases
+    refs, reads, off = case_inputs(name)
+    g = np.load(os.path.join(HERE, "golden", f"{name}_g50_T1.npz"))
+    assert cases.input_digest(refs, reads, off) == str(g["digest"])
+    sh = shimlib.Shim(refs, 1)
+    for dup in (0, 1):
+        co = g[f"cord_off_dup{dup}"]
+        for i in range(off.size - 1):
+            cs, ce = sh.map_read_gap(reads[int(off[i]):int(off[i + 1])], 50, dup)
+            assert np.array_equal(cs, g[f"cords_str_dup{dup}"][int(co[i]):int(co[i + 1])]), f"dup {dup} read {i}"
+            assert np.array_equal(ce, g[f"cords_end_dup{dup}"][int(co[i]):int(co[i + 1])]), f"dup {dup} read {i}"
+
+
+def test_product_gap_path_matches_oracle_on_planted_svs():
+    from oracle import pyorc
+    pyorc.build(ref=False)
+    refs = [synth.repeat_ref(300_000, 61), synth.add_n_runs(synth.random_ref(200_000, 62), 63, n_runs=2, max_run=600)]
+    reads_l = sv_reads(refs, 48, 2027)
+    for T in (1, 3):
+        o = pyorc.Checker("oracle", refs, T)
+        sh = shimlib.Shim(refs, T)
+        for i, rd in enumerate(reads_l):
+            for gap_len, dup in ((50, 0), (50, 1), (1, 0), (5, 1), (200, 0)):
+                a, b = o.map_read_gap(rd, gap_len, dup), sh.map_read_gap(rd, gap_len, dup)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (T, i, gap_len, dup)
+        o.close()
