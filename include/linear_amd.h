@@ -46,7 +46,7 @@ typedef enum lnr_status {
     LNR_ERR_NOMEM = -4,       /* device or host allocation failed */
     LNR_ERR_NO_INDEX = -5,    /* filter/seed call before lnr_index_build / lnr_index_adopt */
     LNR_ERR_LIMIT = -6,       /* input exceeds a format limit (read >= 2^20, sequence >= 2^30 - 2^20; cords.cpp:13-15) */
-    LNR_ERR_UNSUPPORTED = -7, /* option outside this build (index_type not 1 or 2, feature_type != 2, gap_len != 0; -i 2 on a reference with fewer
+    LNR_ERR_UNSUPPORTED = -7, /* option outside this build (index_type not 1 or 2, feature_type != 2, dup > 1; -i 2 on a reference with fewer
                                  than three repeated minimizers) */
     LNR_ERR_INTERNAL = -8     /* device-side capacity overflow that retries could not resolve */
 } lnr_status;
@@ -57,8 +57,9 @@ typedef struct lnr_opts {
     uint32_t index_type;       /* -i : 1 = DIndex (reference default), 2 = HIndex (index_util.cpp:2593-2610: shape 17/9, one sample per 8 bases) */
     uint32_t feature_type;     /* -f : 2 = 2-mer/48 window features (reference default) */
     uint32_t preset;           /* -p : 1 (reference default: chain stop ratio 0) */
-    uint32_t gap_len;          /* -g : must be 0 here (apxMap only; gap re-mapper is next tier) */
-    uint32_t reserved0;
+    uint32_t gap_len;          /* -g : 0 = apxMap only; > 0 = the cords go through the gap re-mapper (mapGaps + reformCords, gap.cpp:407-576) with this
+                                  minimum gap length, mapped as the reference does: 1 -> 50, 2..9 -> 10 (mapper.cpp:438-453) */
+    uint32_t dup;              /* -dup : 0 | 1, the duplication add-on of the gap re-mapper (gap.cpp:303-362) */
     uint64_t scratch_budget;   /* max bytes of per-read device scratch in flight (0 = default 64 GiB of the 288 GB) */
 } lnr_opts;
 
@@ -107,6 +108,8 @@ typedef struct lnr_stats {
     uint64_t seed_bytes;
     double prep_ms, seed_count_ms, seed_gather_ms, job_ms, tail_ms, total_ms;
     uint32_t seed_count_launches, seed_gather_launches, job_launches;
+    uint32_t reserved1;
+    double gap_ms;             /* device time of the gap re-mapper (-g > 0) */
 } lnr_stats;
 
 void lnr_opts_default(lnr_opts *o);

@@ -18,7 +18,7 @@ _u8p, _u64p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_
 
 class LnrOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("index_type", C.c_uint32), ("feature_type", C.c_uint32), ("preset", C.c_uint32),
-                ("gap_len", C.c_uint32), ("reserved0", C.c_uint32), ("scratch_budget", C.c_uint64)]
+                ("gap_len", C.c_uint32), ("dup", C.c_uint32), ("scratch_budget", C.c_uint64)]
 
 
 class LnrIndexInfo(C.Structure):
@@ -45,7 +45,7 @@ class LnrAnchors(C.Structure):
 class LnrStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("reads", "bases", "jobs", "samples", "lookups", "bucket_entries", "anchors", "remap_reads", "cords", "seed_bytes")] + \
                [(k, C.c_double) for k in ("prep_ms", "seed_count_ms", "seed_gather_ms", "job_ms", "tail_ms", "total_ms")] + \
-               [(k, C.c_uint32) for k in ("seed_count_launches", "seed_gather_launches", "job_launches")]
+               [(k, C.c_uint32) for k in ("seed_count_launches", "seed_gather_launches", "job_launches", "reserved1")] + [("gap_ms", C.c_double)]
 
 
 class LnrError(RuntimeError):
@@ -110,13 +110,15 @@ def _p(a: np.ndarray, t):
 class Filter:
     """One context = one GPU.  Mirrors the Mapper's compute interface: build the index once, then filter read blocks."""
 
-    def __init__(self, device: int = -1, scratch_budget: int = 0, index_type: int = 1):
+    def __init__(self, device: int = -1, scratch_budget: int = 0, index_type: int = 1, gap_len: int = 0, dup: int = 0):
         self.lib = load_library()
         o = LnrOpts()
         self.lib.lnr_opts_default(C.byref(o))
         o.device = device
         o.scratch_budget = scratch_budget
         o.index_type = index_type          # the reference's -i: 1 DIndex, 2 HIndex
+        o.gap_len = gap_len                # the reference's -g: 0 = apxMap only, > 0 = + gap re-mapper (mapGaps, reformCords)
+        o.dup = dup                        # the reference's -dup
         h = C.c_void_p()
         st = self.lib.lnr_create(C.byref(o), C.byref(h))
         if st != 0:

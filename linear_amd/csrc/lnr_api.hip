@@ -154,6 +154,7 @@ struct lnr_ctx {
     u32 overflow_reruns = 0;
     u32 seed_lds_pad = 0;   // diagnostic (LNR_SEED_LDS_PAD): dynamic LDS the seed kernel does not use, to lower its waves per CU
     DevBuf hx_nkeys, hx_nvals; u32 hx_nnodes = 0; u64 hx_empty_dir = 0;   // HIndex (-i 2): dir = hdir[2^18] (head of the block of X, -1: none), hs = ysa, nodes of the large blocks
+    DevBuf gap_arena, gap_flag, gap_next, d_seq_len;   // the gap re-mapper (-g > 0): arenas of its workers, per-read retry flags, the two work counters
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl, ov;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines, ov = their aligned overflow lines (k_ix_lines)
     // ---- batch inputs / per-read arrays
     // host-buffer entry points: two input slots, so that the upload of the next batch (copy stream) runs under the kernels of
@@ -194,7 +195,8 @@ struct lnr_ctx {
     u32 last_n = 0;
     u64 last_ncords = 0;
     lnr_stats stats{};
-    Timer t_prep, t_job, t_tail, t_total;
+    Timer t_prep, t_job, t_tail, t_total, t_gap;
+    u64 gap_work_cap = 3000000;   // pair evaluations of the chain DPs one lane spends on a read before the read goes to the wave-per-read launch (LNR_GAP_WORK_CAP)
 };
 
 namespace {
@@ -447,6 +449,7 @@ lnr_status upload_index_layout(lnr_ctx *ctx) {
     lnr_status s;
     if ((s = upload(ctx, ctx->d_seq_off, ctx->seq_off)) != LNR_OK) return s;
     if ((s = upload(ctx, ctx->d_f2_off, ctx->f2_off)) != LNR_OK) return s;
+    if ((s = upload(ctx, ctx->d_seq_len, ctx->seq_len)) != LNR_OK) return s;
     return LNR_OK;
 }
 
@@ -1078,6 +1081,37 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     if (T.n) { hipLaunchKernelGGL(k_tail_b, dim3((T.n + 63) / 64), dim3(64), 0, ctx->stream, T); KCHECK(); }
     ctx->t_tail.stop(ctx->stream);
     if (early) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
+    if (ctx->opts.gap_len) {
+        // the gap re-mapper on the final cords (k_gap): every read with small arenas, then the flagged reads with large ones
+        u32 maxlen = 0;
+        for (u32 i = 0; i < n; i++) maxlen = std::max(maxlen, B.len[i]);
+        const u64 budget = (u64)48 << 30;
+        u64 arena1 = align_up(((u64)512 << 10) * ctx->cap_scale + 16ULL * maxlen + sizeof(LeaderScratch) + 65536, 256);
+        u64 arena2 = std::max<u64>(((u64)64 << 20) * ctx->cap_scale, arena1 * 8);
+        u32 w1 = (u32)std::min<u64>(align_up(n, 64), std::max<u64>(64, (budget / arena1) / 64 * 64));
+        u32 w2 = (u32)std::min<u64>(n, std::max<u64>(1, (budget / 2) / arena2));   // waves of the second launch
+        ENSURE(ctx->gap_arena, std::max((u64)w1 * arena1, (u64)w2 * arena2));
+        ENSURE(ctx->gap_flag, (size_t)n * 4);
+        ENSURE(ctx->gap_next, 64);
+        HIPCK(hipMemsetAsync(ctx->gap_next.p, 0, 64, ctx->stream));
+        GapArgs G;
+        G.g = ctx->g.as<u8>(); G.seq_off = ctx->d_seq_off.as<u64>(); G.seq_len = ctx->d_seq_len.as<u64>();
+        G.gf.base = ctx->f2.as<F96>(); G.gf.off = ctx->d_f2_off.as<u64>(); G.gf.nseq = ctx->info.nseq;
+        G.reads = d_reads; G.off = d_off; G.n = n;
+        G.nf = ctx->nf.as<u32>(); G.f1_off = ctx->f1_off.as<u64>(); G.f1 = ctx->f1.as<F96>();
+        G.out_str = ctx->out_str.as<u64>(); G.out_end = ctx->out_end.as<u64>(); G.cords_off = ctx->cords_off.as<u64>(); G.cords_cap = ctx->cords_cap.as<u32>();
+        G.nout = ctx->nout.as<u32>(); G.read_err = ctx->read_err.as<i32>(); G.gap_flag = ctx->gap_flag.as<u32>();
+        G.arena = (char *)ctx->gap_arena.p;
+        G.gap_len_min = ctx->opts.gap_len == 1 ? 50 : (ctx->opts.gap_len < 10 ? 10 : ctx->opts.gap_len);   // mapper.cpp:438-453
+        G.f_dup = (int)ctx->opts.dup;
+        ctx->t_gap.start(ctx->stream);
+        G.work_cap = ctx->gap_work_cap;
+        G.arena_bytes = arena1; G.next = ctx->gap_next.as<u32>(); G.big = 0;
+        hipLaunchKernelGGL(k_gap, dim3(w1 / 64), dim3(64), 0, ctx->stream, G); KCHECK();
+        G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1;
+        hipLaunchKernelGGL(k_gap, dim3(w2), dim3(64), 0, ctx->stream, G); KCHECK();
+        ctx->t_gap.stop(ctx->stream);
+    }
     std::vector<u32> nout(n);
     std::vector<i32> rerr(n);
     {
@@ -1089,6 +1123,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         rb.finish();
     }
     ctx->stats.tail_ms += ctx->t_tail.ms();
+    if (ctx->opts.gap_len) ctx->stats.gap_ms += ctx->t_gap.ms();
     for (u32 i = 0; i < n; i++)
         if (rerr[i]) {
             // A read outgrew a per-read capacity (cords: 16 per 64 bases + 256; gaps: one per 1000 bases + 4 -- heuristics, generous by an
@@ -1256,7 +1291,7 @@ extern "C" {
 void lnr_opts_default(lnr_opts *o) {
     if (!o) return;
     memset(o, 0, sizeof *o);
-    o->device = -1; o->index_type = 1; o->feature_type = 2; o->preset = 1; o->gap_len = 0; o->scratch_budget = 0;
+    o->device = -1; o->index_type = 1; o->feature_type = 2; o->preset = 1; o->gap_len = 0; o->dup = 0; o->scratch_budget = 0;
 }
 
 const char *lnr_strerror(lnr_status s) {
@@ -1280,7 +1315,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     *out = nullptr;
     lnr_opts o;
     if (opts) o = *opts; else lnr_opts_default(&o);
-    if ((o.index_type != 1 && o.index_type != 2) || o.feature_type != 2 || o.gap_len != 0 || o.preset != 1) return LNR_ERR_UNSUPPORTED;
+    if ((o.index_type != 1 && o.index_type != 2) || o.feature_type != 2 || o.preset != 1 || o.dup > 1) return LNR_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return LNR_ERR_NO_DEVICE; }
     int dev = o.device;
@@ -1296,6 +1331,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     ctx->device = dev;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (const char *e = getenv("LNR_CAP_SHRINK")) { long v = atol(e); if (v >= 1 && v <= 4096) ctx->cap_shrink = (u32)v; }
+    if (const char *e = getenv("LNR_GAP_WORK_CAP")) { long long v = atoll(e); if (v >= 0) ctx->gap_work_cap = (u64)v; }
     if (const char *e = getenv("LNR_SEED_LDS_PAD")) { long v = atol(e); if (v >= 0 && v <= 100000) ctx->seed_lds_pad = (u32)v; }
     if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }
     if (const char *e = getenv("LNR_JOB_STAGE_KB")) { long kb = atol(e); if (kb >= 0 && kb <= 60) ctx->job_stage_bytes = (size_t)kb * 1024; }
@@ -1333,7 +1369,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
         ok = hipEventCreateWithFlags(&ctx->ev_fork[l], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_join[l], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_lane[l], hipEventDisableTiming) == hipSuccess;
     if (!ok) { lnr_destroy(ctx); return LNR_ERR_HIP; }
-    ctx->t_prep.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init();
+    ctx->t_prep.init(); ctx->t_job.init(); ctx->t_tail.init(); ctx->t_total.init(); ctx->t_gap.init();
     *out = ctx;
     return LNR_OK;
 }

@@ -8,22 +8,29 @@
 #include "lnr_hd.h"
 
 namespace lnr {
+#ifdef LNR_GAP_PROF
+static unsigned long long lnr_gap_prof_pairs = 0, lnr_gap_prof_maxn = 0, lnr_gap_prof_sumn = 0;
+static inline void lnr_gap_prof_n(unsigned long long n) { lnr_gap_prof_sumn += n; if (n > lnr_gap_prof_maxn) lnr_gap_prof_maxn = n; }
+#endif
 
 // ---- arena + growable array of the gap path: temporaries of one gap are released together (mark / release)
 struct GArena {
-    char *base; u64 off, cap; int ovf;
-    LNR_HD void init(void *b, u64 c) { base = (char *)b; off = 0; cap = c; ovf = 0; }
+    char *base; u64 off, cap, hw; int ovf;
+    // the first 64 bytes are the dump: what a vector that could not be allocated points at (capacity 0), so that a stray element
+    // access after an overflow stays inside the arena.  ovf: 1 = out of memory, 2 = over the work budget (both: the read is redone
+    // with a larger arena / by the cooperative form, or reported)
+    LNR_HD void init(void *b, u64 c) { base = (char *)b; off = 64; cap = c; ovf = c < 64 ? 1 : 0; hw = 0; }
     LNR_HD void *get(u64 bytes) {
         bytes = (bytes + 15) & ~15ULL;
-        if (off + bytes > cap) { ovf = 1; return (void *)base; }   // (callers check ovf at the end: the result is then discarded)
-        void *r = base + off; off += bytes; return r;
+        if (ovf || off + bytes > cap) { if (!ovf) ovf = 1; return (void *)base; }   // (raw users check ovf before touching the block; GVec falls back to capacity 0)
+        void *r = base + off; off += bytes; if (off > hw) hw = off; return r;
     }
     LNR_HD u64 mark() const { return off; }
     LNR_HD void release(u64 m) { off = m; }
 };
 template <class T> struct GVec {
     T *p; u32 n, cap; GArena *ar;
-    LNR_HD void init(GArena *a, u32 c0 = 16) { ar = a; n = 0; cap = c0; p = (T *)a->get((u64)c0 * sizeof(T)); }
+    LNR_HD void init(GArena *a, u32 c0 = 16) { ar = a; n = 0; cap = c0; p = (T *)a->get((u64)c0 * sizeof(T)); if (a->ovf) cap = 0; }
     LNR_HD void reserve(u32 c) {
         if (c <= cap) return;
         u32 nc = cap * 2 > c ? cap * 2 : c;
@@ -33,9 +40,11 @@ template <class T> struct GVec {
         p = q; cap = nc;
     }
     LNR_HD void push(const T &v) { reserve(n + 1); if (n < cap) p[n++] = v; }
-    LNR_HD T &operator[](u32 i) { return p[i]; }
-    LNR_HD const T &operator[](u32 i) const { return p[i]; }
-    LNR_HD T &back() { return p[n - 1]; }
+    // (element access is clamped: after an overflow the vectors are short or empty and the code that follows may index past them
+    //  before it reaches the next overflow check; results of such a read are discarded)
+    LNR_HD T &operator[](u32 i) { return p[i < cap ? i : 0]; }
+    LNR_HD const T &operator[](u32 i) const { return p[i < cap ? i : 0]; }
+    LNR_HD T &back() { return p[n ? n - 1 : 0]; }
     LNR_HD bool empty() const { return n == 0; }
     LNR_HD void clear() { n = 0; }
     LNR_HD void resize(u32 m, const T &fill = T()) { reserve(m); if (m > cap) return; for (u32 i = n; i < m; i++) p[i] = fill; n = m; }
@@ -105,6 +114,8 @@ struct GapCtx {                                           // one read
     const u8 *g; const u64 *seq_off; const u64 *seq_len;  // genome
     FeatView f1[2]; GenomeFeat gf;
     GapParms gp;
+    u64 work = 0, work_cap = ~0ULL;                       // pair evaluations of the chain DPs so far / the budget (over it: ar->ovf = 2)
+    int coop = 0;                                         // device: all 64 lanes of the wave run this read together (k_gap, second launch)
     LNR_HD GSeq ref(u64 id) const { GSeq s; s.p = g + seq_off[id]; s.len = seq_len[id]; return s; }
 };
 
@@ -157,6 +168,7 @@ LNR_HD inline void c_stream(const GSeq &seq, GVec<u64> &g_hs, u64 sq_str, u64 sq
 
 // ---- anchors from the sorted k-mer list (gap_util.cpp:669-752, 1596-1661, 1818-1853)
 LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, int p2, int k, u64 rvcp, i64 lower, i64 upper, u64 gap_str, u64 gap_end, int direction, const GapParms &gp) {
+    if (out.ar->ovf) return;
     if (direction == 0) {
         for (int i = p1; i < p2; i++) for (int j = p2; j < k; j++) {
             u64 a = ganc_make(g_hs[(u32)i], g_hs[(u32)j], rvcp);
@@ -206,6 +218,7 @@ LNR_HD inline void c_create_anchors2(GVec<u64> &g_hs, GVec<u64> &out, i64 lower,
         u64 t = g_hs_xt(g_hs[(u32)k] ^ g_hs[(u32)k - 1]);
         if (t == 0) continue;
         if (t == 1) { p2 = k; continue; }
+        if (out.ar->ovf) return;
         for (int i = p1; i < p2; i++) {
             i64 x = (i64)(g_hs[(u32)i] & ((1ULL << 30) - 1));
             for (int j = p2; j < k; j++) {
@@ -311,7 +324,10 @@ struct TileSink {
 };
 template <class Score>
 LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, bool to_tiles, u32 depth, u64 dx_depth, int bestn, int min_len, int abort_score, Score score, GapCtx &X, bool first_only = false) {
-    if (n < 2) return;
+    if (n < 2 || X.ar->ovf) return;
+#ifdef LNR_GAP_PROF
+    lnr_gap_prof_n(n);
+#endif
     u64 m0 = X.ar->mark();
     Rec r;
     i32 *blk = (i32 *)X.ar->get((u64)n * 9 * sizeof(i32));
@@ -322,14 +338,44 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
     // record 0 are whatever the allocator left -- 0 in practice, as here)
     for (u32 i = 0; i < n; i++) { r.score[i] = 0; r.score2[i] = 0; r.len[i] = 0; r.p2[i] = 0; r.root[i] = 0; r.leaf[i] = 0; }
     r.score[0] = 0; r.len[0] = 1; r.p2[0] = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (X.coop) {
+        // every lane runs the read's code with the same data; here the predecessors of anchor i are dealt over the lanes, 64 at a
+        // time.  The scan ends at the first j below j_str whose x is dx_depth away: the anchors are x-descending, so that is a
+        // threshold in j.  Among equal sums the serial scan (j descending, >=) keeps the smallest j: the key's low word.
+        const int lane = (int)(threadIdx.x & 63);
+        for (int i = 0; i < (int)n; i++) {
+            int j_str = i - (int)depth < 0 ? 0 : i - (int)depth;
+            u64 ai = anchors[i], xi = ganc_x(ai), key = 0;
+            for (int jb = i - 1; jb >= 0; jb -= 64) {
+                int j = jb - lane;
+                bool ok = j >= 0 && (j >= j_str || ganc_x(anchors[j]) - xi < dx_depth);
+                if (ok) {
+                    int sc = score(anchors[j], ai);
+                    if (sc > 0) { u64 k = ((u64)(u32)(sc + r.score[j]) << 32) | (u64)(0xffffffffu - (u32)j); key = k > key ? k : key; }
+                }
+                if (__any(!ok)) break;
+            }
+            for (int m = 32; m; m >>= 1) { u64 o = __shfl_xor(key, m); key = o > key ? o : key; }
+            int best = key ? (int)(key >> 32) : -1, max_j = key ? (int)(0xffffffffu - (u32)key) : i;
+            if (best > 0) { r.p2[i] = max_j; r.score[i] = best; r.len[i] = r.len[max_j] + 1; r.score2[i] = best; r.root[i] = r.root[max_j]; r.leaf[i] = 1; r.leaf[max_j] = 0; }
+            else { r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = i; r.leaf[i] = 1; }
+        }
+    } else
+#endif
     for (int i = 0; i < (int)n; i++) {
-        int j_str = i - (int)depth < 0 ? 0 : i - (int)depth, max_j = i, best = -1;
-        for (int j = i - 1; j >= 0 && (j >= j_str || ganc_x(anchors[j]) - ganc_x(anchors[i]) < dx_depth); j--) {
+        int j_str = i - (int)depth < 0 ? 0 : i - (int)depth, max_j = i, best = -1, j = i - 1;
+        for (; j >= 0 && (j >= j_str || ganc_x(anchors[j]) - ganc_x(anchors[i]) < dx_depth); j--) {
+#ifdef LNR_GAP_PROF
+            lnr_gap_prof_pairs++;
+#endif
             int sc = score(anchors[j], anchors[i]);
             if (sc > 0 && sc + r.score[j] >= best) { max_j = j; best = sc + r.score[j]; }
         }
         if (best > 0) { r.p2[i] = max_j; r.score[i] = best; r.len[i] = r.len[max_j] + 1; r.score2[i] = best; r.root[i] = r.root[max_j]; r.leaf[i] = 1; r.leaf[max_j] = 0; }
         else { r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = i; r.leaf[i] = 1; }
+        X.work += (u64)(i - 1 - j);
+        if (X.work > X.work_cap) { X.ar->ovf = 2; return; }
     }
     // the output may grow while the records live above it in the arena: collect into a vector allocated before them
     TileSink sink; sink.anchors = anchors; sink.tiles = &out; sink.first_len = 0; sink.nchains = 0; sink.to_tiles = to_tiles;
@@ -363,6 +409,7 @@ LNR_HD inline void gap_best_chains2(const u64 *rec_, const UP *sep, const i32 *s
 // header, the tile-end sign as the block end)
 LNR_HD inline void gap_chain_blocks_cords(GVec<u64> &tiles, GVec<UP> &sep, u64 L, u32 init_score, u64 major_limit, GapCtx &X) {
     u32 nb = sep.n;
+    if (X.ar->ovf) return;
     UP *sp[2]; BlockSink cc[2];
     for (int strand = 0; strand < 2; strand++) {
         sp[strand] = (UP *)X.ar->get((u64)(nb + 1) * sizeof(UP));
@@ -427,9 +474,11 @@ LNR_HD inline void gap_chain_blocks_cords(GVec<u64> &tiles, GVec<UP> &sep, u64 L
 LNR_HD inline void gap_chain_tiles(GVec<u64> &tiles, u64 L, u64 gap_size, GapCtx &X) {       // chainTiles gap_util.cpp:1177-1189
     GVec<UP> sep; sep.init(X.ar);
     gap_gather_tile_blocks(tiles.p, tiles.n, sep, L, gap_size);
+    if (X.ar->ovf) return;
     gap_chain_blocks_cords(tiles, sep, L, 64, X.gp.thd_cts_major_limit, X);
 }
 LNR_HD inline void g_chains_from_anchors(GVec<u64> &anchors, GVec<u64> &tiles, u64 L, GapCtx &X) {   // g_CreateChainsFromAnchors_ gap_util.cpp:1191-1222
+    if (X.ar->ovf) return;
     ref_sort(anchors.p, (long)anchors.n, [](const u64 &a, const u64 &b) { return ganc_x(a) > ganc_x(b); }, X.ls->st);
     int fn = X.gp.chn1_fn;
     gap_chain_anchors(anchors.p, anchors.n, tiles, true, 20, 80, 20, X.gp.chn1_min_len, X.gp.chn1_abort, [fn](u64 a, u64 b) { return fn == 2 ? gap_anchor_score2(a, b) : gap_anchor_score1(a, b); }, X);
@@ -705,7 +754,7 @@ LNR_HD inline int gap_insert_tiles1(GVec<u64> &cords, u32 &pos, GVec<u64> &tiles
     for (u32 i = 0; i < tiles.n; i++) { u64 &t = tiles[i]; remove_tile_sgn(t); t &= ~F_MAIN; if (recd) t |= F_RECD; else t &= ~F_RECD; }   // set_tiles_cords_sgns :619-627
     if (direction == -1) {
         if (is_end(cords[pos])) tiles.back() |= F_END; else tiles.back() &= ~F_END;
-        cords[pos] = tiles.back(); tiles.n--;
+        cords[pos] = tiles.back(); if (tiles.n) tiles.n--;
         cords.insert(pos, tiles.p, tiles.n);
         pos += tiles.n;
     } else if (direction == 1) {
@@ -1027,7 +1076,8 @@ LNR_HD inline u32 gap_splice_generic(const GSeq &ref, GVec<u64> &ts, GVec<u64> &
     u32 added = 0;
     if (!t1.empty()) {
         t1.erase(0, 1); e1.erase(0, 1);
-        t1.n--; e1.n--;
+        if (t1.n) t1.n--;
+        if (e1.n) e1.n--;
         if (!t1.empty()) {
             remove_tile_sgn(t1.back()); remove_tile_sgn(e1.back());
             if (dup_marks) {
@@ -1132,7 +1182,7 @@ LNR_HD inline int gap_map_gap(u64 gap_str, u64 gap_end, GVec<u64> &tiles_str, GV
         }
     }
     for (int i = 1; i < (int)tiles_str.n - 1; i++) { tiles_str[(u32)i - 1] = tiles_str[(u32)i]; tiles_end[(u32)i - 1] = tiles_end[(u32)i]; }
-    tiles_str.n -= 2; tiles_end.n -= 2;
+    tiles_str.n = tiles_str.n >= 2 ? tiles_str.n - 2 : 0; tiles_end.n = tiles_end.n >= 2 ? tiles_end.n - 2 : 0;
     return 0;
 }
 LNR_HD inline i64 gap_max_gapsy_overlap(const UP *gapsy, u32 n, u64 gap_str, u64 gap_end) {   // _getMaxGapsyOverlap gap_util.cpp:343-362

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "lnr_hd.h"
+#include "lnr_gap_hd.h"
 
 namespace lnr {
 
@@ -2900,6 +2901,70 @@ __global__ void __launch_bounds__(64) k_gather_out(const u64 *out_str, const u64
     const u64 *s = out_str + cords_off[r], *e = out_end + cords_off[r];
     u64 o = cord_off[r];
     for (u32 i = threadIdx.x; i < c; i += blockDim.x) { cs[o + i] = s[i]; ce[o + i] = e[i]; }
+}
+
+// ------------------------------------------------------------------ gap re-mapper [f1] ----
+// mapGaps + reformCords (Mapper::p_calRecords with -g > 0, mapper.cpp:207-231 / gap.cpp:407-576 / cords.cpp:504-687) on the final
+// cords of every read, in place in the per-read output slots.  One lane = one worker with an arena of its own; workers take reads
+// from a shared counter (the work per read ranges from nothing to dozens of k-mer joins).  A read whose gaps outgrow the arena (or
+// whose new cords outgrow its slot), or whose chain DPs go over the work budget (a read of N runs joins into 10^5 anchors with
+// thousands of predecessors each), keeps its apxMap cords and is flagged in gap_flag; the second launch (big = 1) takes only the
+// flagged reads, one WAVE per read with a large arena: all lanes run the read's code with the same data (stores of one value to one
+// address), and the chain DP deals the predecessors of an anchor over the lanes (gap_chain_anchors).  What is still flagged
+// afterwards is reported through read_err.
+struct GapArgs {
+    const u8 *g; const u64 *seq_off, *seq_len; GenomeFeat gf;
+    const u8 *reads; const u64 *off; u32 n;
+    const u32 *nf; const u64 *f1_off; const F96 *f1;
+    u64 *out_str, *out_end; const u64 *cords_off; const u32 *cords_cap; u32 *nout; i32 *read_err; u32 *gap_flag;
+    char *arena; u64 arena_bytes; u32 *next; u32 gap_len_min; int f_dup; int big; u64 work_cap;
+};
+__global__ void __launch_bounds__(64) k_gap(GapArgs A) {
+    u32 worker = A.big ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+    char *mine = A.arena + (u64)worker * A.arena_bytes;
+    for (;;) {
+        u32 r;
+        if (A.big) { r = threadIdx.x == 0 ? atomicAdd(A.next, 1u) : 0u; r = (u32)__shfl((int)r, 0); }
+        else r = atomicAdd(A.next, 1u);
+        if (r >= A.n) break;
+        if (A.big && !A.gap_flag[r]) continue;
+        u32 nc = A.nout[r];
+        u64 L = A.off[r + 1] - A.off[r];
+        if (L <= 200 || nc <= 1) { if (!A.big) A.gap_flag[r] = 0; continue; }
+        GArena all; all.init(mine, A.arena_bytes);
+        LeaderScratch *ls = (LeaderScratch *)all.get(sizeof(LeaderScratch));
+        u8 *rd = (u8 *)all.get(L + 64), *rc = (u8 *)all.get(L + 64);
+        u64 keep_bytes = ((u64)A.cords_cap[r] * 16 + (u64)nc * 64 + 8192) * 2;
+        char *kp = (char *)all.get(keep_bytes);
+        bool bad = all.ovf != 0;
+        if (!bad) {
+            const u8 *src = A.reads + A.off[r];
+            for (u64 k = 0; k < L; k++) { u8 b = src[k]; b = b > 4 ? 4 : b; rd[k] = b; rc[L - 1 - k] = b == 4 ? 4 : 3 - b; }
+            for (u32 k = 0; k < 64; k++) { rd[L + k] = 0; rc[L + k] = 0; }
+            GArena keep; keep.init(kp, keep_bytes);
+            GArena ar; ar.init(mine + all.off, A.arena_bytes - all.off);
+            GapCtx X;
+            X.ar = &ar; X.ls = ls; X.read.p = rd; X.read.len = L; X.com.p = rc; X.com.len = L;
+            X.g = A.g; X.seq_off = A.seq_off; X.seq_len = A.seq_len;
+            u32 nf = A.nf[r];
+            X.f1[0].p = A.f1 + A.f1_off[r]; X.f1[0].n = nf; X.f1[1].p = A.f1 + A.f1_off[r] + nf; X.f1[1].n = nf;
+            X.gf = A.gf;
+            X.gp.f_dup = A.f_dup; X.gp.thd_gap_len_min = A.gap_len_min;
+            X.coop = A.big; X.work_cap = A.big ? ~0ULL : A.work_cap;
+            u64 *os = A.out_str + A.cords_off[r], *oe = A.out_end + A.cords_off[r];
+            GVec<u64> cs, ce; cs.init(&keep, nc * 2 + 64); ce.init(&keep, nc * 2 + 64);
+            for (u32 i = 0; i < nc; i++) { cs.push(os[i]); ce.push(oe[i]); }
+            int rc_ = gap_map_gaps(cs, ce, keep, X);
+            gap_reform_cords(cs, ce);
+            bad = rc_ != 0 || ar.ovf || keep.ovf || cs.n > A.cords_cap[r] || cs.n != ce.n;
+            if (!bad) {
+                for (u32 i = 0; i < cs.n; i++) { os[i] = cs[i]; oe[i] = ce[i]; }
+                A.nout[r] = cs.n;
+            }
+        }
+        A.gap_flag[r] = bad ? 1 : 0;
+        if (A.big && bad) A.read_err[r] = 5;
+    }
 }
 
 }  // namespace lnr

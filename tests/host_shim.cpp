@@ -308,9 +308,9 @@ u64 hs_gap_chains(const u64 *anchors, u64 n, u64 read_len, int alt, int directio
 // ---- the whole gap layer on a Shim context (genome + f2 from hs_create): hs_gap_map = orc_gap_map, hs_map_read_g = orc_map_read_g
 namespace {
 struct GapRead {
-    static const size_t M1 = (size_t)256 << 20, M2 = (size_t)64 << 20;
+    size_t M1, M2;
     std::unique_ptr<char[]> mem, mem2; GArena ar, keep; LeaderScratch ls; std::vector<u8> g, r, c; std::vector<u64> so, sl; std::vector<F96> f1a, f1b; GapCtx X;
-    GapRead(Shim &S, const u8 *rp, u64 L) : mem(new char[M1]), mem2(new char[M2]), r(L + PAD, 0), c(L + PAD, 0) {
+    GapRead(Shim &S, const u8 *rp, u64 L, size_t m1 = (size_t)256 << 20, size_t m2 = (size_t)64 << 20) : M1(m1), M2(m2), mem(new char[m1]), mem2(new char[m2]), r(L + PAD, 0), c(L + PAD, 0) {
         for (size_t i = 0; i < S.seqs.size(); i++) { so.push_back(g.size()); sl.push_back(S.lens[i]); g.insert(g.end(), S.seqs[i].begin(), S.seqs[i].begin() + S.lens[i]); g.insert(g.end(), PAD, 0); }
         memcpy(r.data(), rp, L);
         static const u8 cpl[5] = {3, 2, 1, 0, 4};
@@ -346,20 +346,27 @@ u64 hs_gap_map(void *h, const u8 *read, u64 len, int which, u64 gs1, u64 ge1, u6
     return n1 | ((u64)te1.n << 32);
 }
 // apxMap + mapGaps + reformCords (Mapper::p_calRecords with -g gap_len [-dup], mapper.cpp:207-231,438-453); cords through hs_get_cords
-i64 hs_map_read_g(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup) {
+static i64 map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup, u64 arena_bytes, u64 keep_bytes, u64 work_cap);
+i64 hs_map_read_g(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup) { return map_read_g_lim(h, read, len, gap_len, f_dup, (u64)256 << 20, (u64)64 << 20, ~0ULL); }
+// the same with the arena sizes and the work budget of a k_gap worker: -11 = out of arena, -12 = over the work budget (the cords of apxMap stay)
+i64 hs_map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup, u64 arena_bytes, u64 keep_bytes, u64 work_cap) { return map_read_g_lim(h, read, len, gap_len, f_dup, arena_bytes, keep_bytes, work_cap); }
+static i64 map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup, u64 arena_bytes, u64 keep_bytes, u64 work_cap) {
     Shim &S = *(Shim *)h;
     int rc = map_read(S, read, len, false);
     if (rc) return rc;
     if (len <= 200 || gap_len == 0) return (i64)S.cs.size();
-    GapRead H(S, read, len);
+    GapRead H(S, read, len, arena_bytes, keep_bytes);
+    H.X.work_cap = work_cap;
     H.X.gp.f_dup = f_dup;
     H.X.gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
     GVec<u64> cs, ce; cs.init(&H.keep, (u32)S.cs.size() * 2 + 64); ce.init(&H.keep, (u32)S.cs.size() * 2 + 64);
     for (u64 v : S.cs) cs.push(v);
     for (u64 v : S.ce) ce.push(v);
-    if (gap_map_gaps(cs, ce, H.keep, H.X)) return -10;
+    int gr = gap_map_gaps(cs, ce, H.keep, H.X);
     gap_reform_cords(cs, ce);
-    if (H.ar.ovf || H.keep.ovf) return -11;
+    if (H.ar.ovf == 2) return -12;
+    if (gr || H.ar.ovf || H.keep.ovf || cs.n != ce.n) return -11;
+    S.stats[0] = H.ar.hw; S.stats[1] = H.keep.hw;   // (arena high-water marks, read back through hs_get_stats)
     S.cs.assign(cs.p, cs.p + cs.n);
     S.ce.assign(ce.p, ce.p + ce.n);
     return (i64)S.cs.size();

@@ -227,3 +227,36 @@ def test_product_gap_path_matches_oracle_on_planted_svs():
                 a, b = o.map_read_gap(rd, gap_len, dup), sh.map_read_gap(rd, gap_len, dup)
                 assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (T, i, gap_len, dup)
         o.close()
+
+
+def test_product_gap_path_survives_small_arenas_and_work_budget():
+    """What a k_gap worker does when a read outgrows its arena or its work budget: a clean refusal (the read is then redone with a
+    larger arena, or by a whole wave), never a different answer -- whatever the point at which the memory runs out."""
+    from oracle import pyorc
+    pyorc.build(ref=False)
+    refs = [synth.repeat_ref(300_000, 61), synth.add_n_runs(synth.random_ref(200_000, 62), 63, n_runs=2, max_run=600)]
+    reads_l = sv_reads(refs, 12, 2029)
+    nrun = synth.random_ref(7000, 5).copy(); nrun[600:6400] = 4   # a read of N: 10^5 anchors with thousands of predecessors each
+    o = pyorc.Checker("oracle", refs, 1)
+    sh = shimlib.Shim(refs, 1)
+    fn = sh.lib.hs_map_read_g_lim
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]
+    ok = refused = 0
+    for i, rd in enumerate(reads_l):
+        want = o.map_read_gap(rd, 50, 1)
+        for arena in (256, 3000, 20_000, 50_000, 90_000, 150_000, 300_000, 1 << 20):
+            for keep in (2000, 30_000, 1 << 20):
+                n = fn(sh.h, p(rd, u8p), rd.size, 50, 1, arena, keep, 1 << 62)
+                assert n >= 0 or n == -11, (i, arena, keep, n)
+                if n >= 0:
+                    cs, ce = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64)
+                    sh.lib.hs_get_cords(sh.h, p(cs, u64p), p(ce, u64p))
+                    assert np.array_equal(cs[:n], want[0]) and np.array_equal(ce[:n], want[1]), (i, arena, keep)
+                    ok += 1
+                else:
+                    refused += 1
+    assert ok > 20 and refused > 20, (ok, refused)
+    a = o.map_read_gap(nrun, 50, 0)
+    assert fn(sh.h, p(nrun, u8p), nrun.size, 50, 0, 64 << 20, 1 << 20, 3_000_000) in (-12, len(a[0]))
+    o.close()

@@ -463,3 +463,51 @@ def test_gpu_batch_rerun_on_per_read_overflow(case_inputs, monkeypatch):
         f.filter_batch(reads, off)
     assert e.value.status == -8 and "overflow" in str(e.value)
     f.close()
+
+
+# ---- the gap re-mapper (-g > 0): mapGaps + reformCords on the GPU (k_gap)
+@pytest.mark.parametrize("name", ["ont", "edge"])
+def test_gpu_gap_path_matches_golden(case_inputs, name):
+    """lnr_opts.gap_len = 50 [dup = 1] through the C ABI against the cords the real reference produced with -g 50 [-dup 1]"""
+    from linear_amd import Filter
+    refs, reads, off = case_inputs(name)
+    g = np.load(os.path.join(GOLD, f"{name}_g50_T1.npz"))
+    assert cases.input_digest(refs, reads, off) == str(g["digest"])
+    for dup in (0, 1):
+        f = Filter(device=0, gap_len=50, dup=dup)
+        f.build_index(refs, 1)
+        coff, cs, ce = f.filter_batch(reads, off)
+        assert f.stats()["gap_ms"] > 0
+        f.close()
+        assert np.array_equal(coff, g[f"cord_off_dup{dup}"]), f"dup {dup}"
+        assert np.array_equal(cs, g[f"cords_str_dup{dup}"]), f"dup {dup}"
+        assert np.array_equal(ce, g[f"cords_end_dup{dup}"]), f"dup {dup}"
+
+
+def test_gpu_gap_path_matches_oracle_on_planted_svs(oracle_lib):
+    """reads with planted insertions, deletions, duplications, inversions and translocated stretches on a repeat-rich and an N-run
+    reference, several -g values with and without -dup, index layouts -t 1 and 3; the oracle (pinned to the reference on the same kind
+    of input by tests/test_oracle_golden.py) as the checker."""
+    from linear_amd import Filter, synth
+    from tests.test_gap_shim_cpu import sv_reads
+    refs = [synth.repeat_ref(300_000, 61), synth.add_n_runs(synth.random_ref(200_000, 62), 63, n_runs=2, max_run=600)]
+    rl = sv_reads(refs, 96, 2028)
+    off = np.zeros(len(rl) + 1, np.uint64)
+    off[1:] = np.cumsum([r.size for r in rl])
+    reads = np.concatenate(rl)
+    for T in (1, 3):
+        o = oracle_lib.Checker("oracle", refs, T)
+        for gap_len, dup in ((50, 0), (50, 1), (1, 0), (5, 1), (200, 0)):
+            f = Filter(device=0, gap_len=gap_len, dup=dup)
+            f.build_index(refs, T)
+            coff, cs, ce = f.filter_batch(reads, off)
+            f.close()
+            changed = 0
+            for i, rd in enumerate(rl):
+                a = o.map_read_gap(rd, gap_len, dup)
+                lo, hi = int(coff[i]), int(coff[i + 1])
+                assert np.array_equal(a[0], cs[lo:hi]) and np.array_equal(a[1], ce[lo:hi]), (T, gap_len, dup, i)
+                b = o.map_read(rd)
+                changed += not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))
+            assert changed > len(rl) // 2, "the gap path should change the cords of most of these reads"
+        o.close()
