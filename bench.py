@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed-only", action="store_true", help="time only stage a7 (seed lookup) -- used for the roofline profile")
+    ap.add_argument("--gap", type=int, default=0, help="the reference's -g: 0 = apxMap only (the headline configuration); > 0 = cords go through the gap re-mapper (SURVEY 8 f1)")
+    ap.add_argument("--dup", type=int, default=0, help="the reference's -dup (with --gap)")
     ap.add_argument("--small", action="store_true", help="alias of --workload small")
     args = ap.parse_args()
     if args.small:
@@ -185,7 +187,7 @@ def main():
         from linear_amd.synth_torch import grch38_like_cuda, sample_reads_multi_cuda
 
     # ---- reference + index (outside the timed region); rank 0 owns the build
-    flt = Filter(device=local_rank)
+    flt = Filter(device=local_rank, gap_len=args.gap, dup=args.dup)
     index_s, bcast, t_ref, ref_name, info = 0.0, None, 0.0, "", None
     host_genome = None     # [numpy per sequence] for the CPU baseline (rank 0, N = 1)
     if args.workload == "grch38":
@@ -284,6 +286,9 @@ def main():
     achieved = seed_bytes / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
     wl_key = {"workload": args.workload, "scale": args.scale, "reads": args.reads, "read_len": args.read_len, "err": args.err,
               "layout_threads": T, "seed_only": bool(args.seed_only)}
+    if args.gap:
+        wl_key["gap"] = args.gap
+    dup_flag = " -dup 1" if args.dup else ""
     traffic = recorded_traffic(wl_key, launches / K)
     dev_rate = args.reads * world * args.steps / dt
 
@@ -302,7 +307,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.reads} synthetic {args.read_len} bp ONT-profile reads per GPU per step, a different batch every step ({args.err:.0%} errors 40/30/30 sub/del/ins, "
-                        f"50% revcomp) vs {ref_name}; linear filter -f 2 -i 1 -g 0 -p 1, index layout -t {T}" + ("; SEED LOOKUP STAGE ONLY" if args.seed_only else ""),
+                        f"50% revcomp) vs {ref_name}; linear filter -f 2 -i 1 -g {args.gap}{dup_flag} -p 1, index layout -t {T}" + ("; SEED LOOKUP STAGE ONLY" if args.seed_only else ""),
             "baseline_config": {"grch38": "configs[2] (10 kb ONT reads vs full GRCh38; 1 M reads = 10 steps of 100 k)", "chr22": "configs[1]", "small": "plumbing"}[args.workload],
             "reads_per_gpu_per_step": args.reads,
             "distinct_batches": nb,
@@ -319,8 +324,9 @@ def main():
             "per_read": {"samples": acc["samples"] / total_reads, "lookups": acc["lookups"] / total_reads, "bucket_entries": acc["bucket_entries"] / total_reads,
                          "anchors": acc["anchors"] / total_reads, "cords": acc["cords"] / total_reads, "remap_reads_per_step": acc["remap_reads"] / K},
             "stage_ms_per_step": {"prep": acc["prep_ms"] / K, "seed": acc["seed_count_ms"] / K,
-                                  "job": acc["job_ms"] / K, "tail": acc["tail_ms"] / K, "total_device": acc["total_ms"] / K},
+                                  "job": acc["job_ms"] / K, "tail": acc["tail_ms"] / K, "gap": acc.get("gap_ms", 0.0) / K, "total_device": acc["total_ms"] / K},
             "device_resident_reads_per_s": dev_rate,
+            "gap_second_pass_per_step": acc.get("gap_second_pass", 0) / K,
         },
         "roofline": {
             "bound": "hbm",
@@ -375,7 +381,7 @@ def main():
             rr = h_reads[int(h_off[n0]):int(h_off[n1])]
             oo = h_off[n0:n1 + 1] - h_off[n0]
             t0 = time.time()
-            res = chk.map_batch(rr, oo, threads=cores)
+            res = chk.map_batch(rr, oo, threads=cores, gap_len=args.gap, dup=args.dup)
             return time.time() - t0, res, rr, oo
         pilot = min(args.reads, max(4 * cores, 256))
         tp, _, _, _ = cpu_run(0, pilot)
@@ -384,7 +390,7 @@ def main():
         coff, cs, ce = flt.filter_batch(rr, oo)
         parity_ok = bool(np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce))
         label = ("the reference itself: oracle/_ref/libref_linear.so = the reference's own translation units (base, cords, shape_extend, index_util, "
-                 "cluster_util, pmpfinder) compiled by oracle/Makefile, calculator loop of Mapper::p_calRecords with -g 0") if kind == "ref" else \
+                 "cluster_util, pmpfinder, gap, gap_util) compiled by oracle/Makefile, calculator loop of Mapper::p_calRecords with -g " + str(args.gap) + (" -dup 1" if args.dup else "")) if kind == "ref" else \
                 "oracle/lnr_oracle.cpp (bit-exact restatement of the reference)"
         out["cpu_baseline"] = {"value": ns / t_cpu, "unit": "reads/s", "cores": cores, "kind": "reference" if kind == "ref" else "port",
                                "sample": f"first {ns} reads of batch 0, {label}, {cores} OpenMP threads ({cores_note}); {t_cpu:.2f} s wall; "

@@ -108,7 +108,7 @@ typedef struct lnr_stats {
     uint64_t seed_bytes;
     double prep_ms, seed_count_ms, seed_gather_ms, job_ms, tail_ms, total_ms;
     uint32_t seed_count_launches, seed_gather_launches, job_launches;
-    uint32_t reserved1;
+    uint32_t gap_second_pass;  /* reads the gap re-mapper ran a second time (one wave per read: out of arena or over the work budget as one lane) */
     double gap_ms;             /* device time of the gap re-mapper (-g > 0) */
 } lnr_stats;
 

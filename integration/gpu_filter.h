@@ -18,11 +18,14 @@
 
 struct GpuFilter {
     lnr_ctx *ctx;
-    explicit GpuFilter(int device = -1, unsigned index_type = 1 /* options.index_t: 1 DIndex, 2 HIndex (mapper.cpp:200) */) : ctx(nullptr) {
+    explicit GpuFilter(int device = -1, unsigned index_type = 1 /* options.index_t: 1 DIndex, 2 HIndex (mapper.cpp:200) */,
+                       unsigned gap_len = 1 /* options.gap_len (mapper.cpp:209-231) */, unsigned f_dup = 0 /* options.f_dup (mapper.cpp:208) */) : ctx(nullptr) {
         lnr_opts o;
         lnr_opts_default(&o);
         o.device = device;
         o.index_type = index_type;
+        o.gap_len = gap_len;
+        o.dup = f_dup;
         if (lnr_create(&o, &ctx) != LNR_OK) ctx = nullptr;   // no GPU -> the caller keeps the CPU path
     }
     ~GpuFilter() { lnr_destroy(ctx); }

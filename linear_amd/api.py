@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "liblinear_amd.so")
+SO = os.environ.get("LNR_LIB") or os.path.join(HERE, "liblinear_amd.so")   # LNR_LIB: a variant build (tools/build_variant.sh) for A/B measurements
 
 _u8p, _u64p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
 
@@ -45,7 +45,7 @@ class LnrAnchors(C.Structure):
 class LnrStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("reads", "bases", "jobs", "samples", "lookups", "bucket_entries", "anchors", "remap_reads", "cords", "seed_bytes")] + \
                [(k, C.c_double) for k in ("prep_ms", "seed_count_ms", "seed_gather_ms", "job_ms", "tail_ms", "total_ms")] + \
-               [(k, C.c_uint32) for k in ("seed_count_launches", "seed_gather_launches", "job_launches", "reserved1")] + [("gap_ms", C.c_double)]
+               [(k, C.c_uint32) for k in ("seed_count_launches", "seed_gather_launches", "job_launches", "gap_second_pass")] + [("gap_ms", C.c_double)]
 
 
 class LnrError(RuntimeError):

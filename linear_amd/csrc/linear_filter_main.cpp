@@ -1,10 +1,11 @@
 // linear_filter_main.cpp -- `linear filter` front-end over the C ABI (include/linear_amd.h): the reference's command line
-// (src/args_parser.cpp:31,150-270: `linear filter <reads> <genome> [-o prefix] [-t N] [-g 0] [-ot 1|2|3]`) driving
+// (src/args_parser.cpp:31,150-270: `linear filter <reads> <genome> [-o prefix] [-t N] [-g len] [-dup 0|1] [-ot 1|2|3]`) driving
 //     lnr_reader_*  (FASTA / FASTQ(.gz) -> pinned blocks)  ->  lnr_filter_submit / lnr_filter_wait (HIP hot path)  ->
 //     lnr_writer_*  (cords -> <prefix>.sam / <prefix>.apf, mapper.cpp:360,627)
 // with two read blocks in flight: block k + 1 is decoded and uploaded while block k is on the GPU, and block k - 1's text is
 // written.  Plain C++ host code: everything it does goes through the ABI, so it doubles as the integration example.
-// Out of scope here as in the library: -g > 0 (gap re-mapper), -i 2, alignment.  Output order = input order.
+// -g as in the reference: 1 (the default) = gaps of 50 and more are re-mapped, 0 = off (base.cpp:34, mapper.cpp:209-231).  Out of
+// scope here as in the library: alignment (-a).  Output order = input order.
 #include "../../include/linear_amd.h"
 
 #include <chrono>
@@ -25,24 +26,24 @@ struct Block {
 
 int main(int argc, char **argv) {
     if (argc < 4 || strcmp(argv[1], "filter") != 0) {
-        fprintf(stderr, "usage: %s filter <reads.fa|fq[.gz]> <genome.fa[.gz]> [-o prefix] [-t threads] [-i 1|2] [-g 0] [-ot 1|2|3] [-b reads_per_block]\n", argv[0]);
+        fprintf(stderr, "usage: %s filter <reads.fa|fq[.gz]> <genome.fa[.gz]> [-o prefix] [-t threads] [-i 1|2] [-g gap_len] [-dup 0|1] [-ot 1|2|3] [-b reads_per_block]\n", argv[0]);
         return 2;
     }
     std::string reads_path = argv[2], genome_path = argv[3], prefix = "out", cmd;
     for (int i = 0; i < argc; i++) { if (i) cmd += ' '; cmd += argv[i]; }
-    unsigned threads = 1, ot = 3, gap = 0, index_type = 1;
+    unsigned threads = 1, ot = 3, gap = 1, dup = 0, index_type = 1;   // (Options::Options base.cpp:28-45)
     uint32_t block_reads = 65536;
     for (int i = 4; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "-o") prefix = argv[i + 1];
         else if (k == "-t") threads = (unsigned)atoi(argv[i + 1]);
         else if (k == "-g") gap = (unsigned)atoi(argv[i + 1]);
+        else if (k == "-dup") dup = (unsigned)atoi(argv[i + 1]) ? 1u : 0u;
         else if (k == "-i") index_type = (unsigned)atoi(argv[i + 1]);   // 1 DIndex, 2 HIndex (args_parser.cpp:221)
         else if (k == "-ot") ot = (unsigned)atoi(argv[i + 1]);
         else if (k == "-b") block_reads = (uint32_t)atoi(argv[i + 1]);
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
-    if (gap != 0) { fprintf(stderr, "E: -g %u: the gap re-mapper is not part of this build (use -g 0)\n", gap); return 2; }
     if (threads < 1) threads = 1;
     double t0 = now();
     // ---- genome
@@ -71,6 +72,8 @@ int main(int argc, char **argv) {
     lnr_opts opts;
     lnr_opts_default(&opts);
     opts.index_type = index_type;
+    opts.gap_len = gap;
+    opts.dup = dup;
     lnr_status s = lnr_create(&opts, &ctx);
     if (s != LNR_OK) { fprintf(stderr, "E: %s\n", lnr_strerror(s)); return 1; }
     std::vector<const uint8_t *> gp; std::vector<uint64_t> gl; std::vector<const char *> gn;

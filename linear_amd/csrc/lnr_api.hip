@@ -154,7 +154,7 @@ struct lnr_ctx {
     u32 overflow_reruns = 0;
     u32 seed_lds_pad = 0;   // diagnostic (LNR_SEED_LDS_PAD): dynamic LDS the seed kernel does not use, to lower its waves per CU
     DevBuf hx_nkeys, hx_nvals; u32 hx_nnodes = 0; u64 hx_empty_dir = 0;   // HIndex (-i 2): dir = hdir[2^18] (head of the block of X, -1: none), hs = ysa, nodes of the large blocks
-    DevBuf gap_arena, gap_flag, gap_next, d_seq_len;   // the gap re-mapper (-g > 0): arenas of its workers, per-read retry flags, the two work counters
+    DevBuf gap_arena, gap_flag, gap_next, d_seq_len, gap_prof;   // the gap re-mapper (-g > 0): arenas of its workers, per-read retry flags, the two work counters
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl, ov;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines, ov = their aligned overflow lines (k_ix_lines)
     // ---- batch inputs / per-read arrays
     // host-buffer entry points: two input slots, so that the upload of the next batch (copy stream) runs under the kernels of
@@ -196,6 +196,7 @@ struct lnr_ctx {
     u64 last_ncords = 0;
     lnr_stats stats{};
     Timer t_prep, t_job, t_tail, t_total, t_gap;
+    int gap_mode = 1; u32 gap_waves = 16384, gap_arena2_mb = 64;   // LNR_GAP_MODE=1: the first launch of k_gap runs one wave per read as well (LNR_GAP_WAVES of them)
     u64 gap_work_cap = 3000000;   // pair evaluations of the chain DPs one lane spends on a read before the read goes to the wave-per-read launch (LNR_GAP_WORK_CAP)
 };
 
@@ -1087,13 +1088,16 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         for (u32 i = 0; i < n; i++) maxlen = std::max(maxlen, B.len[i]);
         const u64 budget = (u64)48 << 30;
         u64 arena1 = align_up(((u64)512 << 10) * ctx->cap_scale + 16ULL * maxlen + sizeof(LeaderScratch) + 65536, 256);
-        u64 arena2 = std::max<u64>(((u64)64 << 20) * ctx->cap_scale, arena1 * 8);
-        u32 w1 = (u32)std::min<u64>(align_up(n, 64), std::max<u64>(64, (budget / arena1) / 64 * 64));
-        u32 w2 = (u32)std::min<u64>(n, std::max<u64>(1, (budget / 2) / arena2));   // waves of the second launch
-        ENSURE(ctx->gap_arena, std::max((u64)w1 * arena1, (u64)w2 * arena2));
+        u64 arena2 = std::max<u64>(((u64)ctx->gap_arena2_mb << 20) * ctx->cap_scale, arena1 * 2);
+        u64 arena3 = std::max<u64>(((u64)64 << 20) * ctx->cap_scale, arena2 * 2);
+        u32 w1 = (u32)std::min<u64>(align_up(n, 64), std::max<u64>(64, (budget / arena1) / 64 * 64));   // workers: lanes, or waves with LNR_GAP_MODE=1
+        if (ctx->gap_mode) w1 = std::min<u32>(w1, ctx->gap_waves);
+        u32 w2 = (u32)std::min<u64>(std::min<u64>(n, ctx->gap_waves), std::max<u64>(1, budget / arena2));   // waves of the second launch
+        u32 w3 = (u32)std::min<u64>(n, std::max<u64>(1, (budget / 2) / arena3));
+        ENSURE(ctx->gap_arena, std::max(std::max((u64)w1 * arena1, (u64)w2 * arena2), (u64)w3 * arena3));
         ENSURE(ctx->gap_flag, (size_t)n * 4);
-        ENSURE(ctx->gap_next, 64);
-        HIPCK(hipMemsetAsync(ctx->gap_next.p, 0, 64, ctx->stream));
+        ENSURE(ctx->gap_next, 256);
+        HIPCK(hipMemsetAsync(ctx->gap_next.p, 0, 256, ctx->stream));
         GapArgs G;
         G.g = ctx->g.as<u8>(); G.seq_off = ctx->d_seq_off.as<u64>(); G.seq_len = ctx->d_seq_len.as<u64>();
         G.gf.base = ctx->f2.as<F96>(); G.gf.off = ctx->d_f2_off.as<u64>(); G.gf.nseq = ctx->info.nseq;
@@ -1102,28 +1106,54 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         G.out_str = ctx->out_str.as<u64>(); G.out_end = ctx->out_end.as<u64>(); G.cords_off = ctx->cords_off.as<u64>(); G.cords_cap = ctx->cords_cap.as<u32>();
         G.nout = ctx->nout.as<u32>(); G.read_err = ctx->read_err.as<i32>(); G.gap_flag = ctx->gap_flag.as<u32>();
         G.arena = (char *)ctx->gap_arena.p;
+        G.prof = nullptr;
+#ifdef LNR_GAP_DEVPROF
+        ENSURE(ctx->gap_prof, 96 * 8);
+        HIPCK(hipMemsetAsync(ctx->gap_prof.p, 0, 96 * 8, ctx->stream));
+        G.prof = ctx->gap_prof.as<unsigned long long>();
+#endif
         G.gap_len_min = ctx->opts.gap_len == 1 ? 50 : (ctx->opts.gap_len < 10 ? 10 : ctx->opts.gap_len);   // mapper.cpp:438-453
         G.f_dup = (int)ctx->opts.dup;
         ctx->t_gap.start(ctx->stream);
         G.work_cap = ctx->gap_work_cap;
-        G.arena_bytes = arena1; G.next = ctx->gap_next.as<u32>(); G.big = 0;
-        hipLaunchKernelGGL(k_gap, dim3(w1 / 64), dim3(64), 0, ctx->stream, G); KCHECK();
-        G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1;
+        G.arena_bytes = arena1; G.next = ctx->gap_next.as<u32>(); G.big = 0; G.last = 0; G.coop = ctx->gap_mode;
+        hipLaunchKernelGGL(k_gap, dim3(ctx->gap_mode ? w1 : w1 / 64), dim3(64), 0, ctx->stream, G); KCHECK();
+        G.work_cap = ~0ULL;
+        G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1; G.coop = 1;
         hipLaunchKernelGGL(k_gap, dim3(w2), dim3(64), 0, ctx->stream, G); KCHECK();
+        G.arena_bytes = arena3; G.next = ctx->gap_next.as<u32>() + 24; G.last = 1;
+        hipLaunchKernelGGL(k_gap, dim3(w3), dim3(64), 0, ctx->stream, G); KCHECK();
         ctx->t_gap.stop(ctx->stream);
+#ifdef LNR_GAP_DEVPROF
+        {
+            unsigned long long hp[96];
+            HIPCK(hipMemcpyAsync(hp, ctx->gap_prof.p, sizeof hp, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCK(hipStreamSynchronize(ctx->stream));
+            static const char *nm[10] = {"sort k-mers", "join", "k-mer stream", "sort anchors", "chain DP", "traceback", "chain tiles", "map along chain (incl.)", "tiles from chain", "filter anchors (sorts)"};
+            for (int L = 0; L < 3; L++) {
+                const unsigned long long *q = hp + 16 * L;
+                fprintf(stderr, "[gap prof] launch %d: reads %llu, lane/wave time %.1f ms in total, slowest read %.1f ms\n", L, q[12], q[11] / 1e5, q[15] / 1e5);
+                const unsigned long long *w = hp + 48 + 16 * L;
+                fprintf(stderr, "[gap prof]    slowest read: index %llu, length %llu, cords in %llu, arena high-water %llu bytes\n", w[10], w[11], w[12], w[13]);
+                for (int k = 0; k < 10; k++) fprintf(stderr, "[gap prof]    %-26s %10.1f ms  %5.1f %%   slowest read: %8.1f ms\n", nm[k], q[k] / 1e5, q[11] ? 100.0 * q[k] / q[11] : 0.0, w[k] / 1e5);
+            }
+        }
+#endif
     }
     std::vector<u32> nout(n);
     std::vector<i32> rerr(n);
+    u32 gap_second = 0;
     {
         Readback rb;
-        if (!rb.begin(ctx->h_rb[0], (size_t)n * 8 + 64)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+        if (!rb.begin(ctx->h_rb[0], (size_t)n * 8 + 256)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
         HIPCK(rb.add(nout.data(), ctx->nout.p, (size_t)n * 4, ctx->stream));
         HIPCK(rb.add(rerr.data(), ctx->read_err.p, (size_t)n * 4, ctx->stream));
+        if (ctx->opts.gap_len) HIPCK(rb.add(&gap_second, ctx->gap_next.as<u32>() + 16, 4, ctx->stream));
         HIPCK(hipStreamSynchronize(ctx->stream));
         rb.finish();
     }
     ctx->stats.tail_ms += ctx->t_tail.ms();
-    if (ctx->opts.gap_len) ctx->stats.gap_ms += ctx->t_gap.ms();
+    if (ctx->opts.gap_len) { ctx->stats.gap_ms += ctx->t_gap.ms(); ctx->stats.gap_second_pass += gap_second; }
     for (u32 i = 0; i < n; i++)
         if (rerr[i]) {
             // A read outgrew a per-read capacity (cords: 16 per 64 bases + 256; gaps: one per 1000 bases + 4 -- heuristics, generous by an
@@ -1331,6 +1361,9 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     ctx->device = dev;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (const char *e = getenv("LNR_CAP_SHRINK")) { long v = atol(e); if (v >= 1 && v <= 4096) ctx->cap_shrink = (u32)v; }
+    if (const char *e = getenv("LNR_GAP_MODE")) ctx->gap_mode = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LNR_GAP_WAVES")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) ctx->gap_waves = (u32)v; }
+    if (const char *e = getenv("LNR_GAP_ARENA2_MB")) { long v = atol(e); if (v >= 1 && v <= 1024) ctx->gap_arena2_mb = (u32)v; }
     if (const char *e = getenv("LNR_GAP_WORK_CAP")) { long long v = atoll(e); if (v >= 0) ctx->gap_work_cap = (u64)v; }
     if (const char *e = getenv("LNR_SEED_LDS_PAD")) { long v = atol(e); if (v >= 0 && v <= 100000) ctx->seed_lds_pad = (u32)v; }
     if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }

@@ -116,8 +116,18 @@ struct GapCtx {                                           // one read
     GapParms gp;
     u64 work = 0, work_cap = ~0ULL;                       // pair evaluations of the chain DPs so far / the budget (over it: ar->ovf = 2)
     int coop = 0;                                         // device: all 64 lanes of the wave run this read together (k_gap, second launch)
+#ifdef LNR_GAP_DEVPROF
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ticks per phase (diagnostic build, tools/measure/gap_prof.sh)
+#endif
     LNR_HD GSeq ref(u64 id) const { GSeq s; s.p = g + seq_off[id]; s.len = seq_len[id]; return s; }
 };
+
+#if defined(LNR_GAP_DEVPROF) && defined(__HIP_DEVICE_COMPILE__)
+struct GpScope { GapCtx &X; int i; unsigned long long t0; __device__ GpScope(GapCtx &x, int k) : X(x), i(k), t0(wall_clock64()) {} __device__ ~GpScope() { X.prof[i] += wall_clock64() - t0; } };
+#define GP(X, k) GpScope _gp_scope(X, k)
+#else
+#define GP(X, k) do {} while (0)
+#endif
 
 // ---- k-mer streams (shape_extend.cpp:86-116 hashInit, :231-243 hashNextV, :122-131 / :213-219 the single-strand pair)
 struct GShape { u64 h, crh; int x, left; u32 span; };
@@ -190,9 +200,10 @@ LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, 
         if (t < base + acc && t >= lo) out.push(a);
     }
 }
-template <class F> LNR_HD inline void g_hs_blocks(GVec<u64> &g_hs, int shape_len, SortStack &st, F &&emit) {
+template <class F> LNR_HD inline void g_hs_blocks(GVec<u64> &g_hs, int shape_len, GapCtx &X, F &&emit) {
     u64 mask = (1ULL << (2 * shape_len + 33)) - 1;
-    ref_sort(g_hs.p, (long)g_hs.n, [mask](const u64 &a, const u64 &b) { return (a & mask) < (b & mask); }, st);
+    { GP(X, 0); ref_sort(g_hs.p, (long)g_hs.n, [mask](const u64 &a, const u64 &b) { return (a & mask) < (b & mask); }, X.ls->st); }
+    GP(X, 1);
     int p1 = 0, p2 = 0;
     for (int k = 1; k < (int)g_hs.n; k++) {
         u64 t = g_hs_xt((g_hs[(u32)k] ^ g_hs[(u32)k - 1]) & mask);
@@ -203,10 +214,10 @@ template <class F> LNR_HD inline void g_hs_blocks(GVec<u64> &g_hs, int shape_len
     }
 }
 LNR_HD inline void g_create_anchors(GVec<u64> &g_hs, GVec<u64> &anchors, int shape_len, int direction, i64 lower, i64 upper, u64 rvcp, u64 gap_str, u64 gap_end, GapCtx &X) {
-    g_hs_blocks(g_hs, shape_len, X.ls->st, [&](int p1, int p2, int k) { g_set_anchors(g_hs, anchors, p1, p2, k, rvcp, lower, upper, gap_str, gap_end, direction, X.gp); });
+    g_hs_blocks(g_hs, shape_len, X, [&](int p1, int p2, int k) { g_set_anchors(g_hs, anchors, p1, p2, k, rvcp, lower, upper, gap_str, gap_end, direction, X.gp); });
 }
 LNR_HD inline void g_create_anchor_pair(GVec<u64> &g_hs, GVec<u64> &a1, GVec<u64> &a2, int shape_len, u64 rvcp, u64 gs1, u64 ge1, u64 gs2, u64 ge2, GapCtx &X) {
-    g_hs_blocks(g_hs, shape_len, X.ls->st, [&](int p1, int p2, int k) {
+    g_hs_blocks(g_hs, shape_len, X, [&](int p1, int p2, int k) {
         g_set_anchors(g_hs, a1, p1, p2, k, rvcp, 0, 0, gs1, ge1, 1, X.gp);
         g_set_anchors(g_hs, a2, p1, p2, k, rvcp, 0, 0, gs2, ge2, -1, X.gp);
     });
@@ -338,6 +349,8 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
     // record 0 are whatever the allocator left -- 0 in practice, as here)
     for (u32 i = 0; i < n; i++) { r.score[i] = 0; r.score2[i] = 0; r.len[i] = 0; r.p2[i] = 0; r.root[i] = 0; r.leaf[i] = 0; }
     r.score[0] = 0; r.len[0] = 1; r.p2[0] = -1;
+    {
+    GP(X, 4);
 #if defined(__HIP_DEVICE_COMPILE__)
     if (X.coop) {
         // every lane runs the read's code with the same data; here the predecessors of anchor i are dealt over the lanes, 64 at a
@@ -377,6 +390,8 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
         X.work += (u64)(i - 1 - j);
         if (X.work > X.work_cap) { X.ar->ovf = 2; return; }
     }
+    }
+    GP(X, 5);
     // the output may grow while the records live above it in the arena: collect into a vector allocated before them
     TileSink sink; sink.anchors = anchors; sink.tiles = &out; sink.first_len = 0; sink.nchains = 0; sink.to_tiles = to_tiles;
     out.reserve(out.n + n);
@@ -472,6 +487,7 @@ LNR_HD inline void gap_chain_blocks_cords(GVec<u64> &tiles, GVec<UP> &sep, u64 L
     tiles.n = n;
 }
 LNR_HD inline void gap_chain_tiles(GVec<u64> &tiles, u64 L, u64 gap_size, GapCtx &X) {       // chainTiles gap_util.cpp:1177-1189
+    GP(X, 6);
     GVec<UP> sep; sep.init(X.ar);
     gap_gather_tile_blocks(tiles.p, tiles.n, sep, L, gap_size);
     if (X.ar->ovf) return;
@@ -479,7 +495,7 @@ LNR_HD inline void gap_chain_tiles(GVec<u64> &tiles, u64 L, u64 gap_size, GapCtx
 }
 LNR_HD inline void g_chains_from_anchors(GVec<u64> &anchors, GVec<u64> &tiles, u64 L, GapCtx &X) {   // g_CreateChainsFromAnchors_ gap_util.cpp:1191-1222
     if (X.ar->ovf) return;
-    ref_sort(anchors.p, (long)anchors.n, [](const u64 &a, const u64 &b) { return ganc_x(a) > ganc_x(b); }, X.ls->st);
+    { GP(X, 3); ref_sort(anchors.p, (long)anchors.n, [](const u64 &a, const u64 &b) { return ganc_x(a) > ganc_x(b); }, X.ls->st); }
     int fn = X.gp.chn1_fn;
     gap_chain_anchors(anchors.p, anchors.n, tiles, true, 20, 80, 20, X.gp.chn1_min_len, X.gp.chn1_abort, [fn](u64 a, u64 b) { return fn == 2 ? gap_anchor_score2(a, b) : gap_anchor_score1(a, b); }, X);
     gap_chain_tiles(tiles, L, 100, X);
@@ -526,6 +542,7 @@ LNR_HD inline u32 tile_fscore_tri(u64 &t, const GapCtx &X, u64 lower_x, u64 lowe
 }
 LNR_HD inline void tiles_from_chain(const GVec<u64> &ch, GVec<u64> &tiles, u64 gap_str, u64 gap_end, int it_str, int it_end, GapCtx &X) {   // g_CreateTilesFromChains_ :1275-1359 (chain = tiles)
     if (it_end - it_str == 0) return;
+    GP(X, 8);
     u64 pre_chain = ch[(u32)it_str], pre_tile = 0;
     i64 tmp_shift = X.gp.thd_tile_size / 2;
     u64 step = (u64)(X.gp.thd_tile_size / 3);
@@ -799,6 +816,7 @@ LNR_HD inline IPair gap_chain_overlaps(const GVec<u64> &c1, const GVec<u64> &c2,
 // re-map with the small pattern along tiles[i_str, i_end) (mapAlongChain :3320-3377): the first resulting chain, as tiles
 LNR_HD inline int gap_map_along_chain(const GSeq &ref, const GSeq &seq2, const GVec<u64> &ch, GVec<u64> &tiles, int i_str, int i_end, int shape_len, int step1, int step2, GapCtx &X) {
     if (ch.empty() || i_str < 0 || i_end > (int)ch.n || i_end <= i_str) return -1;
+    GP(X, 7);
     GVec<u64> hs, anc; hs.init(X.ar, 1024); anc.init(X.ar, 1024);
     u64 a = ch[(u32)i_str], b = ch[(u32)i_end - 1];
     i64 as = (i64)(cord_x(a) - cord_y(a)), ae = (i64)(cord_x(b) - cord_y(b));
@@ -912,7 +930,7 @@ LNR_HD inline void gap_extend_interval_one_side(const GSeq &ref, GVec<u64> &tile
     int od = gp.direction;
     gp.direction = direction;
     GVec<u64> g_hs, anc, chain; g_hs.init(X.ar, 2048); anc.init(X.ar, 2048); chain.init(X.ar, 256);
-    g_stream(ref, X.read, g_hs, gap_str, gap_end, (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2);
+    { GP(X, 2); g_stream(ref, X.read, g_hs, gap_str, gap_end, (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2); }
     g_create_anchors(g_hs, anc, gp.thd_eis_shape_len, direction, 0, 0, X.read.len - 1, gap_str, gap_end, X);
     g_chains_from_anchors(anc, chain, X.read.len, X);
     closest_extension_chain(chain, gap_str, gap_end, true, gp);
@@ -959,7 +977,7 @@ LNR_HD inline void gap_map_extends(const GSeq &ref, GVec<u64> &ts1, GVec<u64> &t
         u64 id = cord_id(gs1), strand = cord_strand(gs1);
         u64 x1 = cord_x(gs1) < cord_x(gs2) ? cord_x(gs1) : cord_x(gs2), y1 = cord_y(gs1) < cord_y(gs2) ? cord_y(gs1) : cord_y(gs2);
         u64 x2 = cord_x(ge1), y2 = cord_y(ge1) > cord_y(ge2) ? cord_y(ge1) : cord_y(ge2);                   // (x of gap_end1 twice in the reference)
-        g_stream(ref, X.read, g_hs, create_cord(id, x1, y1, strand), create_cord(id, x2, y2, strand), (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2);
+        { GP(X, 2); g_stream(ref, X.read, g_hs, create_cord(id, x1, y1, strand), create_cord(id, x2, y2, strand), (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2); }
         g_create_anchor_pair(g_hs, a1, a2, gp.thd_eis_shape_len, X.read.len - 1, gs1, ge1, gs2, ge2, X);
         int od2 = gp.direction;                                                                             // extendsTilesFromAnchors :3643-3692
         gp.direction = 1;
@@ -1019,6 +1037,7 @@ LNR_HD inline void gap_tiles_from_anchors2(const GSeq &ref, GVec<u64> &anchors, 
     }
 }
 LNR_HD inline void gap_filter_anchors(GVec<u64> &a, GapCtx &X) {                            // filterGapAnchors gap_util.cpp:4275-4441 (density 20, accept 20, err bit 0)
+    GP(X, 9);
     GVec<UP> list; list.init(X.ar);
     if (a.n > 1) {
         a[0] = 0;
@@ -1057,7 +1076,7 @@ LNR_HD inline void gap_map_generic(const GSeq &ref, GVec<u64> &ts, GVec<u64> &te
     X.gp.f_rfts_clip = 0;
     if (!cord_strand(gap_str ^ gap_end)) {
         GVec<u64> g_hs, anc; g_hs.init(X.ar, 2048); anc.init(X.ar, 2048);
-        g_stream(ref, X.read, g_hs, gap_str, gap_end, 9, 5, 1);
+        { GP(X, 2); g_stream(ref, X.read, g_hs, gap_str, gap_end, 9, 5, 1); }
         g_create_anchors(g_hs, anc, 9, 0, -(((i64)1 << 62) - 1), ((i64)1 << 62) - 1, X.read.len - 1, gap_str, gap_end, X);
         if (anc.n > 1000) gap_filter_anchors(anc, X);
         gap_tiles_from_anchors2(ref, anc, ts, te, gap_str, gap_end, X.read.len - 1, X);

@@ -2908,8 +2908,8 @@ __global__ void __launch_bounds__(64) k_gather_out(const u64 *out_str, const u64
 // cords of every read, in place in the per-read output slots.  One lane = one worker with an arena of its own; workers take reads
 // from a shared counter (the work per read ranges from nothing to dozens of k-mer joins).  A read whose gaps outgrow the arena (or
 // whose new cords outgrow its slot), or whose chain DPs go over the work budget (a read of N runs joins into 10^5 anchors with
-// thousands of predecessors each), keeps its apxMap cords and is flagged in gap_flag; the second launch (big = 1) takes only the
-// flagged reads, one WAVE per read with a large arena: all lanes run the read's code with the same data (stores of one value to one
+// thousands of predecessors each), keeps its apxMap cords and is flagged in gap_flag; the second and the third launch (big = 1) take
+// only the flagged reads, one WAVE per read with a larger (8 MB) and a large (64 MB) arena: all lanes run the read's code with the same data (stores of one value to one
 // address), and the chain DP deals the predecessors of an anchor over the lanes (gap_chain_anchors).  What is still flagged
 // afterwards is reported through read_err.
 struct GapArgs {
@@ -2917,17 +2917,25 @@ struct GapArgs {
     const u8 *reads; const u64 *off; u32 n;
     const u32 *nf; const u64 *f1_off; const F96 *f1;
     u64 *out_str, *out_end; const u64 *cords_off; const u32 *cords_cap; u32 *nout; i32 *read_err; u32 *gap_flag;
-    char *arena; u64 arena_bytes; u32 *next; u32 gap_len_min; int f_dup; int big; u64 work_cap;
+    unsigned long long *prof;   // LNR_GAP_DEVPROF builds: [launch][16] ticks per phase, [15] = the slowest read
+    char *arena; u64 arena_bytes; u32 *next; u32 gap_len_min; int f_dup; u64 work_cap;
+    int coop;   // one wave per read (the launches after the first; LNR_GAP_MODE=1: the first too)
+    int big;    // only the reads an earlier launch flagged
+    int last;   // what this launch cannot do either is an error of the read
 };
-__global__ void __launch_bounds__(64) k_gap(GapArgs A) {
-    u32 worker = A.big ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+#ifndef K_GAP_WAVES
+#define K_GAP_WAVES 1
+#endif
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(K_GAP_WAVES, K_GAP_WAVES))) k_gap(GapArgs A) {
+    u32 worker = A.coop ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
     char *mine = A.arena + (u64)worker * A.arena_bytes;
     for (;;) {
         u32 r;
-        if (A.big) { r = threadIdx.x == 0 ? atomicAdd(A.next, 1u) : 0u; r = (u32)__shfl((int)r, 0); }
+        if (A.coop) { r = threadIdx.x == 0 ? atomicAdd(A.next, 1u) : 0u; r = (u32)__shfl((int)r, 0); }
         else r = atomicAdd(A.next, 1u);
         if (r >= A.n) break;
         if (A.big && !A.gap_flag[r]) continue;
+        if (A.big && threadIdx.x == 0) atomicAdd(A.next + 8, 1u);   // (statistics: reads of the second launch)
         u32 nc = A.nout[r];
         u64 L = A.off[r + 1] - A.off[r];
         if (L <= 200 || nc <= 1) { if (!A.big) A.gap_flag[r] = 0; continue; }
@@ -2950,12 +2958,24 @@ __global__ void __launch_bounds__(64) k_gap(GapArgs A) {
             X.f1[0].p = A.f1 + A.f1_off[r]; X.f1[0].n = nf; X.f1[1].p = A.f1 + A.f1_off[r] + nf; X.f1[1].n = nf;
             X.gf = A.gf;
             X.gp.f_dup = A.f_dup; X.gp.thd_gap_len_min = A.gap_len_min;
-            X.coop = A.big; X.work_cap = A.big ? ~0ULL : A.work_cap;
+            X.coop = A.coop; X.work_cap = A.work_cap;
             u64 *os = A.out_str + A.cords_off[r], *oe = A.out_end + A.cords_off[r];
             GVec<u64> cs, ce; cs.init(&keep, nc * 2 + 64); ce.init(&keep, nc * 2 + 64);
             for (u32 i = 0; i < nc; i++) { cs.push(os[i]); ce.push(oe[i]); }
+#ifdef LNR_GAP_DEVPROF
+            unsigned long long t_read = wall_clock64();
+#endif
             int rc_ = gap_map_gaps(cs, ce, keep, X);
             gap_reform_cords(cs, ce);
+#ifdef LNR_GAP_DEVPROF
+            if (A.prof && threadIdx.x == (A.coop ? 0u : threadIdx.x)) {
+                unsigned long long *pp = A.prof + 16 * (A.big + A.last);
+                t_read = wall_clock64() - t_read;
+                for (int k = 0; k < 10; k++) atomicAdd(pp + k, X.prof[k]);
+                atomicAdd(pp + 11, t_read); atomicAdd(pp + 12, 1ULL);
+                if (atomicMax(pp + 15, t_read) < t_read) { unsigned long long *ps = A.prof + 48 + 16 * (A.big + A.last); for (int k = 0; k < 10; k++) ps[k] = X.prof[k]; ps[10] = r; ps[11] = L; ps[12] = nc; ps[13] = ar.hw; }
+            }
+#endif
             bad = rc_ != 0 || ar.ovf || keep.ovf || cs.n > A.cords_cap[r] || cs.n != ce.n;
             if (!bad) {
                 for (u32 i = 0; i < cs.n; i++) { os[i] = cs[i]; oe[i] = ce[i]; }
@@ -2963,7 +2983,7 @@ __global__ void __launch_bounds__(64) k_gap(GapArgs A) {
             }
         }
         A.gap_flag[r] = bad ? 1 : 0;
-        if (A.big && bad) A.read_err[r] = 5;
+        if (A.last && bad) A.read_err[r] = 5;
     }
 }
 

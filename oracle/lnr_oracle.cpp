@@ -1816,8 +1816,14 @@ uint64_t orc_debug_get(void *h, int stage, uint64_t *out, uint64_t cap) {
 
 // batch helper: maps reads [0,n) with `threads` OpenMP threads (per-thread Work), writes CSR in read order.
 // stats5 (optional) accumulates samples, lookups, bucket entries, anchors, DP pair evaluations over the batch.
+uint64_t orc_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
+                         uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint64_t *stats5, uint32_t gap_len, int f_dup);
 uint64_t orc_map_batch(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
                        uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint64_t *stats5) {
+    return orc_map_batch_g(h, reads, off, n, threads, cord_off, cords_str, cords_end, cap, stats5, 0, 0);
+}
+uint64_t orc_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
+                         uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint64_t *stats5, uint32_t gap_len, int f_dup) {
     Ctx *c = (Ctx *)h;
     if (threads < 1) threads = 1;
     std::vector<std::vector<u64>> rs(n), re(n);
@@ -1833,6 +1839,21 @@ uint64_t orc_map_batch(void *h, const uint8_t *reads, const uint64_t *off, uint3
         std::vector<uint8_t> s(len + SEQ_PAD, 0);
         memcpy(s.data(), reads + off[i], len);
         apxMap(*c, w, s.data(), len);
+        if (gap_len && len > 200) {
+            std::vector<uint8_t> com(len + SEQ_PAD, 0);
+            static const uint8_t cpl[5] = {3, 2, 1, 0, 4};
+            for (u64 k = 0; k < len; k++) com[k] = cpl[s[len - k - 1]];
+            Feat f1[2];
+            createFeatures2_48(s.data(), (i64)len, f1[0]);
+            createFeatures2_48(com.data(), (i64)len, f1[1]);
+            GapFeat F{f1, &c->f2};
+            GapGenome G{&c->seqs, &c->lens};
+            GapParms gp;
+            gp.f_dup = f_dup;
+            gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
+            mapGaps(G, Seq{s.data(), len}, Seq{com.data(), len}, w.cords_str, w.cords_end, w.apx_gaps, F, gp);
+            reformCords(w.cords_str, w.cords_end);
+        }
         rs[i] = w.cords_str;
         re[i] = w.cords_end;
     }

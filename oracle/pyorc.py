@@ -176,23 +176,28 @@ class Checker:
         n = fn(self.h, _p(out, _u64p), 4096)
         return out[: 2 * n].reshape(-1, 2).copy()
 
-    def map_batch(self, reads: np.ndarray, off: np.ndarray, threads: int = 1):
+    def map_batch(self, reads: np.ndarray, off: np.ndarray, threads: int = 1, gap_len: int = 0, dup: int = 0):
         """CSR cords for a batch on `threads` host threads; returns (cord_off, cords_str, cords_end, stats5).  The reference
-        (kind "ref") runs its own per-thread scratch as Mapper::p_calRecords does and has no counters (stats5 = zeros)."""
+        (kind "ref") runs its own per-thread scratch as Mapper::p_calRecords does and has no counters (stats5 = zeros).
+        gap_len > 0: the gap re-mapper behind apxMap (-g gap_len [-dup dup])."""
         reads = np.ascontiguousarray(reads, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         n = off.size - 1
-        cap = int(off[-1]) // 32 + 64 * n + 1024
+        cap = int(off[-1]) // (16 if gap_len else 32) + 64 * n + 1024
         coff = np.zeros(n + 1, np.uint64)
         cs = np.zeros(cap, np.uint64)
         ce = np.zeros(cap, np.uint64)
         st = np.zeros(5, np.uint64)
         if self.kind == "ref":
             assert int(off[0]) == 0
-            tot = self.lib.ref_map_batch(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap)
+            self.lib.ref_map_batch_g.restype = C.c_uint64
+            self.lib.ref_map_batch_g.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.c_int, _u64p, _u64p, _u64p, C.c_uint64, C.c_uint32, C.c_int]
+            tot = self.lib.ref_map_batch_g(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap, gap_len, dup)
             assert tot <= cap, "cord capacity"
             return coff, cs[:tot], ce[:tot], st
-        tot = self.lib.orc_map_batch(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap, _p(st, _u64p))
+        self.lib.orc_map_batch_g.restype = C.c_uint64
+        self.lib.orc_map_batch_g.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.c_int, _u64p, _u64p, _u64p, C.c_uint64, _u64p, C.c_uint32, C.c_int]
+        tot = self.lib.orc_map_batch_g(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap, _p(st, _u64p), gap_len, dup)
         assert tot <= cap, "cord capacity"
         return coff, cs[:tot], ce[:tot], st
 

@@ -271,8 +271,15 @@ void ref_get_cords(void *h, uint64_t *cords_str, uint64_t *cords_end) {
 // per-thread scratch exactly as mapper.cpp:423-433 declares it (anchors, crhit, f1, apx_gaps, comStr and a private parameter
 // copy, because toggle() mutates it: mapper.cpp:233-237,447).  Used as the CPU baseline of bench.py (`kind: "reference"`).
 // Returns the total number of cords; cord_off[n+1] always, cords only while they fit `cap`.
+uint64_t ref_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
+                         uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint32_t gap_len, int f_dup);
 uint64_t ref_map_batch(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
                        uint64_t *cords_str, uint64_t *cords_end, uint64_t cap) {
+    return ref_map_batch_g(h, reads, off, n, threads, cord_off, cords_str, cords_end, cap, 0, 0);
+}
+// the calculator loop with the gap re-mapper (-g gap_len [-dup f_dup]) behind apxMap, as Mapper::p_calRecords runs it (mapper.cpp:207-231)
+uint64_t ref_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
+                         uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint32_t gap_len, int f_dup) {
     RefCtx *c = (RefCtx *)h;
     std::vector<String<uint64_t> > CS(n), CE(n);
     if (threads < 1) threads = 1;
@@ -299,6 +306,16 @@ uint64_t ref_map_batch(void *h, const uint8_t *reads, const uint64_t *off, uint3
             createFeatures(begin(r), end(r), f1[0]);
             createFeatures(begin(com), end(com), f1[1]);
             apxMap(*c->idx, r, anchors, hit, f1, c->f2, gaps, CS[i], CE[i], ci, 1, pg, pm);
+            if (gap_len) {
+                GapParms gp(0.2);
+                gp.f_dup = f_dup;
+                gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
+                gp.read_id = "read";
+                String<uint64_t> clips;
+                mapGaps(c->g, r, com, CS[i], CE[i], clips, gaps, f1, c->f2, gp);
+                CordsParms cp;
+                reformCords(CS[i], CE[i], &reformCordsDxDy1, cp);
+            }
         }
     }
     uint64_t tot = 0;
