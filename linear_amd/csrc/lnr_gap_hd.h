@@ -177,27 +177,52 @@ LNR_HD inline void c_stream(const GSeq &seq, GVec<u64> &g_hs, u64 sq_str, u64 sq
 }
 
 // ---- anchors from the sorted k-mer list (gap_util.cpp:669-752, 1596-1661, 1818-1853)
-LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, int p2, int k, u64 rvcp, i64 lower, i64 upper, u64 gap_str, u64 gap_end, int direction, const GapParms &gp) {
+// keep(a): is the anchor of a k-mer pair inside the diagonal band of the gap (direction 0: [lower, upper); else the band that widens
+// with the distance from the end the extension starts at)
+struct GAncBand {
+    int direction; i64 lower, upper, y_ref, base, d_anchor; u64 strand;
+    LNR_HD bool keep(u64 a) const {
+        i64 t = (i64)ganc_stranchor(a);
+        if (direction == 0) return t < upper && t >= lower;
+        i64 dy = direction < 0 ? y_ref - (i64)ganc_y(a) : (i64)ganc_y(a) - y_ref;
+        if (dy < 0 || (ganc_strand(a) ^ strand)) return false;
+        i64 acc = (dy >> 7) * d_anchor; if (acc < 50) acc = 50;
+        i64 lo = base - acc; if (lo < 0) lo = 0;
+        return t < base + acc && t >= lo;
+    }
+};
+LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, int p2, int k, u64 rvcp, i64 lower, i64 upper, u64 gap_str, u64 gap_end, int direction, const GapParms &gp, int coop = 0) {
     if (out.ar->ovf) return;
-    if (direction == 0) {
-        for (int i = p1; i < p2; i++) for (int j = p2; j < k; j++) {
-            u64 a = ganc_make(g_hs[(u32)i], g_hs[(u32)j], rvcp);
-            i64 t = (i64)ganc_stranchor(a);
-            if (t < upper && t >= lower) out.push(a);
+    GAncBand B;
+    B.direction = direction; B.lower = lower; B.upper = upper; B.strand = cord_strand(gap_str);
+    B.y_ref = direction < 0 ? (i64)cord_y(gap_end) : (i64)cord_y(gap_str);
+    B.base = (i64)cord2stranchor(direction < 0 ? gap_end : gap_str);
+    B.d_anchor = (i64)((1LL << 7) * gp.thd_gmsa_d_anchor_rate);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (coop) {                                              // the pairs of one reference k-mer, 64 read k-mers at a time; kept anchors in pair order
+        const int lane = (int)(threadIdx.x & 63);
+        for (int i = p1; i < p2; i++) {
+            u64 hi = g_hs[(u32)i];
+            for (int jb = p2; jb < k; jb += 64) {
+                int j = jb + lane;
+                u64 a = j < k ? ganc_make(hi, g_hs.p[j], rvcp) : 0;
+                bool kp = j < k && B.keep(a);
+                u64 m = __ballot(kp);
+                u32 cnt = (u32)__popcll(m);
+                if (!cnt) continue;
+                out.reserve(out.n + cnt);
+                if (out.n + cnt > out.cap) return;
+                if (kp) out.p[out.n + (u32)__popcll(m & ((1ULL << lane) - 1))] = a;
+                out.n += cnt;
+            }
         }
         return;
     }
-    i64 y_ref = direction < 0 ? (i64)cord_y(gap_end) : (i64)cord_y(gap_str);
-    i64 base = (i64)cord2stranchor(direction < 0 ? gap_end : gap_str);
-    i64 d_anchor = (i64)((1LL << 7) * gp.thd_gmsa_d_anchor_rate);
+#endif
+    (void)coop;
     for (int i = p1; i < p2; i++) for (int j = p2; j < k; j++) {
         u64 a = ganc_make(g_hs[(u32)i], g_hs[(u32)j], rvcp);
-        i64 t = (i64)ganc_stranchor(a);
-        i64 dy = direction < 0 ? y_ref - (i64)ganc_y(a) : (i64)ganc_y(a) - y_ref;
-        if (dy < 0 || (ganc_strand(a) ^ cord_strand(gap_str))) continue;
-        i64 acc = (dy >> 7) * d_anchor; if (acc < 50) acc = 50;
-        i64 lo = base - acc; if (lo < 0) lo = 0;
-        if (t < base + acc && t >= lo) out.push(a);
+        if (B.keep(a)) out.push(a);
     }
 }
 template <class F> LNR_HD inline void g_hs_blocks(GVec<u64> &g_hs, int shape_len, GapCtx &X, F &&emit) {
@@ -214,12 +239,12 @@ template <class F> LNR_HD inline void g_hs_blocks(GVec<u64> &g_hs, int shape_len
     }
 }
 LNR_HD inline void g_create_anchors(GVec<u64> &g_hs, GVec<u64> &anchors, int shape_len, int direction, i64 lower, i64 upper, u64 rvcp, u64 gap_str, u64 gap_end, GapCtx &X) {
-    g_hs_blocks(g_hs, shape_len, X, [&](int p1, int p2, int k) { g_set_anchors(g_hs, anchors, p1, p2, k, rvcp, lower, upper, gap_str, gap_end, direction, X.gp); });
+    g_hs_blocks(g_hs, shape_len, X, [&](int p1, int p2, int k) { g_set_anchors(g_hs, anchors, p1, p2, k, rvcp, lower, upper, gap_str, gap_end, direction, X.gp, X.coop); });
 }
 LNR_HD inline void g_create_anchor_pair(GVec<u64> &g_hs, GVec<u64> &a1, GVec<u64> &a2, int shape_len, u64 rvcp, u64 gs1, u64 ge1, u64 gs2, u64 ge2, GapCtx &X) {
     g_hs_blocks(g_hs, shape_len, X, [&](int p1, int p2, int k) {
-        g_set_anchors(g_hs, a1, p1, p2, k, rvcp, 0, 0, gs1, ge1, 1, X.gp);
-        g_set_anchors(g_hs, a2, p1, p2, k, rvcp, 0, 0, gs2, ge2, -1, X.gp);
+        g_set_anchors(g_hs, a1, p1, p2, k, rvcp, 0, 0, gs1, ge1, 1, X.gp, X.coop);
+        g_set_anchors(g_hs, a2, p1, p2, k, rvcp, 0, 0, gs2, ge2, -1, X.gp, X.coop);
     });
 }
 LNR_HD inline void c_create_anchors2(GVec<u64> &g_hs, GVec<u64> &out, i64 lower, i64 upper, SortStack &st) {
@@ -356,23 +381,50 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
         // every lane runs the read's code with the same data; here the predecessors of anchor i are dealt over the lanes, 64 at a
         // time.  The scan ends at the first j below j_str whose x is dx_depth away: the anchors are x-descending, so that is a
         // threshold in j.  Among equal sums the serial scan (j descending, >=) keeps the smallest j: the key's low word.
+        // The last 64 records stay in registers (lane l: record i - 1 - l; anchor, score, length, root), shifted by one lane per
+        // anchor: a load of what the previous iteration stored would wait for that store to reach L2 (microseconds per anchor).
+        // Memory is read only for the predecessors beyond the window and for the anchors themselves, 64 per load.
         const int lane = (int)(threadIdx.x & 63);
+        u64 wa = 0, blk = 0;
+        i32 ws = 0, wl = 0, wr = 0;
         for (int i = 0; i < (int)n; i++) {
+            if ((i & 63) == 0) blk = (u32)(i + lane) < n ? anchors[i + lane] : 0;
             int j_str = i - (int)depth < 0 ? 0 : i - (int)depth;
-            u64 ai = anchors[i], xi = ganc_x(ai), key = 0;
-            for (int jb = i - 1; jb >= 0; jb -= 64) {
-                int j = jb - lane;
-                bool ok = j >= 0 && (j >= j_str || ganc_x(anchors[j]) - xi < dx_depth);
+            u64 ai = __shfl(blk, i & 63), xi = ganc_x(ai), key = 0;
+            {
+                int j = i - 1 - lane;
+                bool ok = j >= 0 && (j >= j_str || ganc_x(wa) - xi < dx_depth);
                 if (ok) {
-                    int sc = score(anchors[j], ai);
-                    if (sc > 0) { u64 k = ((u64)(u32)(sc + r.score[j]) << 32) | (u64)(0xffffffffu - (u32)j); key = k > key ? k : key; }
+                    int sc = score(wa, ai);
+                    if (sc > 0) key = ((u64)(u32)(sc + ws) << 32) | (u64)(0xffffffffu - (u32)j);
                 }
-                if (__any(!ok)) break;
+                if (!__any(!ok))
+                    for (int jb = i - 65; jb >= 0; jb -= 64) {
+                        int j2 = jb - lane;
+                        bool ok2 = j2 >= 0 && (j2 >= j_str || ganc_x(anchors[j2]) - xi < dx_depth);
+                        if (ok2) {
+                            int sc = score(anchors[j2], ai);
+                            if (sc > 0) { u64 k = ((u64)(u32)(sc + r.score[j2]) << 32) | (u64)(0xffffffffu - (u32)j2); key = k > key ? k : key; }
+                        }
+                        if (__any(!ok2)) break;
+                    }
             }
             for (int m = 32; m; m >>= 1) { u64 o = __shfl_xor(key, m); key = o > key ? o : key; }
             int best = key ? (int)(key >> 32) : -1, max_j = key ? (int)(0xffffffffu - (u32)key) : i;
-            if (best > 0) { r.p2[i] = max_j; r.score[i] = best; r.len[i] = r.len[max_j] + 1; r.score2[i] = best; r.root[i] = r.root[max_j]; r.leaf[i] = 1; r.leaf[max_j] = 0; }
-            else { r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = i; r.leaf[i] = 1; }
+            i32 s_i, len_i, root_i;
+            if (best > 0) {
+                int d = i - 1 - max_j;
+                i32 lm, rm;
+                if (d < 64) { lm = __shfl(wl, d); rm = __shfl(wr, d); } else { lm = r.len[max_j]; rm = r.root[max_j]; }
+                s_i = best; len_i = lm + 1; root_i = rm;
+                r.p2[i] = max_j; r.score[i] = best; r.len[i] = len_i; r.score2[i] = best; r.root[i] = root_i; r.leaf[i] = 1; r.leaf[max_j] = 0;
+            } else {
+                s_i = 0; len_i = 1; root_i = i;
+                r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = i; r.leaf[i] = 1;
+            }
+            u64 na = __shfl_up(wa, 1);
+            i32 ns = __shfl_up(ws, 1), nl = __shfl_up(wl, 1), nr = __shfl_up(wr, 1);
+            wa = lane ? na : ai; ws = lane ? ns : s_i; wl = lane ? nl : len_i; wr = lane ? nr : root_i;
         }
     } else
 #endif

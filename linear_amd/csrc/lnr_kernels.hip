@@ -2924,7 +2924,7 @@ struct GapArgs {
     int last;   // what this launch cannot do either is an error of the read
 };
 #ifndef K_GAP_WAVES
-#define K_GAP_WAVES 1
+#define K_GAP_WAVES 4
 #endif
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(K_GAP_WAVES, K_GAP_WAVES))) k_gap(GapArgs A) {
     u32 worker = A.coop ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
