@@ -1,9 +1,10 @@
 // lnr_gap_hd.h -- the gap re-mapper (mapGaps / reformCords, gap.cpp / gap_util.cpp / cords.cpp:504-687) as host + device
-// functions of the product, in the idiom of lnr_hd.h: plain arrays from a per-read arena, the tie-sensitive sorts through
-// ref_sort.h, the chain traceback and the block chaining through the forms lnr_hd.h already has.  One read is one serial walk over
-// its gaps (the tiles of a gap are inserted into the cord list before the next gap is looked at).  WORK IN PROGRESS (round 2): the
-// layers below are checked on the host against the oracle (tests/test_gap_shim_cpu.py through tests/host_shim.cpp); the kernel that
-// runs them (one wave per read) and the ABI switch (-g) are the next step.  Every function cites the reference lines it follows.
+// functions of the product, in the idiom of lnr_hd.h: arrays from a per-read arena (mark / release per gap), the tie-sensitive sorts
+// through ref_sort.h, the chain traceback and the block chaining through the forms lnr_hd.h already has.  One read is one serial walk
+// over its gaps (the tiles of a gap are inserted into the cord list before the next gap is looked at).  k_gap (lnr_kernels.hip) runs
+// it with one wave per read: every lane executes this code on the same data, and the loops marked `coop` deal their iterations over
+// the 64 lanes (chain DP, k-mer join).  The same source compiled by g++ (tests/host_shim.cpp) is what the CPU tests check function
+// by function against the oracle (tests/test_gap_shim_cpu.py).  Every function cites the reference lines it follows.  DESIGN.md 5c.
 #pragma once
 #include "lnr_hd.h"
 
@@ -129,6 +130,19 @@ struct GpScope { GapCtx &X; int i; unsigned long long t0; __device__ GpScope(Gap
 #define GP(X, k) do {} while (0)
 #endif
 
+// std::sort of the gap path.  Host and lane-per-read form: ref_sort (libstdc++'s introsort, serial).  Wave-per-read form: the same
+// algorithm with the partitions of the large ranges done by all 64 lanes and the small ranges finished one per lane
+// (gap_sort_wave, lnr_kernels.hip: the list formulation of ref_sort.h) -- same permutation, ties included.
+#if defined(__HIPCC__)
+template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp comp, GapCtx &X);
+#endif
+template <class T, class Comp> LNR_HD inline void gap_sort(T *a, long n, Comp comp, GapCtx &X) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (X.coop && n > 96) { gap_sort_wave(a, (u32)n, comp, X); return; }
+#endif
+    ref_sort(a, n, comp, X.ls->st);
+}
+
 // ---- k-mer streams (shape_extend.cpp:86-116 hashInit, :231-243 hashNextV, :122-131 / :213-219 the single-strand pair)
 struct GShape { u64 h, crh; int x, left; u32 span; };
 LNR_HD inline u64 gshape_init(GShape &me, const u8 *it) {
@@ -227,7 +241,7 @@ LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, 
 }
 template <class F> LNR_HD inline void g_hs_blocks(GVec<u64> &g_hs, int shape_len, GapCtx &X, F &&emit) {
     u64 mask = (1ULL << (2 * shape_len + 33)) - 1;
-    { GP(X, 0); ref_sort(g_hs.p, (long)g_hs.n, [mask](const u64 &a, const u64 &b) { return (a & mask) < (b & mask); }, X.ls->st); }
+    { GP(X, 0); gap_sort(g_hs.p, (long)g_hs.n, [mask](const u64 &a, const u64 &b) { return (a & mask) < (b & mask); }, X); }
     GP(X, 1);
     int p1 = 0, p2 = 0;
     for (int k = 1; k < (int)g_hs.n; k++) {
@@ -247,9 +261,10 @@ LNR_HD inline void g_create_anchor_pair(GVec<u64> &g_hs, GVec<u64> &a1, GVec<u64
         g_set_anchors(g_hs, a2, p1, p2, k, rvcp, 0, 0, gs2, ge2, -1, X.gp, X.coop);
     });
 }
-LNR_HD inline void c_create_anchors2(GVec<u64> &g_hs, GVec<u64> &out, i64 lower, i64 upper, SortStack &st) {
+LNR_HD inline void c_create_anchors2(GVec<u64> &g_hs, GVec<u64> &out, i64 lower, i64 upper, SortStack &st, GapCtx *Xp = nullptr) {
     int p1 = 0, p2 = 0;
-    ref_sort(g_hs.p, (long)g_hs.n, [](const u64 &a, const u64 &b) { return a < b; }, st);
+    if (Xp) gap_sort(g_hs.p, (long)g_hs.n, [](const u64 &a, const u64 &b) { return a < b; }, *Xp);
+    else ref_sort(g_hs.p, (long)g_hs.n, [](const u64 &a, const u64 &b) { return a < b; }, st);
     for (int k = 1; k < (int)g_hs.n; k++) {
         u64 t = g_hs_xt(g_hs[(u32)k] ^ g_hs[(u32)k - 1]);
         if (t == 0) continue;
@@ -547,7 +562,7 @@ LNR_HD inline void gap_chain_tiles(GVec<u64> &tiles, u64 L, u64 gap_size, GapCtx
 }
 LNR_HD inline void g_chains_from_anchors(GVec<u64> &anchors, GVec<u64> &tiles, u64 L, GapCtx &X) {   // g_CreateChainsFromAnchors_ gap_util.cpp:1191-1222
     if (X.ar->ovf) return;
-    { GP(X, 3); ref_sort(anchors.p, (long)anchors.n, [](const u64 &a, const u64 &b) { return ganc_x(a) > ganc_x(b); }, X.ls->st); }
+    { GP(X, 3); gap_sort(anchors.p, (long)anchors.n, [](const u64 &a, const u64 &b) { return ganc_x(a) > ganc_x(b); }, X); }
     int fn = X.gp.chn1_fn;
     gap_chain_anchors(anchors.p, anchors.n, tiles, true, 20, 80, 20, X.gp.chn1_min_len, X.gp.chn1_abort, [fn](u64 a, u64 b) { return fn == 2 ? gap_anchor_score2(a, b) : gap_anchor_score1(a, b); }, X);
     gap_chain_tiles(tiles, L, 100, X);
@@ -874,8 +889,8 @@ LNR_HD inline int gap_map_along_chain(const GSeq &ref, const GSeq &seq2, const G
     i64 as = (i64)(cord_x(a) - cord_y(a)), ae = (i64)(cord_x(b) - cord_y(b));
     c_stream(ref, hs, cord_x(a), cord_x(b), step1, shape_len, 0);
     c_stream(seq2, hs, cord_y(a), cord_y(b), step2, shape_len, 1);
-    c_create_anchors2(hs, anc, (as < ae ? as : ae) - 30, (as > ae ? as : ae) + 30, X.ls->st);
-    ref_sort(anc.p, (long)anc.n, [](const u64 &p, const u64 &q) { return ganc_x(p) > ganc_x(q); }, X.ls->st);
+    c_create_anchors2(hs, anc, (as < ae ? as : ae) - 30, (as > ae ? as : ae) + 30, X.ls->st, &X);
+    gap_sort(anc.p, (long)anc.n, [](const u64 &p, const u64 &q) { return ganc_x(p) > ganc_x(q); }, X);
     stick_main_chain(anc, ch, X.gp.thd_smcn_danchor);
     GVec<u64> first; first.init(X.ar, anc.n + 16);
     // bestn 1: only the first chain is wanted; it is collected as anchors and turned into tiles below (chn_ext_clip_metric1: min length 1, abort 0)
@@ -1093,7 +1108,7 @@ LNR_HD inline void gap_filter_anchors(GVec<u64> &a, GapCtx &X) {                
     GVec<UP> list; list.init(X.ar);
     if (a.n > 1) {
         a[0] = 0;
-        ref_sort(a.p, (long)a.n, [](const u64 &p, const u64 &q) { return ganc_stranchor(p) < ganc_stranchor(q); }, X.ls->st);
+        gap_sort(a.p, (long)a.n, [](const u64 &p, const u64 &q) { return ganc_stranchor(p) < ganc_stranchor(q); }, X);
         u64 ak2 = a[1], block_str = 1, count = 0, min_y = ~0ULL, max_y = 0;
         for (u32 i = 1; i < a.n; i++) {
             u64 y = ganc_y(a[i]);

@@ -15,7 +15,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "lnr_hd.h"
-#include "lnr_gap_hd.h"
 
 namespace lnr {
 
@@ -2901,6 +2900,98 @@ __global__ void __launch_bounds__(64) k_gather_out(const u64 *out_str, const u64
     const u64 *s = out_str + cords_off[r], *e = out_end + cords_off[r];
     u64 o = cord_off[r];
     for (u32 i = threadIdx.x; i < c; i += blockDim.x) { cs[o + i] = s[i]; ce[o + i] = e[i]; }
+}
+
+}  // namespace lnr
+#include "lnr_gap_hd.h"
+namespace lnr {
+// ---- gap_sort_wave: introsort_xdesc_wave for any element type and comparator, the scratch taken from the read's arena.  The array,
+// the swap-candidate lists and the task list live in global memory; the explicit stack is wave-uniform private state (this kernel has
+// one wave per workgroup and registers to spare).  Falls back to the serial ref_sort when the arena cannot hold the lists.
+template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp comp, GapCtx &X) {
+    const int lane = lane_id();
+    u64 m0 = X.ar->mark();
+    u32 *Lbuf = (u32 *)X.ar->get((u64)n * 4), *Rbuf = (u32 *)X.ar->get((u64)n * 4);
+    u64 *tasks = (u64 *)X.ar->get(((u64)n + 64) * 8);
+    if (X.ar->ovf) {                                         // (the overflow stands: the read is redone with a larger arena)
+        ref_sort(a, (long)n, comp, X.ls->st);
+        return;
+    }
+    int stk_first[64], stk_last[64], stk_depth[64];
+    int sp = 0, lg = 0;
+    for (u32 t = n; t > 1; t >>= 1) lg++;
+    stk_first[0] = 0; stk_last[0] = (int)n; stk_depth[0] = lg * 2;
+    sp = 1;
+    u32 ntasks = 0;
+    WSYNC();
+    while (sp > 0) {
+        --sp;
+        u32 first = (u32)stk_first[sp], last = (u32)stk_last[sp];
+        int depth = stk_depth[sp];
+        while (true) {
+            if (last - first <= SORT_SMALL) {
+                if (lane == 0) tasks[ntasks] = (u64)first | ((u64)last << 28) | ((u64)depth << 56);
+                ntasks++;
+                break;
+            }
+            if (depth == 0) {
+                if (lane == 0) tasks[ntasks] = (u64)first | ((u64)last << 28) | (1ULL << 63);
+                ntasks++;
+                break;
+            }
+            --depth;
+            u32 iA = first + 1, iB = first + (last - first) / 2, iC = last - 1;
+            T va = a[iA], vb = a[iB], vc = a[iC], vf = a[first];            // (uniform loads)
+            u32 pick;
+            if (comp(va, vb)) pick = comp(vb, vc) ? iB : (comp(va, vc) ? iC : iA);
+            else pick = comp(va, vc) ? iA : (comp(vb, vc) ? iC : iB);
+            T vp = pick == iA ? va : (pick == iB ? vb : vc);
+            WSYNC();                                                          // every lane has read the four before one of them is overwritten
+            if (lane == 0) { a[first] = vp; a[pick] = vf; }
+            u32 lo = first + 1, nL = 0, nR = 0;
+            for (u32 base = lo; base < last; base += 128) {
+                T v2[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) { u32 i = base + 64 * u + lane; v2[u] = i < last ? a[i] : vp; }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (base + 64 * u >= last) break;       // uniform
+                    u32 i = base + 64 * u + lane;
+                    bool in = i < last;
+                    T x = i == pick ? vf : v2[u];
+                    bool fL = in && !comp(x, vp);           // the left scan stops here
+                    bool fR = in && !comp(vp, x);           // the right scan stops here
+                    u64 mL = __ballot(fL), mR = __ballot(fR);
+                    if (fL) Lbuf[nL + __popcll(mL & lanemask_lt())] = i;
+                    if (fR) Rbuf[nR + __popcll(mR & lanemask_lt())] = i;
+                    nL += (u32)__popcll(mL); nR += (u32)__popcll(mR);
+                }
+            }
+            WSYNC();
+            u32 lim = nL < nR ? nL : nR, cnt = 0;
+            for (u32 k = lane; k < lim; k += 64) cnt += Lbuf[k] < Rbuf[nR - 1 - k] ? 1u : 0u;
+            u32 K = wave_sum(cnt);
+            for (u32 k = lane; k < K; k += 64) { u32 i = Lbuf[k], j = Rbuf[nR - 1 - k]; T t = a[i]; a[i] = a[j]; a[j] = t; }
+            u32 cut = last;
+            if (K < nL) cut = Lbuf[K];
+            if (K >= 1) { u32 r = Rbuf[nR - K]; cut = r < cut ? r : cut; }
+            WSYNC();
+            stk_first[sp] = (int)cut; stk_last[sp] = (int)last; stk_depth[sp] = depth;
+            ++sp;
+            last = cut;
+        }
+    }
+    WSYNC();
+    for (u32 b = 0; b < ntasks; b += 64) {                   // the deferred ranges, one per lane
+        u32 t = b + (u32)lane;
+        if (t < ntasks) {
+            u64 v = tasks[t];
+            if (v >> 63) rs_heap_sort(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), comp);
+            else rs_finish_range<16>(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)((v >> 56) & 0x7f), comp);
+        }
+    }
+    WSYNC();
+    X.ar->release(m0);
 }
 
 // ------------------------------------------------------------------ gap re-mapper [f1] ----

@@ -2,7 +2,7 @@
 # the seed kernel (separate runs, counters only).  Outputs under gpurun_out/r02/; copy what is to be judged into profiles/r02/.
 OUT=gpurun_out/r02
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p $OUT
-timeout -k 10 300 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1 || { tail -20 $OUT/gpu_tests.log; exit 1; }
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1 || { tail -20 $OUT/gpu_tests.log; exit 1; }
 tail -1 $OUT/gpu_tests.log
 timeout -k 10 500 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.log || { tail -5 $OUT/bench_default.log; exit 1; }
 grep "\[bench\]" $OUT/bench_default.log
