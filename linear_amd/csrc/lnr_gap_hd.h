@@ -300,6 +300,35 @@ LNR_HD inline int gap_anchor_score2(u64 a1, u64 a2) {
     int s_derr = derr < 5 ? (int)(4 * derr) : (derr < 10 ? (int)(6 * derr - 10) : (int)(derr * derr - 5 * derr));
     return 100 - (int)(dy * (dy + 300) / 300) - s_derr;
 }
+// The chain DP only asks whether a score is positive and, if so, for its value.  These forms return the score of the functions above
+// whenever that is positive and some non-positive number otherwise, in 32-bit arithmetic behind two range tests (the 64-bit divide
+// of the literal form is ~150 instructions on the GPU).  Score 1 is positive only for dy < 245 (s_dy < 100) and derr <= 24, i.e.
+// 100 da < 25 max(dy, 50): da <= 60 (dy < 245 + 32 768 then: no wrap in s_dy either).  Score 2 only for dy <= 79 and derr <= 12; with da = |dx - dy| that bounds dx by 147 and da by 19.
+// tests/test_gap_shim_cpu.py compares them with the literal forms over the whole positive region and its surroundings.
+LNR_HD inline int gap_anchor_score1_pos(u64 a1, u64 a2) {
+    i32 dy = (i32)ganc_y(a1) - (i32)ganc_y(a2);
+    i64 dx = (i64)ganc_x(a1) - (i64)ganc_x(a2);
+    if (dy < 0 || ganc_strand(a1 ^ a2) || (gabs(dx) < 8 && dx != dy)) return -1;
+    u64 da64 = (u64)gabs((i64)(ganc_stranchor(a2) - ganc_stranchor(a1)));
+    if (da64 >= 65536) return gap_anchor_score1(a1, a2);   // (the literal form's int conversion of derr^2 / 10 wraps from da ~ 73 000 on: reproduced, not reasoned about)
+    if (da64 >= 64 || dy >= 245) return -1;
+    u32 da = (u32)da64, m = (u32)(dy > 50 ? dy : 50), derr = (100u * da) / m;
+    i32 s_derr = derr < 10 ? 0 : (derr < 15 ? (i32)(10 + 2 * derr) : (i32)(derr * derr / 10 + 40));
+    i32 s_dy = dy < 100 ? dy / 4 : (dy < 200 ? dy / 3 - 9 : dy - 145);
+    return 100 - s_dy - s_derr;
+}
+LNR_HD inline int gap_anchor_score2_pos(u64 a1, u64 a2) {
+    i32 dy = (i32)ganc_y(a1) - (i32)ganc_y(a2);
+    i64 dx = (i64)ganc_x(a1) - (i64)ganc_x(a2);
+    if (dy < 0 || dy >= 128 || ganc_strand(a1 ^ a2) || ((gabs(dx) < 8 || dy < 8) && dx != dy)) return -1;
+    u64 da64 = (u64)gabs((i64)(ganc_stranchor(a2) - ganc_stranchor(a1)));
+    if (da64 >= 64 || gabs(dx) >= 4096) return -1;
+    u32 da = (u32)da64;
+    i32 m = (i32)dx > dy ? (i32)dx : dy; if (m < 50) m = 50;
+    u32 derr = (100u * da) / (u32)m;
+    i32 s_derr = derr < 5 ? (i32)(4 * derr) : (derr < 10 ? (i32)(6 * derr - 10) : (i32)(derr * derr - 5 * derr));
+    return 100 - dy * (dy + 300) / 300 - s_derr;
+}
 LNR_HD inline int gap_clip_score(u64 a1, u64 a2) {                                        // getExtendClipScore
     i64 dy = (i64)ganc_y(a1) - (i64)ganc_y(a2), dx = (i64)ganc_x(a1) - (i64)ganc_x(a2);
     if (dy <= 0 || ganc_strand(a1 ^ a2) || ((gabs(dx) < 3 || gabs(dy) < 3) && dx != dy)) return -10000;
@@ -414,14 +443,26 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
                     if (sc > 0) key = ((u64)(u32)(sc + ws) << 32) | (u64)(0xffffffffu - (u32)j);
                 }
                 if (!__any(!ok))
-                    for (int jb = i - 65; jb >= 0; jb -= 64) {
-                        int j2 = jb - lane;
-                        bool ok2 = j2 >= 0 && (j2 >= j_str || ganc_x(anchors[j2]) - xi < dx_depth);
-                        if (ok2) {
-                            int sc = score(anchors[j2], ai);
-                            if (sc > 0) { u64 k = ((u64)(u32)(sc + r.score[j2]) << 32) | (u64)(0xffffffffu - (u32)j2); key = k > key ? k : key; }
+                    for (int jb = i - 65; jb >= 0; jb -= 256) {        // 256 predecessors per step: four loads in flight per lane, one exit test
+                        u64 av[4]; i32 sv[4]; bool okv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            int j2 = jb - 64 * u - lane;
+                            av[u] = j2 >= 0 ? anchors[j2] : 0;
+                            sv[u] = j2 >= 0 ? r.score[j2] : 0;
                         }
-                        if (__any(!ok2)) break;
+                        bool stop = false;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            int j2 = jb - 64 * u - lane;
+                            okv[u] = j2 >= 0 && (j2 >= j_str || ganc_x(av[u]) - xi < dx_depth);
+                            if (okv[u]) {
+                                int sc = score(av[u], ai);
+                                if (sc > 0) { u64 k = ((u64)(u32)(sc + sv[u]) << 32) | (u64)(0xffffffffu - (u32)j2); key = k > key ? k : key; }
+                            }
+                            stop = stop || !okv[u];
+                        }
+                        if (__any(stop)) break;                          // (x-descending: once a predecessor is out of range all earlier ones are)
                     }
             }
             for (int m = 32; m; m >>= 1) { u64 o = __shfl_xor(key, m); key = o > key ? o : key; }
@@ -564,7 +605,7 @@ LNR_HD inline void g_chains_from_anchors(GVec<u64> &anchors, GVec<u64> &tiles, u
     if (X.ar->ovf) return;
     { GP(X, 3); gap_sort(anchors.p, (long)anchors.n, [](const u64 &a, const u64 &b) { return ganc_x(a) > ganc_x(b); }, X); }
     int fn = X.gp.chn1_fn;
-    gap_chain_anchors(anchors.p, anchors.n, tiles, true, 20, 80, 20, X.gp.chn1_min_len, X.gp.chn1_abort, [fn](u64 a, u64 b) { return fn == 2 ? gap_anchor_score2(a, b) : gap_anchor_score1(a, b); }, X);
+    gap_chain_anchors(anchors.p, anchors.n, tiles, true, 20, 80, 20, X.gp.chn1_min_len, X.gp.chn1_abort, [fn](u64 a, u64 b) { return fn == 2 ? gap_anchor_score2_pos(a, b) : gap_anchor_score1_pos(a, b); }, X);
     gap_chain_tiles(tiles, L, 100, X);
 }
 struct IPair { int first, second; };

@@ -377,6 +377,8 @@ int hs_gap_score(int which, u64 a, u64 b, u64 c, u64 d, u64 read_len, int strand
         case 2: return gap_anchor_score2(a, b);
         case 3: return gap_block_score2(a, b, c, d, read_len, strand);
         case 5: return gap_clip_score(a, b);
+        case 6: return gap_anchor_score1_pos(a, b);
+        case 7: return gap_anchor_score2_pos(a, b);
         default: return gap_block_score3(a, b, c, d, read_len, strand);
     }
 }

@@ -260,3 +260,31 @@ def test_product_gap_path_survives_small_arenas_and_work_budget():
     a = o.map_read_gap(nrun, 50, 0)
     assert fn(sh.h, p(nrun, u8p), nrun.size, 50, 0, 64 << 20, 1 << 20, 3_000_000) in (-12, len(a[0]))
     o.close()
+
+
+def test_product_positive_only_chain_scores_agree_with_the_literal_ones():
+    """gap_anchor_score{1,2}_pos (what the chain DP evaluates) = the literal scores wherever those are positive, non-positive elsewhere"""
+    o, s = libs()
+    rng = np.random.default_rng(77)
+
+    def anchor(x, y, st):
+        return (st << 50) | (((x - y + (1 << 20)) & ((1 << 30) - 1)) << 20) | y
+
+    npos = 0
+    for it in range(120000):
+        y2 = int(rng.integers(0, 900000)); x2 = y2 + int(rng.integers(3000, 200000))
+        if it % 3 == 0:     # around the positive region: small dy, small distance from the diagonal
+            dy = int(rng.integers(-3, 260)); dx = dy + int(rng.integers(-70, 71))
+        elif it % 3 == 1:
+            dy = int(rng.integers(-50, 3000)); dx = int(rng.integers(-50, 3000))
+        else:
+            dy = int(rng.integers(0, 120)); dx = int(rng.integers(-10, 200))
+        y1 = min(max(y2 + dy, 0), (1 << 20) - 1)
+        if it % 29 == 0:    # far from the diagonal: the literal form's int conversion wraps, and so must the other
+            dx = int(rng.integers(70000, 400000))
+        a1, a2 = anchor(x2 + dx, y1, int(rng.integers(0, 2)) if it % 17 == 0 else 0), anchor(x2, y2, 0)
+        for lit, pos in ((1, 6), (2, 7)):
+            want, got = o.orc_gap_score(lit, a1, a2, 0, 0, 0, 0), s.hs_gap_score(pos, a1, a2, 0, 0, 0, 0)
+            assert (got == want) if want > 0 else (got <= 0), (lit, dx, dy, want, got)
+            npos += want > 0
+    assert npos > 10000
