@@ -196,7 +196,7 @@ struct lnr_ctx {
     u64 last_ncords = 0;
     lnr_stats stats{};
     Timer t_prep, t_job, t_tail, t_total, t_gap;
-    int gap_mode = 1; u32 gap_waves = 16384, gap_arena2_mb = 64;   // LNR_GAP_MODE=1: the first launch of k_gap runs one wave per read as well (LNR_GAP_WAVES of them)
+    int gap_mode = 1, gap_team = 1; u32 gap_waves = 16384, gap_arena2_mb = 64;   // LNR_GAP_TEAM=0: one wave per flagged read, no helper waves   // LNR_GAP_MODE=1: the first launch of k_gap runs one wave per read as well (LNR_GAP_WAVES of them)
     u64 gap_work_cap = 3000000;   // pair evaluations of the chain DPs one lane spends on a read before the read goes to the wave-per-read launch (LNR_GAP_WORK_CAP)
 };
 
@@ -1120,9 +1120,13 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         hipLaunchKernelGGL(k_gap, dim3(ctx->gap_mode ? w1 : w1 / 64), dim3(64), 0, ctx->stream, G); KCHECK();
         G.work_cap = ~0ULL;
         G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1; G.coop = 1;
-        hipLaunchKernelGGL(k_gap, dim3(w2), dim3(64), 0, ctx->stream, G); KCHECK();
+        if (ctx->gap_team) hipLaunchKernelGGL(k_gap_team, dim3(w2), dim3(64 * K_GAP_TEAM), 0, ctx->stream, G);
+        else hipLaunchKernelGGL(k_gap, dim3(w2), dim3(64), 0, ctx->stream, G);
+        KCHECK();
         G.arena_bytes = arena3; G.next = ctx->gap_next.as<u32>() + 24; G.last = 1;
-        hipLaunchKernelGGL(k_gap, dim3(w3), dim3(64), 0, ctx->stream, G); KCHECK();
+        if (ctx->gap_team) hipLaunchKernelGGL(k_gap_team, dim3(w3), dim3(64 * K_GAP_TEAM), 0, ctx->stream, G);
+        else hipLaunchKernelGGL(k_gap, dim3(w3), dim3(64), 0, ctx->stream, G);
+        KCHECK();
         ctx->t_gap.stop(ctx->stream);
 #ifdef LNR_GAP_DEVPROF
         {
@@ -1364,6 +1368,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (const char *e = getenv("LNR_GAP_MODE")) ctx->gap_mode = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LNR_GAP_WAVES")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) ctx->gap_waves = (u32)v; }
     if (const char *e = getenv("LNR_GAP_ARENA2_MB")) { long v = atol(e); if (v >= 1 && v <= 1024) ctx->gap_arena2_mb = (u32)v; }
+    if (const char *e = getenv("LNR_GAP_TEAM")) ctx->gap_team = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LNR_GAP_WORK_CAP")) { long long v = atoll(e); if (v >= 0) ctx->gap_work_cap = (u64)v; }
     if (const char *e = getenv("LNR_SEED_LDS_PAD")) { long v = atol(e); if (v >= 0 && v <= 100000) ctx->seed_lds_pad = (u32)v; }
     if (const char *e = getenv("LNR_JOB_LDS_KB")) { long kb = atol(e); if (kb >= 1 && kb <= 156) ctx->job_lds_bytes = (size_t)kb * 1024; }

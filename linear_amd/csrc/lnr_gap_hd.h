@@ -108,6 +108,7 @@ struct GapParms {
     int chn1_min_len = 1, chn1_abort = 50, chn1_fn = 1;   // anchors: getGapAnchorsChainScore (1) / ...Score2 (2)
     int chn2_min_len = 1, chn2_abort = 0, chn2_fn = 2;    // blocks: getGapBlocksChainScore2 (2) / ...Score3 (3)
 };
+struct GapTeam;
 struct GSeq { const u8 *p; u64 len; };                    // bases with >= 64 zero bytes behind the end
 struct GapCtx {                                           // one read
     GArena *ar; LeaderScratch *ls;
@@ -117,6 +118,7 @@ struct GapCtx {                                           // one read
     GapParms gp;
     u64 work = 0, work_cap = ~0ULL;                       // pair evaluations of the chain DPs so far / the budget (over it: ar->ovf = 2)
     int coop = 0;                                         // device: all 64 lanes of the wave run this read together (k_gap, second launch)
+    int team = 0; struct GapTeam *tm = nullptr;           // device: helper waves of the workgroup for the long rows of the chain DP (k_gap_team)
 #ifdef LNR_GAP_DEVPROF
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ticks per phase (diagnostic build, tools/measure/gap_prof.sh)
 #endif
@@ -392,6 +394,61 @@ LNR_HD inline void drop_chain_gap_x(GVec<u64> &ch, int direction, const GapParms
 // =================================================================== chains and tiles ====
 // chainAnchorsBase (cluster_util.cpp:445-462) = getBestChains (:53-111) + the traceback of lnr_hd.h; every chain becomes tiles, the
 // last tile of a chain carries the end sign (g_CreateChainsFromAnchors_ gap_util.cpp:1207-1216)
+
+// ---- the long rows of the chain DP by several waves (k_gap_team): the main wave (wave 0) runs the read; when a row goes far beyond
+// the register window it posts the row in LDS, every wave of the workgroup scans its share of the predecessors (blocks of 256,
+// dealt round-robin) and posts its best key, the main wave takes the maximum.  Helper waves do nothing else: they wait at the
+// workgroup barrier for the next row or for the exit command.
+LNR_HD inline int gap_dp_score(int fn, u64 a, u64 b) { return fn == 2 ? gap_anchor_score2_pos(a, b) : (fn == 5 ? gap_clip_score(a, b) : gap_anchor_score1_pos(a, b)); }
+#ifndef K_GAP_TEAM_ROW
+#define K_GAP_TEAM_ROW 2048   // predecessors of the previous row from which a row is dealt over the team (two barriers per row)
+#endif
+struct GapTeam { const u64 *anchors; const i32 *score; u64 ai, dx_depth; int i, j_str, fn, cmd; u64 part[16]; };
+#if defined(__HIPCC__)
+// the predecessors [0, i - 65] of row i in blocks of 256 from the top, block b for wave b mod nw; returns this wave's best key
+struct GapDpFn { int fn; __device__ int operator()(u64 a, u64 b) const { return gap_dp_score(fn, a, b); } };
+template <class Score>
+__device__ inline u64 gap_dp_row_share(const u64 *anchors, const i32 *rscore, u64 ai, int i, int j_str, u64 dx_depth, Score score, int wave, int nw, u32 *nblk = nullptr) {
+    const int lane = (int)(threadIdx.x & 63);
+    u64 xi = ganc_x(ai), key = 0;
+    u32 blocks = 0;
+    for (int jb = i - 65 - 256 * wave; jb >= 0; jb -= 256 * nw) {
+        blocks++;
+        u64 av[4]; i32 sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int j2 = jb - 64 * u - lane;
+            av[u] = j2 >= 0 ? anchors[j2] : 0;
+            sv[u] = j2 >= 0 ? rscore[j2] : 0;
+        }
+        bool stop = false;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int j2 = jb - 64 * u - lane;
+            bool ok = j2 >= 0 && (j2 >= j_str || ganc_x(av[u]) - xi < dx_depth);
+            if (ok) {
+                int sc = score(av[u], ai);
+                if (sc > 0) { u64 k = ((u64)(u32)(sc + sv[u]) << 32) | (u64)(0xffffffffu - (u32)j2); key = k > key ? k : key; }
+            }
+            stop = stop || !ok;
+        }
+        if (__any(stop)) break;                                  // (x-descending: once a predecessor is out of range all earlier ones are)
+    }
+    for (int m = 32; m; m >>= 1) { u64 o = __shfl_xor(key, m); key = o > key ? o : key; }
+    if (nblk) *nblk = blocks;
+    return key;
+}
+__device__ inline void gap_team_helper_loop(GapTeam *tm, int wave, int nw) {
+    for (;;) {
+        __syncthreads();                                         // (A) a command is posted
+        if (tm->cmd == 0) break;
+        u64 key = gap_dp_row_share(tm->anchors, tm->score, tm->ai, tm->i, tm->j_str, tm->dx_depth, GapDpFn{tm->fn}, wave, nw);
+        if ((threadIdx.x & 63) == 0) tm->part[wave] = key;
+        __syncthreads();                                         // (B) the shares are posted
+    }
+}
+#endif
+
 struct TileSink {
     const u64 *anchors; GVec<u64> *tiles; u32 first_len, nchains; bool to_tiles;
     LNR_HD void emit(const i32 *idx, const i32 *sc, u32 n) {
@@ -403,7 +460,7 @@ struct TileSink {
     }
 };
 template <class Score>
-LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, bool to_tiles, u32 depth, u64 dx_depth, int bestn, int min_len, int abort_score, Score score, GapCtx &X, bool first_only = false) {
+LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, bool to_tiles, u32 depth, u64 dx_depth, int bestn, int min_len, int abort_score, Score score, GapCtx &X, int fn_id = 0) {
     if (n < 2 || X.ar->ovf) return;
 #ifdef LNR_GAP_PROF
     lnr_gap_prof_n(n);
@@ -431,6 +488,7 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
         const int lane = (int)(threadIdx.x & 63);
         u64 wa = 0, blk = 0;
         i32 ws = 0, wl = 0, wr = 0;
+        u32 far_prev = 0;
         for (int i = 0; i < (int)n; i++) {
             if ((i & 63) == 0) blk = (u32)(i + lane) < n ? anchors[i + lane] : 0;
             int j_str = i - (int)depth < 0 ? 0 : i - (int)depth;
@@ -442,28 +500,25 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
                     int sc = score(wa, ai);
                     if (sc > 0) key = ((u64)(u32)(sc + ws) << 32) | (u64)(0xffffffffu - (u32)j);
                 }
-                if (!__any(!ok))
-                    for (int jb = i - 65; jb >= 0; jb -= 256) {        // 256 predecessors per step: four loads in flight per lane, one exit test
-                        u64 av[4]; i32 sv[4]; bool okv[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            int j2 = jb - 64 * u - lane;
-                            av[u] = j2 >= 0 ? anchors[j2] : 0;
-                            sv[u] = j2 >= 0 ? r.score[j2] : 0;
-                        }
-                        bool stop = false;
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            int j2 = jb - 64 * u - lane;
-                            okv[u] = j2 >= 0 && (j2 >= j_str || ganc_x(av[u]) - xi < dx_depth);
-                            if (okv[u]) {
-                                int sc = score(av[u], ai);
-                                if (sc > 0) { u64 k = ((u64)(u32)(sc + sv[u]) << 32) | (u64)(0xffffffffu - (u32)j2); key = k > key ? k : key; }
-                            }
-                            stop = stop || !okv[u];
-                        }
-                        if (__any(stop)) break;                          // (x-descending: once a predecessor is out of range all earlier ones are)
-                    }
+                if (!__any(!ok) && i >= 65) {
+                    // beyond the window.  The row before tells how long this one is (the x window moves slowly): long rows go to the team
+                    u64 far;
+                    u32 nb = 0;
+                    if (X.team > 1 && fn_id && far_prev >= K_GAP_TEAM_ROW) {
+                        GapTeam *tm = X.tm;
+                        if (lane == 0) { tm->anchors = anchors; tm->score = r.score; tm->ai = ai; tm->dx_depth = dx_depth; tm->i = i; tm->j_str = j_str; tm->fn = fn_id; tm->cmd = 1; }
+                        __syncthreads();                                 // (A)
+                        u64 mine = gap_dp_row_share(anchors, r.score, ai, i, j_str, dx_depth, GapDpFn{fn_id}, 0, X.team, &nb);
+                        nb *= (u32)X.team;
+                        if (lane == 0) tm->part[0] = mine;
+                        __syncthreads();                                 // (B)
+                        far = 0;
+                        for (int w = 0; w < X.team; w++) { u64 o = tm->part[w]; far = o > far ? o : far; }
+                    } else
+                        far = gap_dp_row_share(anchors, r.score, ai, i, j_str, dx_depth, score, 0, 1, &nb);
+                    far_prev = nb * 256;                                 // the row's length in predecessors (rounded up to blocks)
+                    key = far > key ? far : key;
+                } else far_prev = 0;
             }
             for (int m = 32; m; m >>= 1) { u64 o = __shfl_xor(key, m); key = o > key ? o : key; }
             int best = key ? (int)(key >> 32) : -1, max_j = key ? (int)(0xffffffffu - (u32)key) : i;
@@ -504,7 +559,7 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
     TileSink sink; sink.anchors = anchors; sink.tiles = &out; sink.first_len = 0; sink.nchains = 0; sink.to_tiles = to_tiles;
     out.reserve(out.n + n);
     traceback(r, n, sink, chain, chain_sc, cnt, min_len, abort_score, bestn, 0.7f, *X.ls);
-    (void)first_only;
+    (void)fn_id;
     (void)m0;   // (not released: `out` may have been re-allocated above the mark)
 }
 // gather_blocks_ (pmpfinder.cpp:1484-1530) on tiles: a block ends at the tile-end sign (chainTiles gap_util.cpp:1177-1189, f_set_end 0)
@@ -605,7 +660,7 @@ LNR_HD inline void g_chains_from_anchors(GVec<u64> &anchors, GVec<u64> &tiles, u
     if (X.ar->ovf) return;
     { GP(X, 3); gap_sort(anchors.p, (long)anchors.n, [](const u64 &a, const u64 &b) { return ganc_x(a) > ganc_x(b); }, X); }
     int fn = X.gp.chn1_fn;
-    gap_chain_anchors(anchors.p, anchors.n, tiles, true, 20, 80, 20, X.gp.chn1_min_len, X.gp.chn1_abort, [fn](u64 a, u64 b) { return fn == 2 ? gap_anchor_score2_pos(a, b) : gap_anchor_score1_pos(a, b); }, X);
+    gap_chain_anchors(anchors.p, anchors.n, tiles, true, 20, 80, 20, X.gp.chn1_min_len, X.gp.chn1_abort, [fn](u64 a, u64 b) { return fn == 2 ? gap_anchor_score2_pos(a, b) : gap_anchor_score1_pos(a, b); }, X, fn == 2 ? 2 : 1);
     gap_chain_tiles(tiles, L, 100, X);
 }
 struct IPair { int first, second; };
@@ -935,7 +990,7 @@ LNR_HD inline int gap_map_along_chain(const GSeq &ref, const GSeq &seq2, const G
     stick_main_chain(anc, ch, X.gp.thd_smcn_danchor);
     GVec<u64> first; first.init(X.ar, anc.n + 16);
     // bestn 1: only the first chain is wanted; it is collected as anchors and turned into tiles below (chn_ext_clip_metric1: min length 1, abort 0)
-    gap_chain_anchors(anc.p, anc.n, first, false, 15, 30, 1, 1, 0, [](u64 p, u64 q) { return gap_clip_score(p, q); }, X);
+    gap_chain_anchors(anc.p, anc.n, first, false, 15, 30, 1, 1, 0, [](u64 p, u64 q) { return gap_clip_score(p, q); }, X, 5);
     int f_strand = (int)tile_strand(ch[0]);
     for (u32 i = 0; i < first.n; i++) { u64 t = ganc_tile(first[i]); if (f_strand) t |= 1ULL << 61; tiles.push(t); }
     return 0;

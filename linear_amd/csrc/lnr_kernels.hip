@@ -3017,7 +3017,7 @@ struct GapArgs {
 #ifndef K_GAP_WAVES
 #define K_GAP_WAVES 4
 #endif
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(K_GAP_WAVES, K_GAP_WAVES))) k_gap(GapArgs A) {
+__device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
     u32 worker = A.coop ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
     char *mine = A.arena + (u64)worker * A.arena_bytes;
     for (;;) {
@@ -3049,7 +3049,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves
             X.f1[0].p = A.f1 + A.f1_off[r]; X.f1[0].n = nf; X.f1[1].p = A.f1 + A.f1_off[r] + nf; X.f1[1].n = nf;
             X.gf = A.gf;
             X.gp.f_dup = A.f_dup; X.gp.thd_gap_len_min = A.gap_len_min;
-            X.coop = A.coop; X.work_cap = A.work_cap;
+            X.coop = A.coop; X.work_cap = A.work_cap; X.team = team; X.tm = tm;
             u64 *os = A.out_str + A.cords_off[r], *oe = A.out_end + A.cords_off[r];
             GVec<u64> cs, ce; cs.init(&keep, nc * 2 + 64); ce.init(&keep, nc * 2 + 64);
             for (u32 i = 0; i < nc; i++) { cs.push(os[i]); ce.push(oe[i]); }
@@ -3076,6 +3076,19 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves
         A.gap_flag[r] = bad ? 1 : 0;
         if (A.last && bad) A.read_err[r] = 5;
     }
+}
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(K_GAP_WAVES, K_GAP_WAVES))) k_gap(GapArgs A) { gap_worker(A, nullptr, 1); }
+// The launches for the flagged reads: K_GAP_TEAM waves per read.  Wave 0 is the worker; the others only serve the long rows of its
+// chain DPs (gap_team_helper_loop) and leave when wave 0 has run out of reads.
+#ifndef K_GAP_TEAM
+#define K_GAP_TEAM 8
+#endif
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * K_GAP_TEAM, 64 * K_GAP_TEAM))) k_gap_team(GapArgs A) {
+    __shared__ GapTeam tm;
+    if (threadIdx.x >= 64) { gap_team_helper_loop(&tm, (int)(threadIdx.x >> 6), K_GAP_TEAM); return; }
+    gap_worker(A, &tm, K_GAP_TEAM);
+    if (threadIdx.x == 0) tm.cmd = 0;
+    __syncthreads();                                             // (A) with the exit command: the helpers leave
 }
 
 }  // namespace lnr
