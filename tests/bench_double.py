@@ -22,7 +22,7 @@ def sample_reads(n, seed):
 
 
 class FilterDouble:
-    def __init__(self, device=-1, scratch_budget=0):
+    def __init__(self, device=-1, scratch_budget=0, index_type=1, gap_len=0, dup=0):
         self.blobs, self._seq_len, self.info, self.adopted, self.n = None, None, None, False, 0
         self.seen = []
 
