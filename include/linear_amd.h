@@ -58,7 +58,7 @@ typedef struct lnr_opts {
     uint32_t feature_type;     /* -f : 2 = 2-mer/48 window features (reference default) */
     uint32_t preset;           /* -p : 1 (reference default: chain stop ratio 0) */
     uint32_t gap_len;          /* -g : 0 = apxMap only; > 0 = the cords go through the gap re-mapper (mapGaps + reformCords, gap.cpp:407-576) with this
-                                  minimum gap length, mapped as the reference does: 1 -> 50, 2..9 -> 10 (mapper.cpp:438-453) */
+                                  minimum gap length, mapped as the reference does: 1 -> 50, 2..9 -> 10 (mapper.cpp:207-231) */
     uint32_t dup;              /* -dup : 0 | 1, the duplication add-on of the gap re-mapper (gap.cpp:303-362) */
     uint64_t scratch_budget;   /* max bytes of per-read device scratch in flight (0 = default 64 GiB of the 288 GB) */
 } lnr_opts;
@@ -108,7 +108,7 @@ typedef struct lnr_stats {
     uint64_t seed_bytes;
     double prep_ms, seed_count_ms, seed_gather_ms, job_ms, tail_ms, total_ms;
     uint32_t seed_count_launches, seed_gather_launches, job_launches;
-    uint32_t gap_second_pass;  /* reads the gap re-mapper ran a second time (one wave per read: out of arena or over the work budget as one lane) */
+    uint32_t gap_second_pass;  /* reads the gap re-mapper ran a second time (a team of waves per read: out of the first launch's arena or cord slot) */
     double gap_ms;             /* device time of the gap re-mapper (-g > 0) */
 } lnr_stats;
 

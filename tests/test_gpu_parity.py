@@ -511,3 +511,37 @@ def test_gpu_gap_path_matches_oracle_on_planted_svs(oracle_lib):
                 changed += not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))
             assert changed > len(rl) // 2, "the gap path should change the cords of most of these reads"
         o.close()
+
+
+def test_gpu_linear_filter_cli_with_gap_path(case_inputs, tmp_path):
+    """`linear_filter filter ... -g 50 -dup 1` end to end (the reference's default mode is -g on): the .sam / .apf are the writer's text of
+    the cords the real reference produced with -g 50 -dup 1 (tests/golden/edge_g50_T1.npz) -- i.e. the options reach the kernels and the
+    gap path's cords go through the same output surface; and without -g the front-end runs with the reference's default (-g 1 = 50)."""
+    import subprocess
+    from linear_amd import build as lb
+    from linear_amd.api import Writer
+    lb.build()
+    refs, reads, off = case_inputs("edge")
+    g = np.load(os.path.join(GOLD, "edge_g50_T1.npz"))
+    n = off.size - 1
+    rid, gid = cases.text_ids(n, len(refs))
+    abc = np.frombuffer(b"ACGTN", np.uint8)
+    with open(tmp_path / "ref.fa", "wb") as f:
+        for k, r in enumerate(refs):
+            t = abc[r].tobytes()
+            f.write(b">" + gid[k].encode() + b"\n" + b"\n".join(t[i:i + 70] for i in range(0, len(t), 70)) + b"\n")
+    with open(tmp_path / "reads.fa", "wb") as f:
+        for i in range(n):
+            f.write(b">" + rid[i].encode() + b"\n" + abc[reads[int(off[i]):int(off[i + 1])]].tobytes() + b"\n")
+    w = Writer(gid, [r.size for r in refs])
+    rl = np.diff(off.astype(np.int64)).astype(np.uint64)
+    for flags, dup in ((["-g", "50", "-dup", "1"], 1), ([], 0)):
+        p = subprocess.run([lb.CLI, "filter", str(tmp_path / "reads.fa"), str(tmp_path / "ref.fa"), "-t", "1", "-o", str(tmp_path / "out"), "-ot", "3"] + flags,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-1000:]
+        coff, cs, ce = g[f"cord_off_dup{dup}"], g[f"cords_str_dup{dup}"], g[f"cords_end_dup{dup}"]
+        sam = [l for l in open(tmp_path / "out.sam", "rb").read().split(b"\n") if not l.startswith(b"@PG")]
+        assert sam == [l for l in (w.sam_header("x") + w.format(coff, cs, ce, rl, rid, "sam")).split(b"\n") if not l.startswith(b"@PG")], flags
+        apf = [l for l in open(tmp_path / "out.apf", "rb").read().split(b"\n") if l]
+        assert apf == [l for l in w.format(coff, cs, ce, rl, rid, "apf").split(b"\n") if l], flags
+    w.close()
