@@ -327,6 +327,7 @@ def main():
                                   "job": acc["job_ms"] / K, "tail": acc["tail_ms"] / K, "gap": acc.get("gap_ms", 0.0) / K, "total_device": acc["total_ms"] / K},
             "device_resident_reads_per_s": dev_rate,
             "gap_second_pass_per_step": acc.get("gap_second_pass", 0) / K,
+            "gap_path_note": "this line is -g " + str(args.gap) + "; the reference's default mode -g 50 is measured by `python bench.py --gap 50` (profiles/r02/bench_gap50.json, DESIGN.md 5c)",
         },
         "roofline": {
             "bound": "hbm",
