@@ -9,10 +9,6 @@
 #include "lnr_hd.h"
 
 namespace lnr {
-#ifdef LNR_GAP_PROF
-static unsigned long long lnr_gap_prof_pairs = 0, lnr_gap_prof_maxn = 0, lnr_gap_prof_sumn = 0;
-static inline void lnr_gap_prof_n(unsigned long long n) { lnr_gap_prof_sumn += n; if (n > lnr_gap_prof_maxn) lnr_gap_prof_maxn = n; }
-#endif
 
 // ---- arena + growable array of the gap path: temporaries of one gap are released together (mark / release)
 struct GArena {
@@ -462,9 +458,6 @@ struct TileSink {
 template <class Score>
 LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, bool to_tiles, u32 depth, u64 dx_depth, int bestn, int min_len, int abort_score, Score score, GapCtx &X, int fn_id = 0) {
     if (n < 2 || X.ar->ovf) return;
-#ifdef LNR_GAP_PROF
-    lnr_gap_prof_n(n);
-#endif
     u64 m0 = X.ar->mark();
     Rec r;
     i32 *blk = (i32 *)X.ar->get((u64)n * 9 * sizeof(i32));
@@ -542,9 +535,6 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
     for (int i = 0; i < (int)n; i++) {
         int j_str = i - (int)depth < 0 ? 0 : i - (int)depth, max_j = i, best = -1, j = i - 1;
         for (; j >= 0 && (j >= j_str || ganc_x(anchors[j]) - ganc_x(anchors[i]) < dx_depth); j--) {
-#ifdef LNR_GAP_PROF
-            lnr_gap_prof_pairs++;
-#endif
             int sc = score(anchors[j], anchors[i]);
             if (sc > 0 && sc + r.score[j] >= best) { max_j = j; best = sc + r.score[j]; }
         }
