@@ -51,6 +51,31 @@ def case_edge():
     return refs, reads, off
 
 
+def case_ccs_sv():
+    """BASELINE configs[4]'s workload in small: PacBio-CCS-profile reads (15 kb, 0.5 % errors) with planted structural variants
+    (insertion, deletion, tandem duplication, inversion, foreign insert; 50 bp - 5 kb) in two reads out of three, on a repeat-rich
+    reference and one with N runs -- what `-g 50 -dup 1` exists for (gap-path goldens only: CASES_G50)."""
+    refs = [synth.repeat_ref(1_500_000, 515), synth.add_n_runs(synth.random_ref(700_000, 516), 517, n_runs=3, max_run=800)]
+    rng = np.random.default_rng(518)
+    cpl = np.array([3, 2, 1, 0, 4], np.uint8)
+    out = []
+    for k in range(72):
+        ref = refs[k % 2]
+        x0 = int(rng.integers(1000, ref.size - 30000))
+        seg = ref[x0:x0 + 16000].copy()
+        cut = int(rng.integers(3000, 11000)); m = int(rng.choice([50, 120, 400, 1200, 3000, 5000]))
+        kind = k % 6
+        if kind == 1: seg = np.concatenate([seg[:cut], seg[cut + m:]])
+        elif kind == 2: seg = np.concatenate([seg[:cut], rng.integers(0, 4, m, dtype=np.uint8), seg[cut:]])
+        elif kind == 3: seg = np.concatenate([seg[:cut], seg[max(cut - m, 0):cut], seg[cut:]])
+        elif kind == 4: seg = np.concatenate([seg[:cut], cpl[seg[cut:cut + m][::-1]], seg[cut + m:]])
+        elif kind == 5: seg = np.concatenate([seg[:cut], ref[x0 + 20000:x0 + 20000 + m], seg[cut:]])
+        r, o_, _ = synth.sample_reads([seg], 1, min(seg.size - 50, 15000), 0.005, 600 + k, "random")
+        out.append(np.ascontiguousarray(r[: int(o_[1])]))
+    reads, off = synth.pack_reads(out)
+    return refs, reads, off
+
+
 def case_scale():
     """Scale pin: 24 sequences, the first 262.5 Mb (longer than chr1: x + 2^20 beyond 2^28, 8 800 binning
     bins, 37 M index entries), ids up to 23, reads from both ends of the big sequence, chimeras big-end + sequence 23."""
@@ -79,6 +104,9 @@ CASES_I2 = {
     "edge": (case_edge, [1, 3]),
     "hbig": (case_hbig, [1, 4]),
 }
+
+# gap-path goldens (-g 50 and -g 50 -dup 1, made by the reference): name -> (builder, T); files <name>_g50_T<T>.npz
+CASES_G50 = {"ont": (case_ont, 1), "edge": (case_edge, 1), "ccs_sv": (case_ccs_sv, 1)}
 
 CASES = {
     # name: (builder, [T layouts])

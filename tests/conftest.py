@@ -29,6 +29,6 @@ def case_inputs():
 
     def get(name):
         if name not in _case_cache:
-            _case_cache[name] = (cases.CASES[name][0] if name in cases.CASES else cases.CASES_I2[name][0])()
+            _case_cache[name] = (cases.CASES[name][0] if name in cases.CASES else cases.CASES_I2[name][0] if name in cases.CASES_I2 else cases.CASES_G50[name][0])()
         return _case_cache[name]
     return get

@@ -198,7 +198,7 @@ def test_product_gap_map_units_match_oracle():
     co.close()
 
 
-@pytest.mark.parametrize("name", ["ont", "edge"])
+@pytest.mark.parametrize("name", ["ont", "edge", "ccs_sv"])
 def test_product_gap_path_matches_reference_golden(case_inputs, name):
     """apxMap + mapGaps + reformCords of the product's host build against cords the real reference produced with -g 50 [-dup 1]"""
     from tests import cases

@@ -466,7 +466,7 @@ def test_gpu_batch_rerun_on_per_read_overflow(case_inputs, monkeypatch):
 
 
 # ---- the gap re-mapper (-g > 0): mapGaps + reformCords on the GPU (k_gap)
-@pytest.mark.parametrize("name", ["ont", "edge"])
+@pytest.mark.parametrize("name", ["ont", "edge", "ccs_sv"])
 def test_gpu_gap_path_matches_golden(case_inputs, name):
     """lnr_opts.gap_len = 50 [dup = 1] through the C ABI against the cords the real reference produced with -g 50 [-dup 1]"""
     from linear_amd import Filter

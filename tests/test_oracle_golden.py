@@ -113,7 +113,7 @@ def test_oracle_hindex_matches_live_reference(oracle_lib):
 
 
 # ---- gap path (-g 50 [-dup 1]): the oracle's restatement (oracle/lnr_gap.inc) against the reference's goldens
-@pytest.mark.parametrize("name", ["ont", "edge"])
+@pytest.mark.parametrize("name", ["ont", "edge", "ccs_sv"])
 def test_oracle_gap_path_matches_reference_golden(oracle_lib, case_inputs, name):
     refs, reads, off = case_inputs(name)
     g = np.load(os.path.join(GOLD, f"{name}_g50_T1.npz"))

@@ -45,11 +45,11 @@ def main():
                 d[name + ":bases"], d[name + ":off"], d[name + ":ids"] = b, o, np.array(ids)
             np.savez_compressed(os.path.join(outdir, "reader.npz"), **d)
             print("reader.npz:", {k: int(v.size) for k, v in d.items() if k.endswith(":off")})
-    # gap path (-g 50; not built on the GPU yet): the reference's cords after mapGaps + reformCords, for the next tier
-    for name, T in (("ont", 1), ("edge", 1)):
-        if only and "g50" not in only:
+    # gap path (-g 50 [-dup 1]): the reference's cords after mapGaps + reformCords
+    for name, (builder, T) in cases.CASES_G50.items():
+        if only and "g50" not in only and (name + "_g50") not in only:
             continue
-        refs, reads, off = cases.CASES[name][0]()
+        refs, reads, off = builder()
         n = off.size - 1
         r = pyorc.Checker("ref", refs, T)
         d = {"digest": cases.input_digest(refs, reads, off), "T": T, "n_reads": n}
