@@ -388,6 +388,8 @@ def main():
         tp, _, _, _ = cpu_run(0, pilot)
         ns = int(min(args.reads, max(pilot, pilot * args.cpu_seconds / max(tp, 1e-3))))
         t_cpu, (ooff, ocs, oce, ost), rr, oo = cpu_run(0, ns)
+        if args.gap:
+            flt.gap_stream(0)        # the sample is a read stream of its own, as the CPU run took it (lnr_gap_stream)
         coff, cs, ce = flt.filter_batch(rr, oo)
         parity_ok = bool(np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce))
         label = ("the reference itself: oracle/_ref/libref_linear.so = the reference's own translation units (base, cords, shape_extend, index_util, "

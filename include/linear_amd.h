@@ -174,6 +174,17 @@ lnr_status lnr_seed_lookup_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads_concat
 
 lnr_status lnr_last_stats(const lnr_ctx *ctx, lnr_stats *st);
 
+/* The read stream's state of the gap re-mapper (gap_len > 0).  The reference keeps ONE GapParms per calculator thread for the whole run
+ * (Mapper::loadOptions mapper.cpp:233-237, used in p_calRecords :447) and mapExtend / mapExtends leave it modified (gap_util.cpp:4046-4071,
+ * 4088-4119).  Of the fields left behind only thd_cts_major_limit is read before it is written again (chainTiles :1188 under mapGeneric):
+ * 1 until the first mapExtend / mapExtends of the thread's stream, 3 for every read after it.  A context therefore IS one read stream:
+ * batches are taken in submission order, reads in batch order, exactly as `linear filter -t 1` meets them (with more threads the reference
+ * itself is not reproducible: what a read sees depends on which reads its thread met before).  The state lives in the context across
+ * batches.  set < 0: query only; set = 0: start a new stream (a new read file); set = 1: the stream has extended already -- what a
+ * front-end that deals the batches of one file over several contexts / GPUs sets on the others once the first context reports 1.
+ * *state (optional) receives the state after the call. */
+lnr_status lnr_gap_stream(lnr_ctx *ctx, int set, int *state);
+
 /* Input side (host code; replaces, for this path, the fetcher's SeqAn readRecords of src/parallel_io.cpp:433-485): FASTA or
  * FASTQ records, plain or gzip, decoded into the layout lnr_filter_batch / lnr_filter_submit take.  Characters convert as SeqAn's
  * char -> Dna5 table does (A/a 0, C/c 1, G/g 2, T/t/U/u 3, anything else N = 4).  lnr_reader_next fills dst (e.g. a block from

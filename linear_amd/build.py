@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "liblinear_amd.so")
 CLI = os.path.join(HERE, "linear_filter")
-SOURCES = ["lnr_api.hip", "lnr_kernels.hip", "lnr_hd.h", "ref_sort.h", "lnr_reader.cpp", "lnr_output.cpp", "linear_filter_main.cpp"]
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp", ".inc")))   # every source of csrc/: a new header cannot be forgotten
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 

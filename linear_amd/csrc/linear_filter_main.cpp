@@ -29,8 +29,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: %s filter <reads.fa|fq[.gz]> <genome.fa[.gz]> [-o prefix] [-t threads] [-i 1|2] [-g gap_len] [-dup 0|1] [-ot 1|2|3] [-b reads_per_block]\n", argv[0]);
         return 2;
     }
-    std::string reads_path = argv[2], genome_path = argv[3], prefix = "out", cmd;
-    for (int i = 0; i < argc; i++) { if (i) cmd += ' '; cmd += argv[i]; }
+    std::string reads_path = argv[2], genome_path = argv[3], prefix = "out";
     unsigned threads = 1, ot = 3, gap = 1, dup = 0, index_type = 1;   // (Options::Options base.cpp:28-45)
     uint32_t block_reads = 65536;
     for (int i = 4; i + 1 < argc; i += 2) {
@@ -85,7 +84,8 @@ int main(int argc, char **argv) {
     FILE *fsam = (ot & 2) ? fopen((prefix + ".sam").c_str(), "wb") : nullptr;
     FILE *fapf = (ot & 1) ? fopen((prefix + ".apf").c_str(), "wb") : nullptr;
     const char *text; uint64_t size;
-    if (fsam) { lnr_writer_sam_header(wr, cmd.c_str(), &text, &size); fwrite(text, 1, size, fsam); }
+    // `@PG ... CL:` stays empty: the reference's Options constructor fills cmd_line only `if (length(argv) < 1)` (base.cpp:64-72), i.e. never
+    if (fsam) { lnr_writer_sam_header(wr, "", &text, &size); fwrite(text, 1, size, fsam); }
     // ---- reads: two pinned blocks, one being decoded / uploaded while the other is on the GPU
     lnr_reader *rr = nullptr;
     if (lnr_reader_open(reads_path.c_str(), &rr) != LNR_OK) { fprintf(stderr, "E[10]: can't open read file %s\n", reads_path.c_str()); return 1; }

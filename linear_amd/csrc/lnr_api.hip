@@ -154,7 +154,8 @@ struct lnr_ctx {
     u32 overflow_reruns = 0;
     u32 seed_lds_pad = 0;   // diagnostic (LNR_SEED_LDS_PAD): dynamic LDS the seed kernel does not use, to lower its waves per CU
     DevBuf hx_nkeys, hx_nvals; u32 hx_nnodes = 0; u64 hx_empty_dir = 0;   // HIndex (-i 2): dir = hdir[2^18] (head of the block of X, -1: none), hs = ysa, nodes of the large blocks
-    DevBuf gap_arena, gap_flag, gap_next, d_seq_len, gap_prof;   // the gap re-mapper (-g > 0): arenas of its workers, per-read retry flags, the two work counters
+    DevBuf gap_arena, gap_flag, gap_next, d_seq_len, gap_prof, gap_first;
+    int gap_ext = 0;        // the read stream's state: 1 once a read of this context's stream went through mapExtend / mapExtends (lnr_gap_stream)   // the gap re-mapper (-g > 0): arenas of its workers, per-read retry flags, the two work counters
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl, ov;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines, ov = their aligned overflow lines (k_ix_lines)
     // ---- batch inputs / per-read arrays
     // host-buffer entry points: two input slots, so that the upload of the next batch (copy stream) runs under the kernels of
@@ -1082,6 +1083,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
     if (T.n) { hipLaunchKernelGGL(k_tail_b, dim3((T.n + 63) / 64), dim3(64), 0, ctx->stream, T); KCHECK(); }
     ctx->t_tail.stop(ctx->stream);
     if (early) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
+    int ext_state_out = ctx->gap_ext;
     if (ctx->opts.gap_len) {
         // the gap re-mapper on the final cords (k_gap): every read with small arenas, then the flagged reads with large ones
         u32 maxlen = 0;
@@ -1108,25 +1110,52 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         G.arena = (char *)ctx->gap_arena.p;
         G.prof = nullptr;
 #ifdef LNR_GAP_DEVPROF
-        ENSURE(ctx->gap_prof, 96 * 8);
-        HIPCK(hipMemsetAsync(ctx->gap_prof.p, 0, 96 * 8, ctx->stream));
+        ENSURE(ctx->gap_prof, (96 + (size_t)n) * 8);
+        HIPCK(hipMemsetAsync(ctx->gap_prof.p, 0, (96 + (size_t)n) * 8, ctx->stream));
         G.prof = ctx->gap_prof.as<unsigned long long>();
 #endif
         G.gap_len_min = ctx->opts.gap_len == 1 ? 50 : (ctx->opts.gap_len < 10 ? 10 : ctx->opts.gap_len);   // mapper.cpp:438-453
         G.f_dup = (int)ctx->opts.dup;
         ctx->t_gap.start(ctx->stream);
-        G.work_cap = ctx->gap_work_cap;
-        G.arena_bytes = arena1; G.next = ctx->gap_next.as<u32>(); G.big = 0; G.last = 0; G.coop = ctx->gap_mode;
-        hipLaunchKernelGGL(k_gap, dim3(ctx->gap_mode ? w1 : w1 / 64), dim3(64), 0, ctx->stream, G); KCHECK();
-        G.work_cap = ~0ULL;
-        G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1; G.coop = 1;
-        if (ctx->gap_team) hipLaunchKernelGGL(k_gap_team, dim3(w2), dim3(64 * K_GAP_TEAM), 0, ctx->stream, G);
-        else hipLaunchKernelGGL(k_gap, dim3(w2), dim3(64), 0, ctx->stream, G);
-        KCHECK();
-        G.arena_bytes = arena3; G.next = ctx->gap_next.as<u32>() + 24; G.last = 1;
-        if (ctx->gap_team) hipLaunchKernelGGL(k_gap_team, dim3(w3), dim3(64 * K_GAP_TEAM), 0, ctx->stream, G);
-        else hipLaunchKernelGGL(k_gap, dim3(w3), dim3(64), 0, ctx->stream, G);
-        KCHECK();
+        ENSURE(ctx->gap_first, 64);
+        G.first_ext = ctx->gap_first.as<u32>();
+        // one "ladder" = the three launches (small arenas for every read of [lo, hi), then the flagged reads with larger ones)
+        auto ladder = [&](u32 lo, u32 hi, u32 ext_from, int probe) -> hipError_t {
+            hipError_t e = hipMemsetAsync(ctx->gap_next.p, 0, 256, ctx->stream);
+            if (e != hipSuccess) return e;
+            u32 m = hi - lo;
+            G.lo = lo; G.n = hi; G.ext_from = ext_from; G.probe = probe;
+            G.work_cap = ctx->gap_work_cap;
+            G.arena_bytes = arena1; G.next = ctx->gap_next.as<u32>(); G.big = 0; G.last = 0; G.coop = ctx->gap_mode;
+            u32 v1 = std::min<u32>(w1, (u32)align_up(m, 64));
+            hipLaunchKernelGGL(k_gap, dim3(ctx->gap_mode ? v1 : v1 / 64), dim3(64), 0, ctx->stream, G);
+            G.work_cap = ~0ULL;
+            G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1; G.coop = 1;
+            if (ctx->gap_team) hipLaunchKernelGGL(k_gap_team, dim3(std::min(w2, m)), dim3(64 * K_GAP_TEAM), 0, ctx->stream, G);
+            else hipLaunchKernelGGL(k_gap, dim3(std::min(w2, m)), dim3(64), 0, ctx->stream, G);
+            G.arena_bytes = arena3; G.next = ctx->gap_next.as<u32>() + 24; G.last = 1;
+            if (ctx->gap_team) hipLaunchKernelGGL(k_gap_team, dim3(std::min(w3, m)), dim3(64 * K_GAP_TEAM), 0, ctx->stream, G);
+            else hipLaunchKernelGGL(k_gap, dim3(std::min(w3, m)), dim3(64), 0, ctx->stream, G);
+            return hipGetLastError();
+        };
+        // The stream state (GapArgs): once a read of the stream has extended, every later read starts "extended" -- one ladder over the batch.
+        // Until then the batch is taken in growing chunks: a probe ladder finds the chunk's first extending read r* (all reads started "not
+        // extended", nothing written), then the chunk is done for good with the reads behind r* started "extended".  The state is kept in
+        // the context across batches (one context = one read stream in file order, the reference's `-t 1`; lnr_gap_stream).
+        int ext_state = ctx->gap_ext;
+        u32 lo = 0;
+        for (u32 chunk = 256; lo < n && !ext_state; chunk = chunk < (1u << 20) ? chunk * 4 : chunk) {
+            u32 hi = (u32)std::min<u64>(n, (u64)lo + chunk), first = 0xffffffffu;
+            HIPCK(hipMemsetAsync(ctx->gap_first.p, 0xff, 64, ctx->stream));
+            HIPCK(ladder(lo, hi, 0xffffffffu, 1));
+            HIPCK(hipMemcpyAsync(&first, ctx->gap_first.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCK(hipStreamSynchronize(ctx->stream));
+            HIPCK(ladder(lo, hi, first == 0xffffffffu ? first : first + 1, 0));
+            if (first != 0xffffffffu) ext_state = 1;
+            lo = hi;
+        }
+        if (lo < n) HIPCK(ladder(lo, n, 0, 0));
+        ext_state_out = ext_state;
         ctx->t_gap.stop(ctx->stream);
 #ifdef LNR_GAP_DEVPROF
         {
@@ -1140,6 +1169,18 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
                 const unsigned long long *w = hp + 48 + 16 * L;
                 fprintf(stderr, "[gap prof]    slowest read: index %llu, length %llu, cords in %llu, arena high-water %llu bytes\n", w[10], w[11], w[12], w[13]);
                 for (int k = 0; k < 10; k++) fprintf(stderr, "[gap prof]    %-26s %10.1f ms  %5.1f %%   slowest read: %8.1f ms\n", nm[k], q[k] / 1e5, q[11] ? 100.0 * q[k] / q[11] : 0.0, w[k] / 1e5);
+            }
+            std::vector<unsigned long long> pr(n);
+            HIPCK(hipMemcpy(pr.data(), (char *)ctx->gap_prof.p + 96 * 8, (size_t)n * 8, hipMemcpyDeviceToHost));
+            for (int L = 0; L < 3; L++) {
+                std::vector<double> t;
+                for (u32 i = 0; i < n; i++) if (pr[i] && (int)(pr[i] >> 56) == L) t.push_back((double)(pr[i] & ((1ULL << 56) - 1)) / 1e5);
+                if (t.empty()) continue;
+                std::sort(t.begin(), t.end());
+                double sum = 0; for (double v : t) sum += v;
+                fprintf(stderr, "[gap prof] launch %d per-read ms: n %zu sum %.1f p50 %.3f p90 %.3f p99 %.3f p99.9 %.3f max %.3f | top:", L, t.size(), sum, t[t.size() / 2], t[t.size() * 9 / 10], t[t.size() * 99 / 100], t[(size_t)(t.size() * 0.999)], t.back());
+                for (size_t k = 0; k < 12 && k < t.size(); k++) fprintf(stderr, " %.1f", t[t.size() - 1 - k]);
+                fprintf(stderr, "\n");
             }
         }
 #endif
@@ -1176,6 +1217,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
             ctx->err = b;
             return LNR_ERR_INTERNAL;
         }
+    ctx->gap_ext = ext_state_out;        // (only a batch that went through: a re-run after an overflow starts from the state the batch met)
     ctx->h_cord_off.assign((size_t)n + 1, 0);
     for (u32 i = 0; i < n; i++) ctx->h_cord_off[i + 1] = ctx->h_cord_off[i] + nout[i];
     u64 tot = ctx->h_cord_off[n];
@@ -1765,6 +1807,13 @@ lnr_status lnr_prof_read(lnr_ctx *ctx, unsigned long long *out16) {
     return LNR_OK;
 }
 #endif
+
+lnr_status lnr_gap_stream(lnr_ctx *ctx, int set, int *state) {
+    if (!ctx || set > 1) return LNR_ERR_ARG;
+    if (set >= 0) ctx->gap_ext = set;
+    if (state) *state = ctx->gap_ext;
+    return LNR_OK;
+}
 
 lnr_status lnr_last_stats(const lnr_ctx *ctx, lnr_stats *st) {
     if (!ctx || !st) return LNR_ERR_ARG;

@@ -1285,13 +1285,13 @@ LNR_HD inline int gap_map_gap(u64 gap_str, u64 gap_end, GVec<u64> &tiles_str, GV
         if (shift_y > (i64)(X.read.len - 1 - cord_y(gap_str))) shift_y = (i64)(X.read.len - 1 - cord_y(gap_str));
         if (shift_x < 0) shift_x = 0;
         if (shift_y < 0) shift_y = 0;
-        gap_map_extend(ref, ts1, te1, gap_str, shift_cord(gap_str, shift_x, shift_y), 1, X);
+        gap_map_extend(ref, ts1, te1, gap_str, shift_cord(gap_str, shift_x, shift_y), 1, X);     // (mapExtend takes seqs[id of ITS gap_str], gap_util.cpp:4055)
         shift_x = (x2 - x1 > 0) ? gmin3(x2 - x1, (i64)cord_x(gap_end), ext2) : ext1;
         shift_y = (i64)((float)(x2 - x1) * (1 + gp.thd_err));
         if (shift_y > (i64)cord_y(gap_end)) shift_y = (i64)cord_y(gap_end);
         if (shift_x < 0) shift_x = 0;
         if (shift_y < 0) shift_y = 0;
-        gap_map_extend(ref, ts2, te2, shift_cord(gap_end, -shift_x, -shift_y), gap_end, -1, X);
+        { u64 gs_ = shift_cord(gap_end, -shift_x, -shift_y); gap_map_extend(X.ref(cord_id(gs_)), ts2, te2, gs_, gap_end, -1, X); }   // the other sequence when the gap joins cords of two
         if (!ts1.empty()) { gvec_cat(tiles_str, ts1); gvec_cat(tiles_end, te1); }
         if (!ts2.empty()) { gvec_cat(tiles_str, ts2); gvec_cat(tiles_end, te2); }
     } else if (x1 + T > x2 || y1 + T > y2) return 0;
@@ -1323,7 +1323,7 @@ LNR_HD inline int gap_map_gap(u64 gap_str, u64 gap_end, GVec<u64> &tiles_str, GV
             } else f_extends = 0;
             if (f_extends) {
                 if (f_extends == 1) gap_map_extends(ref, ts1, te1, ts2, te2, gs1, ge1, gs2, ge2, X);
-                else { gap_map_extend(ref, ts1, te1, gs1, ge1, 1, X); gap_map_extend(ref, ts2, te2, gs2, ge2, -1, X); }
+                else { gap_map_extend(ref, ts1, te1, gs1, ge1, 1, X); gap_map_extend(X.ref(cord_id(gs2)), ts2, te2, gs2, ge2, -1, X); }
                 if (!ts1.empty()) { gvec_cat(tiles_str, ts1); gvec_cat(tiles_end, te1); remove_tile_sgn(tiles_str.back()); remove_tile_sgn(tiles_end.back()); }
                 if (!ts2.empty()) { remove_tile_sgn(ts2[0]); remove_tile_sgn(te2[0]); gvec_cat(tiles_str, ts2); gvec_cat(tiles_end, te2); }
             }
@@ -1338,7 +1338,7 @@ LNR_HD inline int gap_map_gap(u64 gap_str, u64 gap_end, GVec<u64> &tiles_str, GV
     for (u32 i = 1; i < tiles_str.n; i++) {                                                     // addon 1: what is still open between consecutive tiles
         i64 dx = (i64)(cord_x(tiles_str[i]) - cord_x(tiles_end[i - 1])), dy = (i64)(cord_y(tiles_str[i]) - cord_y(tiles_end[i - 1]));
         if (tile_strand(tiles_str[i] ^ tiles_str[i - 1])) continue;
-        if (dx > 90 && dy > 90) i += gap_splice_generic(ref, tiles_str, tiles_end, i, tiles_str[i - 1], tiles_str[i], false, X);
+        if (dx > 90 && dy > 90) i += gap_splice_generic(X.ref(cord_id(tiles_str[i - 1])), tiles_str, tiles_end, i, tiles_str[i - 1], tiles_str[i], false, X);   // mapGeneric: seqs[id of its gap_str] (gap_util.cpp:4508)
     }
     if (gp.f_dup) {                                                                              // addon 2: duplications (-dup 1)
         const float rate = 0.1f;
@@ -1349,7 +1349,7 @@ LNR_HD inline int gap_map_gap(u64 gap_str, u64 gap_end, GVec<u64> &tiles_str, GV
             if (dy > 100 && dy - dx > gp.thd_mg1_danc_indel) {
                 i64 w = (i64)((float)dy * (1 + rate));
                 i64 e1 = -(w < xa ? w : xa), lim = (i64)(ref.len - (u64)xb - 1), e2 = w < lim ? w : lim;
-                i += gap_splice_generic(ref, tiles_str, tiles_end, i, shift_cord(tiles_end[i - 1], e1, 0), shift_cord(tiles_str[i], e2, 0), true, X);
+                { u64 gs_ = shift_cord(tiles_end[i - 1], e1, 0); i += gap_splice_generic(X.ref(cord_id(gs_)), tiles_str, tiles_end, i, gs_, shift_cord(tiles_str[i], e2, 0), true, X); }
             }
         }
     }

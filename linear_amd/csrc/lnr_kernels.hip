@@ -3013,6 +3013,11 @@ struct GapArgs {
     int coop;   // one wave per read (the launches after the first; LNR_GAP_MODE=1: the first too)
     int big;    // only the reads an earlier launch flagged
     int last;   // what this launch cannot do either is an error of the read
+    // The read stream's state (DESIGN 5c "stream state"): the reference keeps ONE GapParms per thread for the whole run and the first
+    // mapExtend / mapExtends of the stream leaves thd_cts_major_limit = 3 behind for every later read (mapper.cpp:233-237,447,
+    // gap_util.cpp:4052,4091; read by chainTiles :1188).  Reads [lo, n) are processed; those with index >= ext_from start "extended".
+    // probe: nothing is written back -- the launch only finds the first read that extends (atomicMin into *first_ext).
+    u32 lo; u32 ext_from; int probe; u32 *first_ext;
 };
 #ifndef K_GAP_WAVES
 #define K_GAP_WAVES 4
@@ -3024,6 +3029,7 @@ __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
         u32 r;
         if (A.coop) { r = threadIdx.x == 0 ? atomicAdd(A.next, 1u) : 0u; r = (u32)__shfl((int)r, 0); }
         else r = atomicAdd(A.next, 1u);
+        r += A.lo;
         if (r >= A.n) break;
         if (A.big && !A.gap_flag[r]) continue;
         if (A.big && threadIdx.x == 0) atomicAdd(A.next + 8, 1u);   // (statistics: reads of the second launch)
@@ -3049,6 +3055,8 @@ __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
             X.f1[0].p = A.f1 + A.f1_off[r]; X.f1[0].n = nf; X.f1[1].p = A.f1 + A.f1_off[r] + nf; X.f1[1].n = nf;
             X.gf = A.gf;
             X.gp.f_dup = A.f_dup; X.gp.thd_gap_len_min = A.gap_len_min;
+            const bool ext_in = r >= A.ext_from;
+            if (ext_in) X.gp.thd_cts_major_limit = 3;
             X.coop = A.coop; X.work_cap = A.work_cap; X.team = team; X.tm = tm;
             u64 *os = A.out_str + A.cords_off[r], *oe = A.out_end + A.cords_off[r];
             GVec<u64> cs, ce; cs.init(&keep, nc * 2 + 64); ce.init(&keep, nc * 2 + 64);
@@ -3064,13 +3072,17 @@ __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
                 t_read = wall_clock64() - t_read;
                 for (int k = 0; k < 10; k++) atomicAdd(pp + k, X.prof[k]);
                 atomicAdd(pp + 11, t_read); atomicAdd(pp + 12, 1ULL);
+                A.prof[96 + r] = t_read | ((unsigned long long)(A.big + A.last) << 56);      // per-read time of the launch that did the read
                 if (atomicMax(pp + 15, t_read) < t_read) { unsigned long long *ps = A.prof + 48 + 16 * (A.big + A.last); for (int k = 0; k < 10; k++) ps[k] = X.prof[k]; ps[10] = r; ps[11] = L; ps[12] = nc; ps[13] = ar.hw; }
             }
 #endif
             bad = rc_ != 0 || ar.ovf || keep.ovf || cs.n > A.cords_cap[r] || cs.n != ce.n;
             if (!bad) {
-                for (u32 i = 0; i < cs.n; i++) { os[i] = cs[i]; oe[i] = ce[i]; }
-                A.nout[r] = cs.n;
+                if (!ext_in && X.gp.thd_cts_major_limit == 3 && threadIdx.x == (A.coop ? 0u : threadIdx.x)) atomicMin(A.first_ext, r);
+                if (!A.probe) {
+                    for (u32 i = 0; i < cs.n; i++) { os[i] = cs[i]; oe[i] = ce[i]; }
+                    A.nout[r] = cs.n;
+                }
             }
         }
         A.gap_flag[r] = bad ? 1 : 0;

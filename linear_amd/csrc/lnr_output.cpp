@@ -116,7 +116,10 @@ void put_u(std::string &s, unsigned long long v) { char b[24]; int n = snprintf(
 void put_i(std::string &s, long long v) { char b[24]; int n = snprintf(b, sizeof b, "%lld", v); s.append(b, (size_t)n); }
 
 // SA:Z entry of one record (createSAZTagCigar / createSAZTagOneChimeric, align_util.cpp:452-520,682-714): xS yM z[I|D] 0S, zeros kept
-void saz_entry(const Rec &r, const char *gname, std::string &out) {
+// `first_visit`: createSAZTagCigarOneChimeric (align_util.cpp:642-678) sums NM only while the record's saz_cigar is still empty, i.e. the
+// first time any line of the read lists this record; every later listing prints 0 (the cached saz_cigar is merged, nm_i_sum stays at its
+// sentinel).  Line 0 therefore carries the real NM of every other record, line 1 the real NM of record 0 only, all else 0.
+void saz_entry(const Rec &r, const char *gname, bool first_visit, std::string &out) {
     unsigned long long s0 = 0, cm = 0, nm = 0;
     long long ci = 0;
     for (size_t i = 0; i < r.cigar.size(); i++) {
@@ -135,7 +138,7 @@ void saz_entry(const Rec &r, const char *gname, std::string &out) {
     put_u(out, (unsigned)cm); out += 'M';
     put_u(out, (unsigned)std::llabs(ci)); out += ci < 0 ? 'I' : 'D';
     out += "0S,255,";
-    put_i(out, (int)nm); out += ';';
+    put_i(out, first_visit ? (int)nm : 0); out += ';';
 }
 
 struct Writer {
@@ -147,6 +150,7 @@ struct Writer {
 
 void sam_read(const Writer &w, const u64 *cs, const u64 *ce, u64 n, u64 L, const char *qname, std::string &out, std::vector<Rec> &recs) {
     cords_to_records(cs, ce, n, L, recs, w.thd_large_X, w.thd_DI, w.thd_X);
+    std::vector<char> saz_done(recs.size(), 0);       // "saz_cigar not empty" per record (fillBamRecordLinkRecords walks the heads in record order)
     for (size_t it = 0; it < recs.size(); it++) {
         const Rec &r = recs[it];
         const char *g = (size_t)r.rid < w.gid.size() ? w.gid[(size_t)r.rid].c_str() : "*";
@@ -160,7 +164,10 @@ void sam_read(const Writer &w, const u64 *cs, const u64 *ce, u64 n, u64 L, const
         if (recs.size() > 1) {                         // SA:Z: every other line of the read, in record order (createSAZTagOneLine)
             out += "\tSA:Z:";
             for (size_t j = 0; j < recs.size(); j++)
-                if (j != it) saz_entry(recs[j], (size_t)recs[j].rid < w.gid.size() ? w.gid[(size_t)recs[j].rid].c_str() : "*", out);
+                if (j != it) {
+                    saz_entry(recs[j], (size_t)recs[j].rid < w.gid.size() ? w.gid[(size_t)recs[j].rid].c_str() : "*", !saz_done[j], out);
+                    saz_done[j] = 1;
+                }
         }
         out += '\n';
     }

@@ -1713,7 +1713,8 @@ uint64_t orc_gap_canchors(const uint8_t *g, uint64_t glen, const uint8_t *r, uin
     return out_u64(anc, out, cap);
 }
 
-static void gp_alt(GapParms &gp, int alt) { if (alt) { gp.chn1_min_len = 1; gp.chn1_abort = 0; gp.chn1_fn = 2; gp.chn2_abort = 0; gp.chn2_fn = 3; } }
+// alt bit 0: the chain metrics mapGap_ swaps in around its extensions (gap.cpp:124-130); bit 1: thd_cts_major_limit 3 (the stream state "extended")
+static void gp_alt(GapParms &gp, int alt) { if (alt & 1) { gp.chn1_min_len = 1; gp.chn1_abort = 0; gp.chn1_fn = 2; gp.chn2_abort = 0; gp.chn2_fn = 3; } if (alt & 2) gp.thd_cts_major_limit = 3; }
 uint64_t orc_gap_chains(const uint64_t *anchors, uint64_t n, uint64_t read_len, int alt, int direction, uint64_t gap_str, uint64_t gap_end, int closest, uint64_t *out, uint64_t cap, int *pr) {
     std::vector<u64> a(anchors, anchors + n), tiles;
     GapParms gp; gp_alt(gp, alt); gp.direction = direction;
@@ -1747,8 +1748,20 @@ uint64_t orc_gap_map(void *h, const uint8_t *read, uint64_t len, int which, uint
     return n1 | ((u64)te1.size() << 32);
 }
 
-// apxMap + mapGaps + reformCords as Mapper::p_calRecords runs them for -g gap_len [-dup] (mapper.cpp:207-231,438-453)
-uint64_t orc_map_read_g(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup) {
+// apxMap + mapGaps + reformCords as Mapper::p_calRecords runs them for -g gap_len [-dup] (mapper.cpp:207-231,438-453).
+// THE STREAM STATE.  The Mapper keeps ONE GapParms per thread for the whole run (mapper.cpp:233-237, used :447) and mapExtend / mapExtends leave
+// fields of it changed (gap_util.cpp:4046-4071,4088-4119).  Of those only thd_cts_major_limit is ever read before it is written again:
+// `direction` is set by every caller of getClosestExtensionChain_ (gap_util.cpp:3667,3671,3935), f_gmsa_direction is never read, the two
+// thd_ctfas2_* values are re-set to their defaults.  thd_cts_major_limit is 1 until the first mapExtend / mapExtends of the thread's read
+// stream and 3 from then on (read by chainTiles, :1188, under mapGeneric).  `*ext_state` carries that bit in and out: 0 = nothing extended
+// yet, 1 = extended.  With one thread (`-t 1`, file order) this is the program's result; with more threads the reference itself is not
+// reproducible (which reads a thread meets before its first extension depends on the schedule).
+static void gap_parms_for(GapParms &gp, uint32_t gap_len, int f_dup, int ext_state) {
+    gp.f_dup = f_dup;
+    gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
+    if (ext_state) gp.thd_cts_major_limit = 3;
+}
+uint64_t orc_map_read_g2(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup, int *ext_state) {
     Ctx *c = (Ctx *)h;
     auto rd = padded(read, len);
     apxMap(*c, c->w, rd.data(), len);
@@ -1762,11 +1775,21 @@ uint64_t orc_map_read_g(void *h, const uint8_t *read, uint64_t len, uint32_t gap
     GapFeat F{f1, &c->f2};
     GapGenome G{&c->seqs, &c->lens};
     GapParms gp;
-    gp.f_dup = f_dup;
-    gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
+    gap_parms_for(gp, gap_len, f_dup, ext_state ? *ext_state : 0);
     mapGaps(G, Seq{rd.data(), len}, Seq{com.data(), len}, c->w.cords_str, c->w.cords_end, c->w.apx_gaps, F, gp);
     reformCords(c->w.cords_str, c->w.cords_end);
+    if (ext_state) *ext_state = gp.thd_cts_major_limit == 3;
     return c->w.cords_str.size();
+}
+uint64_t orc_map_read_g(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup) { return orc_map_read_g2(h, read, len, gap_len, f_dup, nullptr); }
+// the same with the trace of every mapExtend / mapExtends / mapGeneric call of mapGap_ (layout: gap_trace_call in lnr_gap.inc); returns the words of the trace
+uint64_t orc_map_read_g_trace(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup, int ext_state, uint64_t *out, uint64_t cap) {
+    std::vector<u64> t;
+    gap_trace = &t;
+    orc_map_read_g2(h, read, len, gap_len, f_dup, &ext_state);
+    gap_trace = nullptr;
+    for (size_t i = 0; i < t.size() && i < cap; i++) out[i] = t[i];
+    return t.size();
 }
 int orc_gap_score(int which, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t read_len, int strand) {
     switch (which) {
@@ -1818,15 +1841,26 @@ uint64_t orc_debug_get(void *h, int stage, uint64_t *out, uint64_t cap) {
 // stats5 (optional) accumulates samples, lookups, bucket entries, anchors, DP pair evaluations over the batch.
 uint64_t orc_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
                          uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint64_t *stats5, uint32_t gap_len, int f_dup);
+uint64_t orc_map_batch_g2(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
+                          uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint64_t *stats5, uint32_t gap_len, int f_dup, int *ext_state);
 uint64_t orc_map_batch(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
                        uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint64_t *stats5) {
     return orc_map_batch_g(h, reads, off, n, threads, cord_off, cords_str, cords_end, cap, stats5, 0, 0);
 }
 uint64_t orc_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
                          uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint64_t *stats5, uint32_t gap_len, int f_dup) {
+    int st = 0;     // a fresh stream: the batch is the whole read file
+    return orc_map_batch_g2(h, reads, off, n, threads, cord_off, cords_str, cords_end, cap, stats5, gap_len, f_dup, &st);
+}
+// The batch in FILE ORDER as one thread of the reference would meet it (`-t 1`), on `threads` host threads: apxMap of every read in
+// parallel; then the gap re-mapper read by read until the stream state flips (see orc_map_read_g2) and in parallel from there on -- every
+// later read starts from the flipped state whatever the schedule.  *ext_state in / out.
+uint64_t orc_map_batch_g2(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
+                          uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint64_t *stats5, uint32_t gap_len, int f_dup, int *ext_state) {
     Ctx *c = (Ctx *)h;
     if (threads < 1) threads = 1;
     std::vector<std::vector<u64>> rs(n), re(n);
+    std::vector<std::vector<UPair>> rg(gap_len ? n : 0);
     std::vector<Work> works(threads);
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 16)
     for (uint32_t i = 0; i < n; i++) {
@@ -1839,8 +1873,16 @@ uint64_t orc_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uin
         std::vector<uint8_t> s(len + SEQ_PAD, 0);
         memcpy(s.data(), reads + off[i], len);
         apxMap(*c, w, s.data(), len);
-        if (gap_len && len > 200) {
-            std::vector<uint8_t> com(len + SEQ_PAD, 0);
+        rs[i] = w.cords_str;
+        re[i] = w.cords_end;
+        if (gap_len) rg[i] = w.apx_gaps;
+    }
+    if (gap_len) {
+        auto gap_read = [&](uint32_t i, int entry) -> int {
+            u64 len = off[i + 1] - off[i];
+            if (len <= 200) return entry;
+            std::vector<uint8_t> s(len + SEQ_PAD, 0), com(len + SEQ_PAD, 0);
+            memcpy(s.data(), reads + off[i], len);
             static const uint8_t cpl[5] = {3, 2, 1, 0, 4};
             for (u64 k = 0; k < len; k++) com[k] = cpl[s[len - k - 1]];
             Feat f1[2];
@@ -1849,13 +1891,17 @@ uint64_t orc_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uin
             GapFeat F{f1, &c->f2};
             GapGenome G{&c->seqs, &c->lens};
             GapParms gp;
-            gp.f_dup = f_dup;
-            gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
-            mapGaps(G, Seq{s.data(), len}, Seq{com.data(), len}, w.cords_str, w.cords_end, w.apx_gaps, F, gp);
-            reformCords(w.cords_str, w.cords_end);
-        }
-        rs[i] = w.cords_str;
-        re[i] = w.cords_end;
+            gap_parms_for(gp, gap_len, f_dup, entry);
+            mapGaps(G, Seq{s.data(), len}, Seq{com.data(), len}, rs[i], re[i], rg[i], F, gp);
+            reformCords(rs[i], re[i]);
+            return gp.thd_cts_major_limit == 3;
+        };
+        uint32_t i0 = 0;
+        int st = ext_state ? *ext_state : 0;
+        while (i0 < n && !st) st = gap_read(i0++, 0);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 16)
+        for (uint32_t i = i0; i < n; i++) gap_read(i, 1);
+        if (ext_state) *ext_state = st;
     }
     u64 tot = 0;
     cord_off[0] = 0;

@@ -155,13 +155,17 @@ class Checker:
         self._f("get_cords")(self.h, _p(cs, _u64p), _p(ce, _u64p))
         return cs[:n], ce[:n]
 
-    def map_read_gap(self, read: np.ndarray, gap_len: int = 50, dup: int = 0):
-        """apxMap + mapGaps + reformCords as `linear filter -g gap_len [-dup 1]` runs them."""
-        fn = self._f("map_read_g")
+    def map_read_gap(self, read: np.ndarray, gap_len: int = 50, dup: int = 0, ext: int = 0):
+        """apxMap + mapGaps + reformCords as `linear filter -g gap_len [-dup 1]` runs them.  `ext`: the stream state the
+        read starts from (0 = nothing extended yet in this thread's stream, 1 = extended: thd_cts_major_limit 3); the state it leaves
+        behind is kept in self.ext_out."""
+        fn = self._f("map_read_g2")
         fn.restype = C.c_uint64
-        fn.argtypes = [C.c_void_p, _u8p, C.c_uint64, C.c_uint32, C.c_int]
+        fn.argtypes = [C.c_void_p, _u8p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
         read = np.ascontiguousarray(read, dtype=np.uint8)
-        n = int(fn(self.h, _p(read, _u8p), read.size, gap_len, dup))
+        st = C.c_int(ext)
+        n = int(fn(self.h, _p(read, _u8p), read.size, gap_len, dup, C.byref(st)))
+        self.ext_out = st.value
         cs, ce = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
         if n:
             self._f("get_cords")(self.h, _p(cs, _u64p), _p(ce, _u64p))
@@ -176,10 +180,12 @@ class Checker:
         n = fn(self.h, _p(out, _u64p), 4096)
         return out[: 2 * n].reshape(-1, 2).copy()
 
-    def map_batch(self, reads: np.ndarray, off: np.ndarray, threads: int = 1, gap_len: int = 0, dup: int = 0):
+    def map_batch(self, reads: np.ndarray, off: np.ndarray, threads: int = 1, gap_len: int = 0, dup: int = 0, ext: int | None = 0):
         """CSR cords for a batch on `threads` host threads; returns (cord_off, cords_str, cords_end, stats5).  The reference
         (kind "ref") runs its own per-thread scratch as Mapper::p_calRecords does and has no counters (stats5 = zeros).
-        gap_len > 0: the gap re-mapper behind apxMap (-g gap_len [-dup dup])."""
+        gap_len > 0: the gap re-mapper behind apxMap (-g gap_len [-dup dup]).  `ext`: the stream state the batch starts from -- the result
+        is the program's `-t 1` result in file order whatever `threads` is (the state after the batch is kept in self.ext_out);
+        ext=None (reference only): one GapParms per thread and a dynamic schedule, as the program runs with -t threads."""
         reads = np.ascontiguousarray(reads, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         n = off.size - 1
@@ -190,14 +196,19 @@ class Checker:
         st = np.zeros(5, np.uint64)
         if self.kind == "ref":
             assert int(off[0]) == 0
-            self.lib.ref_map_batch_g.restype = C.c_uint64
-            self.lib.ref_map_batch_g.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.c_int, _u64p, _u64p, _u64p, C.c_uint64, C.c_uint32, C.c_int]
-            tot = self.lib.ref_map_batch_g(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap, gap_len, dup)
+            self.lib.ref_map_batch_g2.restype = C.c_uint64
+            self.lib.ref_map_batch_g2.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.c_int, _u64p, _u64p, _u64p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
+            es = C.c_int(ext or 0)
+            tot = self.lib.ref_map_batch_g2(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap, gap_len, dup,
+                                            None if ext is None else C.byref(es))
+            self.ext_out = es.value
             assert tot <= cap, "cord capacity"
             return coff, cs[:tot], ce[:tot], st
-        self.lib.orc_map_batch_g.restype = C.c_uint64
-        self.lib.orc_map_batch_g.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.c_int, _u64p, _u64p, _u64p, C.c_uint64, _u64p, C.c_uint32, C.c_int]
-        tot = self.lib.orc_map_batch_g(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap, _p(st, _u64p), gap_len, dup)
+        self.lib.orc_map_batch_g2.restype = C.c_uint64
+        self.lib.orc_map_batch_g2.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint32, C.c_int, _u64p, _u64p, _u64p, C.c_uint64, _u64p, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
+        es = C.c_int(ext or 0)
+        tot = self.lib.orc_map_batch_g2(self.h, _p(reads, _u8p), _p(off, _u64p), n, threads, _p(coff, _u64p), _p(cs, _u64p), _p(ce, _u64p), cap, _p(st, _u64p), gap_len, dup, C.byref(es))
+        self.ext_out = es.value
         assert tot <= cap, "cord capacity"
         return coff, cs[:tot], ce[:tot], st
 

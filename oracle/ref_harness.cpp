@@ -157,7 +157,10 @@ uint64_t ref_map_read(void *h, const uint8_t *read, uint64_t len) {
 }
 // apxMap + the gap re-mapper as Mapper::p_calRecords runs them for `-g gap_len [-dup f_dup]` (mapper.cpp:207-231,438-453): SURVEY 8 f1,
 // not built on the GPU yet -- this entry point makes its goldens.
-uint64_t ref_map_read_g(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup) {
+uint64_t ref_map_read_g2(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup, int *ext_state);
+uint64_t ref_map_read_g(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup) { return ref_map_read_g2(h, read, len, gap_len, f_dup, nullptr); }
+// ext_state (optional, in / out): the stream state the read starts from and leaves behind (see ref_map_batch_g2)
+uint64_t ref_map_read_g2(void *h, const uint8_t *read, uint64_t len, uint32_t gap_len, int f_dup, int *ext_state) {
     uint64_t n0 = ref_map_read(h, read, len);
     RefCtx *c = (RefCtx *)h;
     if (len <= 200 || gap_len == 0) return n0;
@@ -167,10 +170,12 @@ uint64_t ref_map_read_g(void *h, const uint8_t *read, uint64_t len, uint32_t gap
     gp.f_dup = f_dup;
     gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
     gp.read_id = "read";
+    if (ext_state && *ext_state) gp.thd_cts_major_limit = 3;
     String<uint64_t> clips;
     mapGaps(c->g, r, c->com, c->cs, c->ce, clips, c->gaps, c->f1, c->f2, gp);
     CordsParms cp;
     reformCords(c->cs, c->ce, &reformCordsDxDy1, cp);
+    if (ext_state) *ext_state = gp.thd_cts_major_limit == 3;
     return length(c->cs);
 }
 
@@ -206,8 +211,9 @@ uint64_t ref_gap_canchors(const uint8_t *g, uint64_t glen, const uint8_t *r, uin
 }
 
 // alt != 0: the chain metrics as mapGap_ sets them for its indel branch (gap.cpp:123-130)
-static void gp_alt(GapParms &gp, int alt) {
-    if (!alt) return;
+static void gp_alt(GapParms &gp, int alt) {          // bit 0: mapGap_'s swapped chain metrics (gap.cpp:124-130); bit 1: thd_cts_major_limit 3 (stream state "extended")
+    if (alt & 2) gp.thd_cts_major_limit = 3;
+    if (!(alt & 1)) return;
     gp.chn_score1.thd_min_chain_len = 1; gp.chn_score1.thd_abort_score = 0; gp.chn_score1.getScore = &getGapAnchorsChainScore2;
     gp.chn_score2.thd_abort_score = 0; gp.chn_score2.getScore2 = &getGapBlocksChainScore3;
 }
@@ -277,47 +283,63 @@ uint64_t ref_map_batch(void *h, const uint8_t *reads, const uint64_t *off, uint3
                        uint64_t *cords_str, uint64_t *cords_end, uint64_t cap) {
     return ref_map_batch_g(h, reads, off, n, threads, cord_off, cords_str, cords_end, cap, 0, 0);
 }
-// the calculator loop with the gap re-mapper (-g gap_len [-dup f_dup]) behind apxMap, as Mapper::p_calRecords runs it (mapper.cpp:207-231)
-uint64_t ref_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
-                         uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint32_t gap_len, int f_dup) {
+// the calculator loop with the gap re-mapper (-g gap_len [-dup f_dup]) behind apxMap, as Mapper::p_calRecords runs it (mapper.cpp:207-231).
+// GapParms: ONE per thread for the whole call, as the Mapper keeps one per thread for the whole run (mapper.cpp:233-237, used :447) --
+// mapExtend / mapExtends leave it modified (gap_util.cpp:4046-4071,4088-4119), so with more than one thread the result of a read can
+// depend on which reads its thread met before (in the reference itself).
+//   ext_state == NULL : exactly that, `threads` threads, dynamic schedule (the CPU baseline of bench.py).
+//   ext_state != NULL : the program's `-t 1` result (file order through one GapParms) computed on `threads` threads: reads are taken one by
+//                       one through ONE GapParms until its thd_cts_major_limit flips to 3 (the only leaked field that is read before it is
+//                       written again; see oracle/lnr_oracle.cpp orc_map_read_g2), the rest in parallel on copies of that object.
+//                       *ext_state in (0 fresh stream, 1 already extended) / out.
+static GapParms harness_gap_parms(uint32_t gap_len, int f_dup) {
+    GapParms gp(0.2);
+    gp.f_dup = f_dup;
+    gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);     // mapper.cpp:207-231
+    gp.read_id = "read";
+    return gp;
+}
+uint64_t ref_map_batch_g2(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
+                          uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint32_t gap_len, int f_dup, int *ext_state) {
     RefCtx *c = (RefCtx *)h;
     std::vector<String<uint64_t> > CS(n), CE(n);
     if (threads < 1) threads = 1;
+    GapParms gp0 = harness_gap_parms(gap_len, f_dup);
+    if (ext_state && *ext_state) gp0.thd_cts_major_limit = 3;
+    uint32_t i0 = 0;
+    struct Scratch {
+        Anchors anchors; String<uint64_t> hit; String<UPair> gaps; String<Dna5> com, r; StringSet<FeaturesDynamic> f1; PMPParms pm; GlobalParms pg;
+        Scratch(RefCtx *c) : pm(c->pm), pg(c->pg) { resize(f1, 2); f1[0].init(2); f1[1].init(2); }
+    };
+    auto one = [&](Scratch &S, uint32_t i, GapParms &gp) {
+        uint64_t len = off[i + 1] - off[i];
+        if (len <= 200) return;                         // mapper.cpp:430,440
+        assign_padded(S.r, reads + off[i], len);
+        String<CordInfo> ci;
+        _compltRvseStr(S.r, S.com);
+        { uint64_t m = length(S.com); resize(S.com, m + PAD, Dna5(0)); resize(S.com, m); }
+        createFeatures(begin(S.r), end(S.r), S.f1[0]);
+        createFeatures(begin(S.com), end(S.com), S.f1[1]);
+        apxMap(*c->idx, S.r, S.anchors, S.hit, S.f1, c->f2, S.gaps, CS[i], CE[i], ci, 1, S.pg, S.pm);
+        if (gap_len) {
+            String<uint64_t> clips;
+            mapGaps(c->g, S.r, S.com, CS[i], CE[i], clips, S.gaps, S.f1, c->f2, gp);
+            CordsParms cp;
+            reformCords(CS[i], CE[i], &reformCordsDxDy1, cp);
+        }
+    };
+    if (ext_state && gap_len) {
+        Scratch S(c);
+        while (i0 < n && gp0.thd_cts_major_limit != 3) one(S, i0++, gp0);
+    }
 #pragma omp parallel num_threads(threads)
     {
-        Anchors anchors;
-        String<uint64_t> hit;
-        String<UPair> gaps;
-        String<Dna5> com, r;
-        StringSet<FeaturesDynamic> f1;
-        resize(f1, 2);
-        f1[0].init(2);
-        f1[1].init(2);
-        PMPParms pm = c->pm;
-        GlobalParms pg = c->pg;
+        Scratch S(c);
+        GapParms gp = gp0;
 #pragma omp for schedule(dynamic, 16)
-        for (uint32_t i = 0; i < n; i++) {
-            uint64_t len = off[i + 1] - off[i];
-            if (len <= 200) continue;                         // mapper.cpp:430,440
-            assign_padded(r, reads + off[i], len);
-            String<CordInfo> ci;
-            _compltRvseStr(r, com);
-            { uint64_t m = length(com); resize(com, m + PAD, Dna5(0)); resize(com, m); }
-            createFeatures(begin(r), end(r), f1[0]);
-            createFeatures(begin(com), end(com), f1[1]);
-            apxMap(*c->idx, r, anchors, hit, f1, c->f2, gaps, CS[i], CE[i], ci, 1, pg, pm);
-            if (gap_len) {
-                GapParms gp(0.2);
-                gp.f_dup = f_dup;
-                gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
-                gp.read_id = "read";
-                String<uint64_t> clips;
-                mapGaps(c->g, r, com, CS[i], CE[i], clips, gaps, f1, c->f2, gp);
-                CordsParms cp;
-                reformCords(CS[i], CE[i], &reformCordsDxDy1, cp);
-            }
-        }
+        for (uint32_t i = i0; i < n; i++) one(S, i, gp);
     }
+    if (ext_state) *ext_state = gp0.thd_cts_major_limit == 3;
     uint64_t tot = 0;
     cord_off[0] = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -327,6 +349,10 @@ uint64_t ref_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uin
         cord_off[i + 1] = tot;
     }
     return tot;
+}
+uint64_t ref_map_batch_g(void *h, const uint8_t *reads, const uint64_t *off, uint32_t n, int threads, uint64_t *cord_off,
+                         uint64_t *cords_str, uint64_t *cords_end, uint64_t cap, uint32_t gap_len, int f_dup) {
+    return ref_map_batch_g2(h, reads, off, n, threads, cord_off, cords_str, cords_end, cap, gap_len, f_dup, nullptr);
 }
 
 // The reference's reader: SeqAn readRecords on a SeqFileIn, the call of its fetcher (src/parallel_io.cpp:433-485), into

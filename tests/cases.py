@@ -76,6 +76,29 @@ def case_ccs_sv():
     return refs, reads, off
 
 
+def case_chim():
+    """Chimeric reads: 3 - 5 segments of 2.5 - 4 kb from unrelated places / strands / sequences glued together, 3 % errors -> 3 - 5 SAM
+    lines per read, each with an SA:Z listing the others (the reference's NM cache of createSAZTagCigarOneChimeric, flag 2048 chains).
+    CLI goldens only (CASES_CLI)."""
+    refs = [synth.random_ref(900_000, 8101), synth.repeat_ref(600_000, 8102), synth.random_ref(120_000, 8103)]
+    rng = np.random.default_rng(8104)
+    cpl = np.array([3, 2, 1, 0, 4], np.uint8)
+    out = []
+    for k in range(36):
+        segs = []
+        for _ in range(int(rng.integers(3, 6)) if k % 6 else 1):
+            ref = refs[int(rng.integers(0, 3))]
+            m = int(rng.integers(2500, 4000))
+            x0 = int(rng.integers(100, ref.size - m - 100))
+            sg = ref[x0:x0 + m]
+            segs.append(cpl[sg[::-1]] if rng.random() < 0.5 else sg)
+        seg = np.concatenate(segs)
+        r, o_, _ = synth.sample_reads([seg], 1, seg.size - 40, 0.03, 8200 + k, "random")
+        out.append(np.ascontiguousarray(r[: int(o_[1])]))
+    reads, off = synth.pack_reads(out)
+    return refs, reads, off
+
+
 def case_scale():
     """Scale pin: 24 sequences, the first 262.5 Mb (longer than chr1: x + 2^20 beyond 2^28, 8 800 binning
     bins, 37 M index entries), ids up to 23, reads from both ends of the big sequence, chimeras big-end + sequence 23."""
@@ -106,7 +129,12 @@ CASES_I2 = {
 }
 
 # gap-path goldens (-g 50 and -g 50 -dup 1, made by the reference): name -> (builder, T); files <name>_g50_T<T>.npz
-CASES_G50 = {"ont": (case_ont, 1), "edge": (case_edge, 1), "ccs_sv": (case_ccs_sv, 1)}
+CASES_G50 = {"ont": (case_ont, 1), "edge": (case_edge, 1), "ccs_sv": (case_ccs_sv, 1), "rep": (case_rep, 1), "chim": (case_chim, 1)}
+
+# goldens made by the REAL `linear filter` program (oracle/_ref/linear, tools/make_cli_golden.py): name -> builder; files cli_<name>.npz hold
+# the program's .sam and .apf bytes at -t 1 for -g 0, -g 50 and -g 50 -dup 1
+CASES_CLI = {"edge": case_edge, "ccs_sv": case_ccs_sv, "rep": case_rep, "chim": case_chim}
+CLI_MODES = {"g0": ["-g", "0"], "g50": ["-g", "50"], "g50dup1": ["-g", "50", "-dup", "1"], "gdef": []}
 
 CASES = {
     # name: (builder, [T layouts])
@@ -142,3 +170,22 @@ def text_ids(n_reads: int, n_refs: int):
 
 
 CMD_LINE = "linear filter reads.fa ref.fa -g 0"
+
+
+def write_fasta_case(dirpath, refs, reads, off, width=80):
+    """The case as the files a user would hand to `linear filter`: ref.fa (ids chr1.. + a description the reference cuts off) and reads.fa
+    (ids with blanks, kept whole).  Returns (reads path, genome path, read ids, genome ids)."""
+    import os
+    n = off.size - 1
+    rid, gid = text_ids(n, len(refs))
+    abc = np.frombuffer(b"ACGTN", np.uint8)
+    gp, rp = os.path.join(str(dirpath), "ref.fa"), os.path.join(str(dirpath), "reads.fa")
+    with open(gp, "wb") as f:
+        for k, r in enumerate(refs):
+            f.write(b">" + gid[k].encode() + b" some description\n")
+            t = abc[r].tobytes()
+            f.write(b"\n".join(t[i:i + width] for i in range(0, len(t), width)) + b"\n")
+    with open(rp, "wb") as f:
+        for i in range(n):
+            f.write(b">" + rid[i].encode() + b"\n" + abc[reads[int(off[i]):int(off[i + 1])]].tobytes() + b"\n")
+    return rp, gp, rid, gid

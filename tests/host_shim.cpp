@@ -331,7 +331,8 @@ u64 hs_gap_map(void *h, const u8 *read, u64 len, int which, u64 gs1, u64 ge1, u6
     Shim &S = *(Shim *)h;
     GapRead H(S, read, len);
     GapParms &gp = H.X.gp;
-    if (alt) { gp.chn1_min_len = 1; gp.chn1_abort = 0; gp.chn1_fn = 2; gp.chn2_abort = 0; gp.chn2_fn = 3; }
+    if (alt & 1) { gp.chn1_min_len = 1; gp.chn1_abort = 0; gp.chn1_fn = 2; gp.chn2_abort = 0; gp.chn2_fn = 3; }
+    if (alt & 2) gp.thd_cts_major_limit = 3;          // the stream state "extended" (oracle/lnr_oracle.cpp orc_map_read_g2)
     gp.read_len = len; gp.ref_len = S.lens[cord_id(gs1)];
     GSeq ref = H.X.ref(cord_id(gs1));
     GVec<u64> ts1, te1, ts2, te2; ts1.init(&H.keep, 64); te1.init(&H.keep, 64); ts2.init(&H.keep, 64); te2.init(&H.keep, 64);
@@ -346,11 +347,13 @@ u64 hs_gap_map(void *h, const u8 *read, u64 len, int which, u64 gs1, u64 ge1, u6
     return n1 | ((u64)te1.n << 32);
 }
 // apxMap + mapGaps + reformCords (Mapper::p_calRecords with -g gap_len [-dup], mapper.cpp:207-231,438-453); cords through hs_get_cords
-static i64 map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup, u64 arena_bytes, u64 keep_bytes, u64 work_cap);
+static i64 map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup, u64 arena_bytes, u64 keep_bytes, u64 work_cap, int *ext_state = nullptr);
 i64 hs_map_read_g(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup) { return map_read_g_lim(h, read, len, gap_len, f_dup, (u64)256 << 20, (u64)64 << 20, ~0ULL); }
+// *ext_state in / out: the stream state of the reference's per-thread GapParms (0 nothing extended yet, 1 extended: thd_cts_major_limit 3)
+i64 hs_map_read_g2(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup, int *ext_state) { return map_read_g_lim(h, read, len, gap_len, f_dup, (u64)256 << 20, (u64)64 << 20, ~0ULL, ext_state); }
 // the same with the arena sizes and the work budget of a k_gap worker: -11 = out of arena, -12 = over the work budget (the cords of apxMap stay)
 i64 hs_map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup, u64 arena_bytes, u64 keep_bytes, u64 work_cap) { return map_read_g_lim(h, read, len, gap_len, f_dup, arena_bytes, keep_bytes, work_cap); }
-static i64 map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup, u64 arena_bytes, u64 keep_bytes, u64 work_cap) {
+static i64 map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_dup, u64 arena_bytes, u64 keep_bytes, u64 work_cap, int *ext_state) {
     Shim &S = *(Shim *)h;
     int rc = map_read(S, read, len, false);
     if (rc) return rc;
@@ -359,6 +362,7 @@ static i64 map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_d
     H.X.work_cap = work_cap;
     H.X.gp.f_dup = f_dup;
     H.X.gp.thd_gap_len_min = gap_len == 1 ? 50 : (gap_len < 10 ? 10 : gap_len);
+    if (ext_state && *ext_state) H.X.gp.thd_cts_major_limit = 3;
     GVec<u64> cs, ce; cs.init(&H.keep, (u32)S.cs.size() * 2 + 64); ce.init(&H.keep, (u32)S.cs.size() * 2 + 64);
     for (u64 v : S.cs) cs.push(v);
     for (u64 v : S.ce) ce.push(v);
@@ -366,6 +370,7 @@ static i64 map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_d
     gap_reform_cords(cs, ce);
     if (H.ar.ovf == 2) return -12;
     if (gr || H.ar.ovf || H.keep.ovf || cs.n != ce.n) return -11;
+    if (ext_state) *ext_state = H.X.gp.thd_cts_major_limit == 3;
     S.stats[0] = H.ar.hw; S.stats[1] = H.keep.hw;   // (arena high-water marks, read back through hs_get_stats)
     S.cs.assign(cs.p, cs.p + cs.n);
     S.ce.assign(ce.p, ce.p + ce.n);

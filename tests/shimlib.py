@@ -101,12 +101,15 @@ class Shim:
         self.lib.hs_get_cords(self.h, _p(cs, _u64p), _p(ce, _u64p))
         return cs[:n], ce[:n]
 
-    def map_read_gap(self, read, gap_len=50, dup=0):
-        """apxMap + the product's gap path (lnr_gap_hd.h: mapGaps + reformCords) on the host"""
+    def map_read_gap(self, read, gap_len=50, dup=0, ext=0):
+        """apxMap + the product's gap path (lnr_gap_hd.h: mapGaps + reformCords) on the host.  `ext`: the stream state the read starts
+        from (oracle/pyorc.py map_read_gap); the state it leaves is kept in self.ext_out."""
         read = np.ascontiguousarray(read, dtype=np.uint8)
-        self.lib.hs_map_read_g.restype = C.c_int64
-        self.lib.hs_map_read_g.argtypes = [C.c_void_p, _u8p, C.c_uint64, C.c_uint32, C.c_int]
-        n = self.lib.hs_map_read_g(self.h, _p(read, _u8p), read.size, gap_len, dup)
+        self.lib.hs_map_read_g2.restype = C.c_int64
+        self.lib.hs_map_read_g2.argtypes = [C.c_void_p, _u8p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
+        st = C.c_int(ext)
+        n = self.lib.hs_map_read_g2(self.h, _p(read, _u8p), read.size, gap_len, dup, C.byref(st))
+        self.ext_out = st.value
         assert n >= 0, f"shim error {n}"
         cs = np.zeros(max(int(n), 1), np.uint64)
         ce = np.zeros(max(int(n), 1), np.uint64)

@@ -198,9 +198,10 @@ def test_product_gap_map_units_match_oracle():
     co.close()
 
 
-@pytest.mark.parametrize("name", ["ont", "edge", "ccs_sv"])
+@pytest.mark.parametrize("name", ["ont", "edge", "ccs_sv", "rep", "chim"])
 def test_product_gap_path_matches_reference_golden(case_inputs, name):
-    """apxMap + mapGaps + reformCords of the product's host build against cords the real reference produced with -g 50 [-dup 1]"""
+    """apxMap + mapGaps + reformCords of the product's host build against cords the real reference produced with -g 50 [-dup 1] on the case
+    as one read stream in file order (`-t 1`): the stream state (thd_cts_major_limit 1 -> 3 at the first extension) is carried read to read"""
     from tests import cases
     refs, reads, off = case_inputs(name)
     g = np.load(os.path.join(HERE, "golden", f"{name}_g50_T1.npz"))
@@ -208,8 +209,10 @@ def test_product_gap_path_matches_reference_golden(case_inputs, name):
     sh = shimlib.Shim(refs, 1)
     for dup in (0, 1):
         co = g[f"cord_off_dup{dup}"]
+        ext = 0
         for i in range(off.size - 1):
-            cs, ce = sh.map_read_gap(reads[int(off[i]):int(off[i + 1])], 50, dup)
+            cs, ce = sh.map_read_gap(reads[int(off[i]):int(off[i + 1])], 50, dup, ext)
+            ext = sh.ext_out
             assert np.array_equal(cs, g[f"cords_str_dup{dup}"][int(co[i]):int(co[i + 1])]), f"dup {dup} read {i}"
             assert np.array_equal(ce, g[f"cords_end_dup{dup}"][int(co[i]):int(co[i + 1])]), f"dup {dup} read {i}"
 
@@ -224,8 +227,9 @@ def test_product_gap_path_matches_oracle_on_planted_svs():
         sh = shimlib.Shim(refs, T)
         for i, rd in enumerate(reads_l):
             for gap_len, dup in ((50, 0), (50, 1), (1, 0), (5, 1), (200, 0)):
-                a, b = o.map_read_gap(rd, gap_len, dup), sh.map_read_gap(rd, gap_len, dup)
-                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (T, i, gap_len, dup)
+                for ext in (0, 1):
+                    a, b = o.map_read_gap(rd, gap_len, dup, ext), sh.map_read_gap(rd, gap_len, dup, ext)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and o.ext_out == sh.ext_out, (T, i, gap_len, dup, ext)
         o.close()
 
 

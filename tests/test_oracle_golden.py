@@ -113,18 +113,26 @@ def test_oracle_hindex_matches_live_reference(oracle_lib):
 
 
 # ---- gap path (-g 50 [-dup 1]): the oracle's restatement (oracle/lnr_gap.inc) against the reference's goldens
-@pytest.mark.parametrize("name", ["ont", "edge", "ccs_sv"])
+@pytest.mark.parametrize("name", ["ont", "edge", "ccs_sv", "rep", "chim"])
 def test_oracle_gap_path_matches_reference_golden(oracle_lib, case_inputs, name):
+    """the case as ONE read stream in file order (`linear filter -t 1`): the reference keeps one GapParms per thread for the run and the first
+    mapExtend / mapExtends leaves thd_cts_major_limit = 3 behind for every later read (read by read here; the batch entry point -- serial until
+    the state flips, parallel behind -- must give the same)"""
     refs, reads, off = case_inputs(name)
     g = np.load(os.path.join(GOLD, f"{name}_g50_T1.npz"))
     assert cases.input_digest(refs, reads, off) == str(g["digest"])
     o = oracle_lib.Checker("oracle", refs, 1)
     for dup in (0, 1):
         co = g[f"cord_off_dup{dup}"]
+        ext = 0
         for i in range(off.size - 1):
-            cs, ce = o.map_read_gap(reads[int(off[i]):int(off[i + 1])], 50, dup)
+            cs, ce = o.map_read_gap(reads[int(off[i]):int(off[i + 1])], 50, dup, ext)
+            ext = o.ext_out
             assert np.array_equal(cs, g[f"cords_str_dup{dup}"][int(co[i]):int(co[i + 1])]), f"dup {dup} read {i}"
             assert np.array_equal(ce, g[f"cords_end_dup{dup}"][int(co[i]):int(co[i + 1])]), f"dup {dup} read {i}"
+        assert ext == int(g[f"ext_out_dup{dup}"])
+        coff, cs, ce, _ = o.map_batch(reads, off, threads=4, gap_len=50, dup=dup)
+        assert np.array_equal(coff, co) and np.array_equal(cs, g[f"cords_str_dup{dup}"]) and np.array_equal(ce, g[f"cords_end_dup{dup}"]) and o.ext_out == ext
     o.close()
 
 
@@ -155,5 +163,6 @@ def test_oracle_gap_path_matches_live_reference(oracle_lib):
         r = oracle_lib.Checker("ref", refs, T)
         for i, rd in enumerate(reads_l):
             for gap_len, dup in ((50, 0), (50, 1), (1, 0), (5, 1), (200, 0)):
-                a, b = o.map_read_gap(rd, gap_len, dup), r.map_read_gap(rd, gap_len, dup)
-                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (T, i, gap_len, dup)
+                for ext in (0, 1):
+                    a, b = o.map_read_gap(rd, gap_len, dup, ext), r.map_read_gap(rd, gap_len, dup, ext)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and o.ext_out == r.ext_out, (T, i, gap_len, dup, ext)

@@ -45,7 +45,7 @@ def main():
                 d[name + ":bases"], d[name + ":off"], d[name + ":ids"] = b, o, np.array(ids)
             np.savez_compressed(os.path.join(outdir, "reader.npz"), **d)
             print("reader.npz:", {k: int(v.size) for k, v in d.items() if k.endswith(":off")})
-    # gap path (-g 50 [-dup 1]): the reference's cords after mapGaps + reformCords
+    # gap path (-g 50 [-dup 1]): the reference's cords after mapGaps + reformCords, the case taken as one read stream (-t 1)
     for name, (builder, T) in cases.CASES_G50.items():
         if only and "g50" not in only and (name + "_g50") not in only:
             continue
@@ -54,13 +54,11 @@ def main():
         r = pyorc.Checker("ref", refs, T)
         d = {"digest": cases.input_digest(refs, reads, off), "T": T, "n_reads": n}
         for dup in (0, 1):
-            coff = np.zeros(n + 1, np.uint64)
-            cs_l, ce_l = [], []
-            for i in range(n):
-                cs, ce = r.map_read_gap(reads[int(off[i]):int(off[i + 1])], 50, dup)
-                cs_l.append(cs); ce_l.append(ce)
-                coff[i + 1] = coff[i] + cs.size
-            d[f"cord_off_dup{dup}"], d[f"cords_str_dup{dup}"], d[f"cords_end_dup{dup}"] = coff, np.concatenate(cs_l), np.concatenate(ce_l)
+            # the whole case as ONE read stream in file order through one GapParms (`linear filter -t 1`: mapper.cpp:233-237,447 keeps one
+            # per thread for the run and mapExtend / mapExtends leave thd_cts_major_limit = 3 behind; DESIGN 5c "stream state")
+            coff, cs, ce, _ = r.map_batch(reads, off, threads=1, gap_len=50, dup=dup, ext=0)
+            d[f"cord_off_dup{dup}"], d[f"cords_str_dup{dup}"], d[f"cords_end_dup{dup}"] = coff, cs, ce
+            d[f"ext_out_dup{dup}"] = r.ext_out
         path = os.path.join(outdir, f"{name}_g50_T{T}.npz")
         np.savez_compressed(path, **d)
         print(f"{path}: reads {n} cords {int(d['cord_off_dup0'][-1])} / {int(d['cord_off_dup1'][-1])} size {os.path.getsize(path) / 1024:.0f} kB")
