@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["grch38", "chr22", "small"], default="grch38")
+    ap.add_argument("--workload", choices=["grch38", "chr22", "small", "ccs_sv"], default="grch38",
+                    help="grch38 = configs[2] (default); chr22 = configs[1]; ccs_sv = configs[4] at one GPU: 15 kb CCS-profile reads (0.5 %% errors) with a planted SV in 5 %% of them vs the GRCh38 stand-in, -g 50 -dup 1")
     ap.add_argument("--scale", type=float, default=1.0, help="grch38 only: scale of the chromosome lengths")
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=10_000)
@@ -129,6 +130,13 @@ def main():
     args = ap.parse_args()
     if args.small:
         args.workload = "small"
+    explicit = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+    if args.workload == "ccs_sv":                      # BASELINE configs[4]: the flags and the read profile it names (unless given on the command line)
+        if "--read-len" not in explicit: args.read_len = 15_000
+        if "--err" not in explicit: args.err = 0.005
+        if "--gap" not in explicit: args.gap = 50
+        if "--dup" not in explicit: args.dup = 1
+        if "--reads" not in explicit: args.reads = 66_000
     if args.workload == "small":
         args.reads = min(args.reads, 2000)
 
@@ -190,7 +198,7 @@ def main():
     flt = Filter(device=local_rank, gap_len=args.gap, dup=args.dup)
     index_s, bcast, t_ref, ref_name, info = 0.0, None, 0.0, "", None
     host_genome = None     # [numpy per sequence] for the CPU baseline (rank 0, N = 1)
-    if args.workload == "grch38":
+    if args.workload in ("grch38", "ccs_sv"):
         ref_name = (f"GRCh38 stand-in synth_torch.grch38_like_cuda(seed 38, scale {args.scale:g}): 24 sequences with the human chromosome lengths, "
                     "N runs (telomeres, centromeres, acrocentric arms), 1500 repeat families over ~45 %, tandem repeats, segmental duplications")
     elif args.workload == "chr22":
@@ -204,7 +212,7 @@ def main():
             t_ref = time.time() - t0
             t0 = time.time()
             info = flt.build_index(seqs, T)
-        elif args.workload == "grch38":
+        elif args.workload in ("grch38", "ccs_sv"):
             gen, offs = grch38_like_cuda(dev, seed=38, scale=args.scale)
             sync()
             t_ref = time.time() - t0
@@ -236,6 +244,7 @@ def main():
     nb = max(1, min(args.steps + args.warmup, 16))
     seq_len = [int(v) for v in flt.seq_len()]
     t0 = time.time()
+    sv_note = ""
     if double:
         batches = [sample_reads(args.reads, 1000 * rank + b) for b in range(nb)]
     else:
@@ -243,8 +252,20 @@ def main():
         gp, gb = flt.index_blobs()[0]
         gview = ldist.blob_tensor(gp, gb, dev)
         non_n = [starts[0] + 10_510_000] + starts[1:] if args.workload == "chr22" else starts
-        batches = [sample_reads_multi_cuda(gview, non_n, args.reads, args.read_len, args.err, 777 + 1000 * rank + b,
-                                           ends=[s + L for s, L in zip(starts, seq_len)]) for b in range(nb)]
+        ends = [s + L for s, L in zip(starts, seq_len)]
+        if args.workload == "ccs_sv":
+            from linear_amd.synth_torch import plant_svs_cuda
+            batches, n_sv = [], 0
+            for b in range(nb):
+                src_len = args.read_len + 5200
+                r0, _ = sample_reads_multi_cuda(gview, non_n, args.reads, src_len, args.err, 777 + 1000 * rank + b, ends=ends)
+                r1, o1, k = plant_svs_cuda(r0, args.reads, src_len, args.read_len, 0.05, 4242 + 1000 * rank + b)
+                batches.append((r1, o1)); n_sv += k
+                del r0
+            sv_note = f", one planted SV (deletion / insertion / tandem duplication / inversion, 50 bp - 5 kb) in {n_sv / (nb * args.reads):.1%} of the reads"
+        else:
+            batches = [sample_reads_multi_cuda(gview, non_n, args.reads, args.read_len, args.err, 777 + 1000 * rank + b, ends=ends) for b in range(nb)]
+            sv_note = ""
         sync()
     log(f"[bench] rank {rank}: {nb} distinct batches of {args.reads} reads x {args.read_len} bp generated on device in {time.time() - t0:.1f}s")
 
@@ -255,26 +276,56 @@ def main():
         else:
             flt.filter_batch_dev(r.data_ptr(), o.data_ptr(), args.reads)
 
-    for k in range(args.warmup):
-        step(k)
-    sync()
-    if use_dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    acc = {}
-    for k in range(args.steps):
-        step(args.warmup + k)
-        st = flt.stats()
-        for key, v in st.items():
-            acc[key] = acc.get(key, 0) + v
-    sync()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(fn_step, pre=None, post=None):
+        """W untimed + exactly K timed steps between barrier + synchronize on both sides; the MAX over the ranks"""
+        for k in range(args.warmup):
+            fn_step(k)
+        if pre:
+            pre()
+        sync()
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        acc_ = {}
+        for k in range(args.steps):
+            fn_step(args.warmup + k)
+            for key, v in flt.stats().items():
+                acc_[key] = acc_.get(key, 0) + v
+        sync()
+        if use_dist:
+            dist.barrier()
+        dt_ = time.perf_counter() - t0
+        if post:
+            post()
+        if use_dist:
+            t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, acc_
+
+    # (1) the batch resident in HBM (config.device_resident_reads_per_s; the roofline's seed launches are timed here)
+    dt_dev, acc = timed(step)
+    # (2) THE METRIC (SURVEY 8d: first read batch submitted -> last cords batch returned): host read blocks in, host cords out, through
+    # lnr_filter_submit / lnr_filter_wait with two batches in flight, in steady state -- when the clock starts the upload of the first timed
+    # batch is under way (it was submitted during the last warm-up step, as every later batch is submitted during its predecessor's step);
+    # inside the clock: K submits (uploads), K computes, K result downloads.  The batch submitted by the last timed step is drained after.
+    host_path = not args.seed_only
+    dt = dt_dev
+    if host_path:
+        nhb = min(4 if world > 1 else 8, nb)
+        hb = []
+        for k in range(nhb):
+            buf = flt.host_alloc(int(batches[k][0].numel()))
+            buf[:] = batches[k][0].cpu().numpy()
+            hb.append((buf, batches[k][1].cpu().numpy().astype(np.uint64)))
+        flt.filter_submit(*hb[0])
+
+        def host_step(k):
+            flt.filter_submit(*hb[(k + 1) % nhb])
+            flt.filter_wait(copy=False)
+        dt, acc_h = timed(host_step, post=lambda: flt.filter_wait(copy=False))
+    if args.gap:
+        flt.gap_stream(1)                 # (whatever the drained batch left: the timed batches above all ran in the extended state)
 
     K = max(args.steps, 1)
     total_reads = args.reads * K
@@ -290,11 +341,12 @@ def main():
         wl_key["gap"] = args.gap
     dup_flag = " -dup 1" if args.dup else ""
     traffic = recorded_traffic(wl_key, launches / K)
-    dev_rate = args.reads * world * args.steps / dt
+    dev_rate = args.reads * world * args.steps / dt_dev
+    rate = args.reads * world * args.steps / dt
 
     out = {
         "metric": "reads/sec (whole node) + HBM GB/s on seed lookup, 10 kb reads vs GRCh38",
-        "value": dev_rate,
+        "value": rate,
         "unit": "reads/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -306,9 +358,12 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.reads} synthetic {args.read_len} bp ONT-profile reads per GPU per step, a different batch every step ({args.err:.0%} errors 40/30/30 sub/del/ins, "
-                        f"50% revcomp) vs {ref_name}; linear filter -f 2 -i 1 -g {args.gap}{dup_flag} -p 1, index layout -t {T}" + ("; SEED LOOKUP STAGE ONLY" if args.seed_only else ""),
-            "baseline_config": {"grch38": "configs[2] (10 kb ONT reads vs full GRCh38; 1 M reads = 10 steps of 100 k)", "chr22": "configs[1]", "small": "plumbing"}[args.workload],
+            "workload": f"{args.reads} synthetic {args.read_len} bp {'PacBio-CCS' if args.err < 0.02 else 'ONT'}-profile reads per GPU per step, a different batch every step ({args.err:.1%} errors 40/30/30 sub/del/ins, "
+                        f"50% revcomp{sv_note}) vs {ref_name}; linear filter -f 2 -i 1 -g {args.gap}{dup_flag} -p 1, index layout -t {T}" + ("; SEED LOOKUP STAGE ONLY" if args.seed_only else ""),
+            "baseline_config": {"grch38": "configs[2] (10 kb ONT reads vs full GRCh38; 1 M reads = 10 steps of 100 k)", "chr22": "configs[1]", "small": "plumbing",
+                                "ccs_sv": "configs[4] at ONE GPU (15 kb CCS-profile reads with planted SVs vs GRCh38, -g 50 -dup 1; 66 k reads per step)"}[args.workload],
+            "value_is": ("host read blocks in -> host cords out (lnr_filter_submit / lnr_filter_wait, pinned blocks, 2 batches in flight, steady state; reads H2D + cords D2H inside the clock)"
+                         if host_path else "seed stage only, batch resident in HBM"),
             "reads_per_gpu_per_step": args.reads,
             "distinct_batches": nb,
             "read_len": args.read_len,
@@ -327,7 +382,7 @@ def main():
                                   "job": acc["job_ms"] / K, "tail": acc["tail_ms"] / K, "gap": acc.get("gap_ms", 0.0) / K, "total_device": acc["total_ms"] / K},
             "device_resident_reads_per_s": dev_rate,
             "gap_second_pass_per_step": acc.get("gap_second_pass", 0) / K,
-            "gap_path_note": "this line is -g " + str(args.gap) + "; the reference's default mode -g 50 is measured by `python bench.py --gap 50` (profiles/r02/bench_gap50.json, DESIGN.md 5c)",
+            "gap_path_note": "this line is -g " + str(args.gap) + "; the reference's default mode (-g 1 = gaps of 50 and more re-mapped) is measured in this same run: config.gap50_*",
         },
         "roofline": {
             "bound": "hbm",
@@ -344,28 +399,32 @@ def main():
         },
     }
 
-    parity_ok = True
-    if rank == 0 and world == 1 and not double and not args.seed_only:
-        # ---- the drop-in entry point as the caller sees it: host reads in -> host cords out (PCIe both ways); never `value`.
-        # Read blocks sit in pinned memory from lnr_host_alloc (where a front-end's reader would decode them), two batches are in
-        # flight: the upload of batch k + 1 runs under the kernels of batch k (lnr_filter_submit / lnr_filter_wait).
-        nhb = min(8, nb)
-        hb = []
-        for k in range(nhb):
-            buf = flt.host_alloc(int(batches[k][0].numel()))
-            buf[:] = batches[k][0].cpu().numpy()
-            hb.append((buf, batches[k][1].cpu().numpy().astype(np.uint64)))
-        flt.filter_batch(*hb[0])
+    # ---- the reference's DEFAULT mode in the same line: -g 1 (gaps of 50 and more re-mapped, mapper.cpp:207-231), same batches, same context
+    gap50 = None
+    if args.gap == 0 and not args.seed_only and not double and world == 1 and rank == 0 and args.workload in ("grch38", "chr22"):
+        flt.set_gap(1, 0)
+        step(0)                                   # (also takes the stream through its first extension: the timed steps run in the steady state)
+        sync()
+        gk = min(3, args.steps)
         t0 = time.perf_counter()
-        flt.filter_submit(*hb[0])
-        for k in range(nhb):
-            if k + 1 < nhb:
-                flt.filter_submit(*hb[k + 1])
-            flt.filter_wait(copy=False)
-        host_rate = args.reads * nhb / (time.perf_counter() - t0)
-        out["config"]["host_path_reads_per_s"] = host_rate
-        out["config"]["host_path"] = "lnr_filter_submit / lnr_filter_wait, pinned read blocks, 2 batches in flight; reads H2D + cords D2H included"
-        log(f"[bench] host entry point (pinned reads in, cords out, PCIe both ways, upload overlapped): {host_rate:.0f} reads/s = {host_rate / dev_rate:.0%} of the device-resident rate")
+        gacc = {}
+        for k in range(gk):
+            step(1 + k)
+            for key, v in flt.stats().items():
+                gacc[key] = gacc.get(key, 0) + v
+        sync()
+        gdt = time.perf_counter() - t0
+        gap50 = {"reads_per_s": args.reads * gk / gdt, "ms_per_step": gdt / gk * 1e3, "steps": gk, "gap_stage_ms_per_step": gacc.get("gap_ms", 0.0) / gk,
+                 "second_pass_reads_per_step": gacc.get("gap_second_pass", 0) / gk, "mode": "batch resident in HBM, linear filter -g 1 (= 50)"}
+        out["config"]["gap50_reads_per_s"] = gap50["reads_per_s"]
+        out["config"]["gap50"] = gap50
+        log(f"[bench] -g 50 (the reference's default mode): {gap50['reads_per_s']:.0f} reads/s, {gap50['ms_per_step']:.1f} ms per step (gap stage {gap50['gap_stage_ms_per_step']:.1f} ms)")
+        flt.set_gap(0, 0)
+
+    parity_ok = True
+    out["config"]["host_path_reads_per_s"] = rate if host_path else None
+    if rank == 0:
+        log(f"[bench] device-resident {dev_rate:.0f} reads/s; host entry point (pinned reads in, cords out, PCIe both ways, two batches in flight) {rate:.0f} reads/s = {rate / dev_rate:.0%}")
 
     if rank == 0 and world == 1 and not double and not args.no_cpu_baseline and not args.seed_only and host_genome is not None:
         # ---- CPU baseline + parity on a bounded sample of batch 0
@@ -400,6 +459,26 @@ def main():
                                          f"its index + genome features build ({t_cidx:.1f} s, -t {T}) not included"}
         out["parity"] = {"checked_reads": ns, "bit_exact": parity_ok, "against": out["cpu_baseline"]["kind"]}
         log(f"[bench] cpu baseline ({kind}) {ns / t_cpu:.0f} reads/s on {cores} threads; GPU parity on the sample: {parity_ok}")
+        if gap50 is not None:
+            def cpu_run_g(n1):
+                rr2 = h_reads[: int(h_off[n1])]
+                oo2 = h_off[: n1 + 1] - h_off[0]
+                t0 = time.time()
+                res = chk.map_batch(rr2, oo2, threads=cores, gap_len=1, dup=0)
+                return time.time() - t0, res, rr2, oo2
+            tg, _, _, _ = cpu_run_g(pilot)
+            ng = int(min(args.reads, max(pilot, pilot * 0.6 * args.cpu_seconds / max(tg, 1e-3))))
+            t_g, (goff, gcs, gce, _), rr2, oo2 = cpu_run_g(ng)
+            flt.set_gap(1, 0)                      # a new stream, as the CPU run took the sample
+            coff2, cs2, ce2 = flt.filter_batch(rr2, oo2)
+            flt.set_gap(0, 0)
+            gpar = bool(np.array_equal(coff2, goff) and np.array_equal(cs2, gcs) and np.array_equal(ce2, gce))
+            out["config"]["gap50"]["cpu_baseline"] = {"value": ng / t_g, "unit": "reads/s", "cores": cores, "kind": "reference" if kind == "ref" else "port",
+                                                      "sample": f"first {ng} reads of batch 0 with -g 1, {cores} OpenMP threads, {t_g:.2f} s wall"}
+            out["config"]["gap50"]["parity"] = {"checked_reads": ng, "bit_exact": gpar}
+            out["config"]["gap50"]["x_cpu"] = gap50["reads_per_s"] / (ng / t_g)
+            log(f"[bench] -g 50 cpu baseline ({kind}) {ng / t_g:.0f} reads/s on {cores} threads -> {gap50['reads_per_s'] / (ng / t_g):.1f} x; GPU parity on the sample: {gpar}")
+            parity_ok = parity_ok and gpar
         # secondary roofline: chaining-DP predecessor pairs per second next to the VALU integer peak.  Pair counts
         # come from the restatement's counter on a slice of the sample (the reference has no counter).
         if kind == "ref":

@@ -184,6 +184,8 @@ lnr_status lnr_last_stats(const lnr_ctx *ctx, lnr_stats *st);
  * front-end that deals the batches of one file over several contexts / GPUs sets on the others once the first context reports 1.
  * *state (optional) receives the state after the call. */
 lnr_status lnr_gap_stream(lnr_ctx *ctx, int set, int *state);
+/* Change -g / -dup of an existing context (the index does not depend on them); starts a new read stream. */
+lnr_status lnr_set_gap(lnr_ctx *ctx, uint32_t gap_len, uint32_t dup);
 
 /* Input side (host code; replaces, for this path, the fetcher's SeqAn readRecords of src/parallel_io.cpp:433-485): FASTA or
  * FASTQ records, plain or gzip, decoded into the layout lnr_filter_batch / lnr_filter_submit take.  Characters convert as SeqAn's

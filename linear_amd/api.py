@@ -58,7 +58,7 @@ EXPORTS = ["lnr_opts_default", "lnr_create", "lnr_destroy", "lnr_strerror", "lnr
            "lnr_index_export", "lnr_index_alloc", "lnr_index_blob", "lnr_index_adopt", "lnr_filter_batch", "lnr_filter_batch_dev",
            "lnr_cords_to_host", "lnr_seed_lookup_batch", "lnr_seed_lookup_batch_dev", "lnr_last_stats", "lnr_filter_submit", "lnr_filter_wait",
            "lnr_host_alloc", "lnr_host_free", "lnr_reader_open", "lnr_reader_next", "lnr_reader_ids", "lnr_reader_error", "lnr_reader_close",
-           "lnr_writer_create", "lnr_writer_format", "lnr_writer_sam_header", "lnr_writer_destroy", "lnr_last_gaps", "lnr_gap_stream"]
+           "lnr_writer_create", "lnr_writer_format", "lnr_writer_sam_header", "lnr_writer_destroy", "lnr_last_gaps", "lnr_gap_stream", "lnr_set_gap"]
 
 
 def load_library() -> C.CDLL:
@@ -85,6 +85,7 @@ def load_library() -> C.CDLL:
     lib.lnr_seed_lookup_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.lnr_last_stats.argtypes = [C.c_void_p, C.POINTER(LnrStats)]
     lib.lnr_gap_stream.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    lib.lnr_set_gap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.lnr_filter_submit.argtypes = [C.c_void_p, C.c_void_p, _u64p, C.c_uint32]
     lib.lnr_filter_wait.argtypes = [C.c_void_p, C.POINTER(LnrCords)]
     lib.lnr_host_alloc.restype = C.c_void_p
@@ -279,6 +280,10 @@ class Filter:
 
     def seed_lookup_batch_dev(self, d_reads_ptr: int, d_off_ptr: int, n: int):
         self._ck(self.lib.lnr_seed_lookup_batch_dev(self.h, C.c_void_p(d_reads_ptr), C.c_void_p(d_off_ptr), n))
+
+    def set_gap(self, gap_len: int, dup: int = 0) -> None:
+        """-g / -dup of this context from now on (lnr_set_gap); a new read stream starts."""
+        self._ck(self.lib.lnr_set_gap(self.h, gap_len, dup))
 
     def gap_stream(self, set_to: int = -1) -> int:
         """The read stream's state of the gap re-mapper (lnr_gap_stream): -1 query, 0 start a new stream, 1 mark it extended; returns the state."""

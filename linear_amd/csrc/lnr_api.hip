@@ -5,6 +5,7 @@
 // point fails (LNR_ERR_NO_DEVICE / LNR_ERR_HIP) when no GPU is usable.
 #include <hipcub/hipcub.hpp>
 #include "lnr_kernels.hip"
+#include "lnr_gap_args.h"
 #include "../../include/linear_amd.h"
 
 #include <algorithm>
@@ -1128,15 +1129,12 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
             G.work_cap = ctx->gap_work_cap;
             G.arena_bytes = arena1; G.next = ctx->gap_next.as<u32>(); G.big = 0; G.last = 0; G.coop = ctx->gap_mode;
             u32 v1 = std::min<u32>(w1, (u32)align_up(m, 64));
-            hipLaunchKernelGGL(k_gap, dim3(ctx->gap_mode ? v1 : v1 / 64), dim3(64), 0, ctx->stream, G);
+            if ((e = launch_gap(G, 0, ctx->gap_mode ? v1 : v1 / 64, ctx->stream)) != hipSuccess) return e;
             G.work_cap = ~0ULL;
             G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1; G.coop = 1;
-            if (ctx->gap_team) hipLaunchKernelGGL(k_gap_team, dim3(std::min(w2, m)), dim3(64 * K_GAP_TEAM), 0, ctx->stream, G);
-            else hipLaunchKernelGGL(k_gap, dim3(std::min(w2, m)), dim3(64), 0, ctx->stream, G);
+            if ((e = launch_gap(G, ctx->gap_team, std::min(w2, m), ctx->stream)) != hipSuccess) return e;
             G.arena_bytes = arena3; G.next = ctx->gap_next.as<u32>() + 24; G.last = 1;
-            if (ctx->gap_team) hipLaunchKernelGGL(k_gap_team, dim3(std::min(w3, m)), dim3(64 * K_GAP_TEAM), 0, ctx->stream, G);
-            else hipLaunchKernelGGL(k_gap, dim3(std::min(w3, m)), dim3(64), 0, ctx->stream, G);
-            return hipGetLastError();
+            return launch_gap(G, ctx->gap_team, std::min(w3, m), ctx->stream);
         };
         // The stream state (GapArgs): once a read of the stream has extended, every later read starts "extended" -- one ladder over the batch.
         // Until then the batch is taken in growing chunks: a probe ladder finds the chunk's first extending read r* (all reads started "not
@@ -1333,15 +1331,15 @@ lnr_status submit_reads(lnr_ctx *ctx, int slot, const u8 *reads, const u64 *off,
                 if (!ctx->h_up[k].ensure(CH)) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
                 if (!ctx->ev_up[k]) HIPCK(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
             }
+            // (the staging buffers and their events belong to the context: a second submit right behind the first -- two batches in flight --
+            //  must wait for the first one's DMA out of a buffer as well.  An event that was never recorded reads as complete.)
             int k = 0;
-            bool used[2] = {false, false};
             for (u64 o2 = 0; o2 < total; o2 += CH, k ^= 1) {
                 u64 len = std::min<u64>(CH, total - o2);
-                if (used[k]) HIPCK(hipEventSynchronize(ctx->ev_up[k]));   // the DMA out of this staging buffer has finished
+                HIPCK(hipEventSynchronize(ctx->ev_up[k]));                // the last DMA out of this staging buffer has finished
                 par_memcpy(ctx->h_up[k].p, reads + base + o2, len);
                 HIPCK(hipMemcpyAsync(dr.as<u8>() + o2, ctx->h_up[k].p, len, hipMemcpyHostToDevice, sc));
                 HIPCK(hipEventRecord(ctx->ev_up[k], sc));
-                used[k] = true;
             }
         }
     }
@@ -1812,6 +1810,12 @@ lnr_status lnr_gap_stream(lnr_ctx *ctx, int set, int *state) {
     if (!ctx || set > 1) return LNR_ERR_ARG;
     if (set >= 0) ctx->gap_ext = set;
     if (state) *state = ctx->gap_ext;
+    return LNR_OK;
+}
+
+lnr_status lnr_set_gap(lnr_ctx *ctx, uint32_t gap_len, uint32_t dup) {
+    if (!ctx || dup > 1) return LNR_ERR_ARG;
+    ctx->opts.gap_len = gap_len; ctx->opts.dup = dup; ctx->gap_ext = 0;
     return LNR_OK;
 }
 

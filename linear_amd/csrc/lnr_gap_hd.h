@@ -7,6 +7,9 @@
 // by function against the oracle (tests/test_gap_shim_cpu.py).  Every function cites the reference lines it follows.  DESIGN.md 5c.
 #pragma once
 #include "lnr_hd.h"
+#if defined(__HIPCC__)
+#include "lnr_wave.h"
+#endif
 
 namespace lnr {
 
@@ -151,13 +154,49 @@ LNR_HD inline u64 gshape_init(GShape &me, const u8 *it) {
     for (u32 i = 0; i < me.span - 1; ++i) { u64 v = it[k + i]; me.x += ((int)v << 1) - 3; me.h = (me.h << 2) + v; me.crh += (3ULL - v) << bit; bit += 2; }
     return k;
 }
-LNR_HD inline void g_kmer_stream(const GSeq &seq, GVec<u64> &g_hs, u64 str, u64 end, int shape_len, int step, u64 type) {   // g_mapHs_kmer_ gap_util.cpp:632-662
+// Closed form of the rolling state (device, wave-per-read form: one lane per pushed k-mer).  With v = the bases of the window at k
+// (values 0..4, N = 4), s = span:   hValue  = ((sum_{i>=1} v[k+s-1-i] 4^i) mod 4^s) + v[k+s-1]      (the newest base is added after the mask: an N carries)
+//                                    crhValue = sum_i ((3 - v[k+i]) & 3) << 2i, all ones above bit 2s when the newest base is N ((3 - 4) << (2s - 2))
+//                                    x        = C + 2 * sum(v), C = x_init - 2 * sum(v[str .. str+s-2])  (= -3s when hashInit skipped nothing)
+// -- the recurrences of hashNextV (shape_extend.cpp:231-243) unrolled; valid from the first iteration on when hashInit found its N-free window
+// at the stream's first base (skip 0: the init digits ARE the window's older digits); a stream that starts inside an N run keeps the serial loop.
+LNR_HD inline u64 kmer_h_closed(const u8 *w, u32 span) {
+    u64 S = 0;
+    for (u32 i = 0; i < span; i++) S = S * 4 + w[i];
+    u64 nw = w[span - 1];
+    return ((S - nw) & ((1ULL << (2 * span)) - 1)) + nw;
+}
+LNR_HD inline void g_kmer_stream(const GSeq &seq, GVec<u64> &g_hs, u64 str, u64 end, int shape_len, int step, u64 type, int coop = 0) {   // g_mapHs_kmer_ gap_util.cpp:632-662
     if (seq.len < (u64)shape_len) return;
     GShape sh; sh.span = (u32)shape_len;
-    gshape_init(sh, seq.p + str);
+    u64 skip = gshape_init(sh, seq.p + str);
     u64 mask = (1ULL << (2 * sh.span - 2)) - 1;
     int count = 0;
     u64 lim = end < seq.len - (u64)shape_len ? end : seq.len - (u64)shape_len;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (coop && skip == 0 && lim > str) {
+        const u32 span = sh.span, lane = threadIdx.x & 63;
+        u32 M = (u32)((lim - str) / (u64)step), n0 = g_hs.n;
+        if (!M) return;
+        g_hs.reserve(n0 + M);
+        if (n0 + M > g_hs.cap) return;
+        const int C = -3 * (int)span;
+        for (u32 m = lane; m < M; m += 64) {
+            u64 k = str + (u64)(m + 1) * (u64)step - 1;
+            const u8 *w = seq.p + k;
+            u64 S = 0, crh = 0; int ws = 0;
+            for (u32 i = 0; i < span; i++) { u64 v = w[i]; S = S * 4 + v; crh |= ((3 - v) & 3) << (2 * i); ws += (int)v; }
+            u64 nw = w[span - 1];
+            u64 h = ((S - nw) & ((1ULL << (2 * span)) - 1)) + nw;
+            if (nw == 4) crh |= ~0ULL << (2 * span);
+            u64 strand = (C + 2 * ws) < 0 ? 1 : 0;
+            g_hs.p[n0 + m] = g_hs_make(strand ? crh : h, type, strand, k);
+        }
+        g_hs.n = n0 + M;
+        return;
+    }
+#endif
+    (void)coop; (void)skip;
     for (u64 k = str; k < lim; k++) {
         const u8 *it = seq.p + k;
         int v2 = it[sh.span - 1];
@@ -169,19 +208,35 @@ LNR_HD inline void g_kmer_stream(const GSeq &seq, GVec<u64> &g_hs, u64 str, u64 
         if (++count == step) { g_hs.push(g_hs_make(strand ? sh.crh : sh.h, type, strand, k)); count = 0; }
     }
 }
-LNR_HD inline void g_stream(const GSeq &ref, const GSeq &read, GVec<u64> &g_hs, u64 gap_str, u64 gap_end, u32 shape_len, int step1, int step2) {   // g_stream_ :1663-1688
+LNR_HD inline void g_stream(const GSeq &ref, const GSeq &read, GVec<u64> &g_hs, u64 gap_str, u64 gap_end, u32 shape_len, int step1, int step2, int coop = 0) {   // g_stream_ :1663-1688
     u64 gs_str = cord_x(gap_str), gs_end = cord_x(gap_end), gr_str = cord_y(gap_str), gr_end = cord_y(gap_end);
     if (cord_strand(gap_str)) { u64 a = read.len - gr_str - 1, b = read.len - gr_end - 1; gr_str = b; gr_end = a; }
-    g_kmer_stream(ref, g_hs, gs_str, gs_end, (int)shape_len, step1, 0);
-    g_kmer_stream(read, g_hs, gr_str, gr_end, (int)shape_len, step2, 1);
+    g_kmer_stream(ref, g_hs, gs_str, gs_end, (int)shape_len, step1, 0, coop);
+    g_kmer_stream(read, g_hs, gr_str, gr_end, (int)shape_len, step2, 1, coop);
 }
-LNR_HD inline void c_stream(const GSeq &seq, GVec<u64> &g_hs, u64 sq_str, u64 sq_end, int step, int shape_len, u64 type) {   // c_stream_ :1694-1716
+LNR_HD inline void c_stream(const GSeq &seq, GVec<u64> &g_hs, u64 sq_str, u64 sq_end, int step, int shape_len, u64 type, int coop = 0) {   // c_stream_ :1694-1716
     if (seq.len < (u64)shape_len) return;
     u32 span = (u32)shape_len;
+    u64 lim = sq_end < seq.len - (u64)shape_len ? sq_end : seq.len - (u64)shape_len;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (coop && lim > sq_str) {                              // (no hashInit here: the closed form holds from the first iteration on)
+        const u32 lane = threadIdx.x & 63;
+        u32 M = (u32)((lim - sq_str) / (u64)step), n0 = g_hs.n;
+        if (!M) return;
+        g_hs.reserve(n0 + M);
+        if (n0 + M > g_hs.cap) return;
+        for (u32 m = lane; m < M; m += 64) {
+            u64 k = sq_str + (u64)(m + 1) * (u64)step - 1;
+            g_hs.p[n0 + m] = g_hs_make(kmer_h_closed(seq.p + k, span), type, 0, k);
+        }
+        g_hs.n = n0 + M;
+        return;
+    }
+#endif
+    (void)coop;
     u64 h = 0, mask = (1ULL << (2 * span - 2)) - 1;
     for (u32 i = 0; i < span - 1; ++i) h = (h << 2) + seq.p[sq_str + i];
     int count = 0;
-    u64 lim = sq_end < seq.len - (u64)shape_len ? sq_end : seq.len - (u64)shape_len;
     for (u64 k = sq_str; k < lim; k++) {
         h = ((h & mask) << 2) + seq.p[k + span - 1];
         if (++count == step) { g_hs.push(g_hs_make(h, type, 0, k)); count = 0; }
@@ -211,22 +266,21 @@ LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, 
     B.base = (i64)cord2stranchor(direction < 0 ? gap_end : gap_str);
     B.d_anchor = (i64)((1LL << 7) * gp.thd_gmsa_d_anchor_rate);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (coop) {                                              // the pairs of one reference k-mer, 64 read k-mers at a time; kept anchors in pair order
+    if (coop) {                                              // the block's (reference k-mer, read k-mer) pairs, 64 at a time in pair order (i major)
         const int lane = (int)(threadIdx.x & 63);
-        for (int i = p1; i < p2; i++) {
-            u64 hi = g_hs[(u32)i];
-            for (int jb = p2; jb < k; jb += 64) {
-                int j = jb + lane;
-                u64 a = j < k ? ganc_make(hi, g_hs.p[j], rvcp) : 0;
-                bool kp = j < k && B.keep(a);
-                u64 m = __ballot(kp);
-                u32 cnt = (u32)__popcll(m);
-                if (!cnt) continue;
-                out.reserve(out.n + cnt);
-                if (out.n + cnt > out.cap) return;
-                if (kp) out.p[out.n + (u32)__popcll(m & ((1ULL << lane) - 1))] = a;
-                out.n += cnt;
-            }
+        const u32 ni = (u32)(p2 - p1), nj = (u32)(k - p2), np = ni * nj;
+        for (u32 pb = 0; pb < np; pb += 64) {
+            u32 q = pb + (u32)lane;
+            u32 qi = q / nj, qj = q - qi * nj;
+            u64 a = q < np ? ganc_make(g_hs.p[(u32)p1 + qi], g_hs.p[(u32)p2 + qj], rvcp) : 0;
+            bool kp = q < np && B.keep(a);
+            u64 m = __ballot(kp);
+            u32 cnt = (u32)__popcll(m);
+            if (!cnt) continue;
+            out.reserve(out.n + cnt);
+            if (out.n + cnt > out.cap) return;
+            if (kp) out.p[out.n + (u32)__popcll(m & ((1ULL << lane) - 1))] = a;
+            out.n += cnt;
         }
         return;
     }
@@ -242,6 +296,26 @@ template <class F> LNR_HD inline void g_hs_blocks(GVec<u64> &g_hs, int shape_len
     { GP(X, 0); gap_sort(g_hs.p, (long)g_hs.n, [mask](const u64 &a, const u64 &b) { return (a & mask) < (b & mask); }, X); }
     GP(X, 1);
     int p1 = 0, p2 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (X.coop) {
+        // 64 neighbour comparisons per load; the events (t == 1: the block's read k-mers begin; t > 1: the block ends) are then taken in
+        // order -- a block is handed on only when it holds pairs (emit with an empty side does nothing)
+        const u32 n = g_hs.n, lane = threadIdx.x & 63;
+        for (u32 base = 1; base < n; base += 64) {
+            u32 k = base + lane;
+            u64 t = k < n ? g_hs_xt((g_hs.p[k] ^ g_hs.p[k - 1]) & mask) : 0;
+            u64 m1 = __ballot(t == 1), ev = __ballot(t >= 1);
+            while (ev) {
+                int b = __builtin_ctzll(ev);
+                ev &= ev - 1;
+                int kk = (int)base + b;
+                if ((m1 >> b) & 1) p2 = kk;
+                else { if (p2 > p1 && kk > p2) emit(p1, p2, kk); p1 = kk; p2 = kk; }
+            }
+        }
+        return;
+    }
+#endif
     for (int k = 1; k < (int)g_hs.n; k++) {
         u64 t = g_hs_xt((g_hs[(u32)k] ^ g_hs[(u32)k - 1]) & mask);
         if (t == 0) continue;
@@ -263,6 +337,42 @@ LNR_HD inline void c_create_anchors2(GVec<u64> &g_hs, GVec<u64> &out, i64 lower,
     int p1 = 0, p2 = 0;
     if (Xp) gap_sort(g_hs.p, (long)g_hs.n, [](const u64 &a, const u64 &b) { return a < b; }, *Xp);
     else ref_sort(g_hs.p, (long)g_hs.n, [](const u64 &a, const u64 &b) { return a < b; }, st);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Xp && Xp->coop) {
+        // the wave-per-read form: 64 neighbour comparisons per load, the blocks in order, a block's (reference k-mer, read k-mer) pairs
+        // dealt over the lanes and the kept ones appended in pair order (i major, as the loops below)
+        const u32 n = g_hs.n, lane = threadIdx.x & 63;
+        for (u32 base = 1; base < n; base += 64) {
+            u32 kq = base + lane;
+            u64 t = kq < n ? g_hs_xt(g_hs.p[kq] ^ g_hs.p[kq - 1]) : 0;
+            u64 m1 = __ballot(t == 1), ev = __ballot(t >= 1);
+            while (ev) {
+                int bb = __builtin_ctzll(ev);
+                ev &= ev - 1;
+                int k = (int)base + bb;
+                if ((m1 >> bb) & 1) { p2 = k; continue; }
+                if (out.ar->ovf) return;
+                const u32 ni = (u32)(p2 - p1), nj = (u32)(k - p2), np = p2 > p1 && k > p2 ? ni * nj : 0;
+                for (u32 pb = 0; pb < np; pb += 64) {
+                    u32 q = pb + lane;
+                    u32 qi = q / nj, qj = q - qi * nj;
+                    u64 hi_ = q < np ? g_hs.p[(u32)p1 + qi] : 0, hj_ = q < np ? g_hs.p[(u32)p2 + qj] : 0;
+                    i64 d = (i64)(hi_ & ((1ULL << 30) - 1)) - (i64)(hj_ & ((1ULL << 30) - 1));
+                    bool kp = q < np && lower <= d && d < upper;
+                    u64 m = __ballot(kp);
+                    u32 cnt = (u32)__popcll(m);
+                    if (!cnt) continue;
+                    out.reserve(out.n + cnt);
+                    if (out.n + cnt > out.cap) return;
+                    if (kp) out.p[out.n + (u32)__popcll(m & ((1ULL << lane) - 1))] = canc_make(hi_, hj_);
+                    out.n += cnt;
+                }
+                p1 = k; p2 = k;
+            }
+        }
+        return;
+    }
+#endif
     for (int k = 1; k < (int)g_hs.n; k++) {
         u64 t = g_hs_xt(g_hs[(u32)k] ^ g_hs[(u32)k - 1]);
         if (t == 0) continue;
@@ -399,7 +509,10 @@ LNR_HD inline int gap_dp_score(int fn, u64 a, u64 b) { return fn == 2 ? gap_anch
 #ifndef K_GAP_TEAM_ROW
 #define K_GAP_TEAM_ROW 2048   // predecessors of the previous row from which a row is dealt over the team (two barriers per row)
 #endif
-struct GapTeam { const u64 *anchors; const i32 *score; u64 ai, dx_depth; int i, j_str, fn, cmd; u64 part[16]; };
+struct GapTeam { const u64 *anchors; const i32 *score; u64 ai, dx_depth; int i, j_str, fn, cmd; u64 part[16]; Rec rec; u32 n, depth; int dup; };   // cmd: 0 exit, 1 one long row, 2 a whole DP by columns
+#ifndef K_GAP_COL_MIN
+#define K_GAP_COL_MIN 1024    // anchors from which a chain DP is run column by column on the whole team
+#endif
 #if defined(__HIPCC__)
 // the predecessors [0, i - 65] of row i in blocks of 256 from the top, block b for wave b mod nw; returns this wave's best key
 struct GapDpFn { int fn; __device__ int operator()(u64 a, u64 b) const { return gap_dp_score(fn, a, b); } };
@@ -434,16 +547,187 @@ __device__ inline u64 gap_dp_row_share(const u64 *anchors, const i32 *rscore, u6
     if (nblk) *nblk = blocks;
     return key;
 }
+// ---- a whole chain DP on the team, COLUMN BY COLUMN.  The anchors are x-descending; a column = the run of anchors with one x.  A pair of
+// anchors with dx = 0 never scores (all three score functions reject |dx| < 8 (3) unless dx == dy, and dx == dy == 0 would be the same k-mer
+// pair twice), so the rows of a column depend on earlier columns only: they are dealt over the waves (row c0 + w, c0 + w + nw, ...), each wave
+// scans its row's whole window from memory (the predecessors before the column: the same blocks of 256 as gap_dp_row_share) and writes the
+// row's record; one workgroup barrier per column.  Same records as the serial scan: the window of row i is [first j with x_j - x_i < dx_depth
+// or i - depth, i - 1], of which [c0, i - 1] cannot score; ties keep the smallest j (the key's low word).  Identical anchor words inside a
+// column (never produced by the joins; checked all the same) set *dup and the caller falls back to the single-wave form.
+template <class Score>
+__device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 depth, u64 dx_depth, Score score, int w, int nw, int *dup) {
+    const int lane = (int)(threadIdx.x & 63);
+    u32 c0 = 0;
+    while (c0 < n) {
+        const u64 x0 = ganc_x(anchors[c0]);
+        u32 c1 = c0 + 1;
+        for (;;) {
+            u32 idx = c1 + (u32)lane;
+            bool same = idx < n && ganc_x(anchors[idx]) == x0;
+            u64 m = __ballot(!same);
+            if (m) { c1 += (u32)__builtin_ctzll(m); break; }
+            c1 += 64;
+        }
+        for (u32 i = c0 + (u32)w; i < c1; i += (u32)nw) {
+            const u64 ai = anchors[i];
+            const int j_str = (int)i - (int)depth < 0 ? 0 : (int)i - (int)depth;
+            bool twin = false;
+            for (u32 jb = c0; jb < i; jb += 64) { u32 j = jb + (u32)lane; twin = twin || (j < i && anchors[j] == ai); }
+            if (__any(twin)) { if (lane == 0) *dup = 1; }
+            u64 key = 0;
+            for (int jb = (int)c0 - 1; jb >= 0; jb -= 256) {
+                u64 av[4]; i32 sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int j2 = jb - 64 * u - lane;
+                    av[u] = j2 >= 0 ? anchors[j2] : 0;
+                    sv[u] = j2 >= 0 ? r.score[j2] : 0;
+                }
+                bool stop = false;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int j2 = jb - 64 * u - lane;
+                    bool ok = j2 >= 0 && (j2 >= j_str || ganc_x(av[u]) - x0 < dx_depth);
+                    if (ok) {
+                        int sc = score(av[u], ai);
+                        if (sc > 0) { u64 k = ((u64)(u32)(sc + sv[u]) << 32) | (u64)(0xffffffffu - (u32)j2); key = k > key ? k : key; }
+                    }
+                    stop = stop || !ok;
+                }
+                if (__any(stop)) break;
+            }
+            for (int m = 32; m; m >>= 1) { u64 o = __shfl_xor(key, m); key = o > key ? o : key; }
+            if (lane == 0) {
+                if (key) {
+                    int best = (int)(key >> 32), max_j = (int)(0xffffffffu - (u32)key);
+                    r.p2[i] = max_j; r.score[i] = best; r.len[i] = r.len[max_j] + 1; r.score2[i] = best; r.root[i] = r.root[max_j]; r.leaf[i] = 1; r.leaf[max_j] = 0;
+                } else { r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = (i32)i; r.leaf[i] = 1; }
+            }
+        }
+        __syncthreads();                                         // the column's records are written: the next column reads them
+        c0 = c1;
+    }
+}
 __device__ inline void gap_team_helper_loop(GapTeam *tm, int wave, int nw) {
     for (;;) {
         __syncthreads();                                         // (A) a command is posted
         if (tm->cmd == 0) break;
+        if (tm->cmd == 2) { gap_dp_columns(tm->anchors, tm->n, tm->rec, tm->depth, tm->dx_depth, GapDpFn{tm->fn}, wave, nw, &tm->dup); continue; }
         u64 key = gap_dp_row_share(tm->anchors, tm->score, tm->ai, tm->i, tm->j_str, tm->dx_depth, GapDpFn{tm->fn}, wave, nw);
         if ((threadIdx.x & 63) == 0) tm->part[wave] = key;
         __syncthreads();                                         // (B) the shares are posted
     }
 }
 #endif
+
+// ---- traceBackChains (cluster_util.cpp:306-335) in the wave-per-read form: the scans over the records (distinct roots, the search for the
+// best score of traceBackChains0 and the best score before it, the table of traceBackChains1) run on all 64 lanes; the walks along a chain and
+// the emission stay the uniform code of lnr_hd.h (every lane, same data).  Same results as traceback(): the scan of traceBackChains0 returns
+// the FIRST index of the maximal score > -1 and, as its second best, the maximum of the scores before that index.
+#if defined(__HIPCC__)
+__device__ inline i64 gtb_range_best(const i32 *score, u32 lo, u32 hi) {
+    const u32 lane = threadIdx.x & 63;
+    i64 best = -1;
+    for (u32 j0 = lo; j0 < hi; j0 += 256) {
+        i32 sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { u32 j = j0 + 64 * u + lane; sc[u] = j < hi ? score[j] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            u32 j = j0 + 64 * u + lane;
+            if (sc[u] > -1) { i64 k = ((i64)sc[u] << 32) | (i64)(u32)(0x7fffffff - (int)j); best = k > best ? k : best; }
+        }
+    }
+    return wave_max_i64(best);
+}
+__device__ inline int gtb_prefix_max(const i32 *score, u32 end) {
+    const u32 lane = threadIdx.x & 63;
+    i64 m = -1;
+    for (u32 j0 = 0; j0 < end; j0 += 256) {
+        i32 sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { u32 j = j0 + 64 * u + lane; sc[u] = j < end ? score[j] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { i64 v = sc[u]; m = v > m ? v : m; }
+    }
+    return (int)wave_max_i64(m);
+}
+// traceback1_table (lnr_hd.h) with the lanes over the records: trees are numbered by their first leaf (per 64 records the roots not yet listed
+// are appended lowest lane first), the best leaf of a tree is the maximum of (score, earliest j) -- an atomic max on a 64-bit key in ls.ranks
+__device__ inline int gtb_table_wave(const Rec &r, u32 n, LeaderScratch &ls) {
+    const u32 lane = threadIdx.x & 63;
+    int nl = 0;
+    unsigned long long *key = (unsigned long long *)ls.ranks;
+    key[lane] = 0;
+    WSYNC();
+    for (u32 base = 0; base < n; base += 64) {
+        u32 j = base + lane;
+        bool lf = j < n && r.leaf[j] != 0;
+        i32 root = lf ? r.root[j] : -1;
+        int k = -1;
+        if (lf) for (int q = 0; q < nl; q++) if (ls.l_root[q] == root) { k = q; break; }
+        u64 pend = __ballot(lf && k < 0);
+        while (pend) {
+            int src = (int)__builtin_ctzll(pend);
+            i32 rt = __shfl(root, src);
+            if (nl < 64) { if (lane == 0) ls.l_root[nl] = rt; }
+            if (lf && k < 0 && root == rt) k = nl < 64 ? nl : -2;      // -2: table full, the leaf is ignored like the serial form does
+            if (nl < 64) nl++;
+            WSYNC();
+            pend = __ballot(lf && k == -1);
+        }
+        if (lf && k >= 0) {
+            unsigned long long kv = ((unsigned long long)(u32)(r.score[j] + 0x40000000) << 32) | (unsigned long long)(0xffffffffu - j);
+            atomicMax(&key[k], kv);
+        }
+    }
+    WSYNC();
+    if ((int)lane < nl) {
+        unsigned long long kv = key[lane];
+        u32 j = 0xffffffffu - (u32)(kv & 0xffffffffu);
+        ls.l_score[lane] = (i32)(u32)(kv >> 32) - 0x40000000; ls.l_len[lane] = r.len[j]; ls.l_leaf[lane] = (i32)j;
+    }
+    WSYNC();
+    return nl;
+}
+template <class Sink>
+__device__ inline void gap_traceback_wave(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int min_len, int abort_score, int bestn, float stop_ratio, LeaderScratch &ls) {
+    const u32 lane = threadIdx.x & 63;
+    for (u32 i = lane; i < n; i += 64) cnt[i] = 0;
+    WSYNC();
+    for (u32 i = lane; i < n; i += 64) cnt[r.root[i]] = 1;
+    WSYNC();
+    u32 c = 0;
+    for (u32 i = lane; i < n; i += 64) c += (u32)cnt[i];
+    u32 root_num = wave_sum(c);
+    if (root_num > 50) {
+        int search_times = bestn < 50 ? bestn : 50;
+        for (int it = 0; it < search_times; it++) {
+            i64 best = gtb_range_best(r.score, 0, n);
+            Tb0Scan sc; sc.max_score = -1; sc.max_2nd = -1; sc.max_str = -1; sc.max_len = 0;
+            if (best >= 0) {
+                sc.max_score = (int)(best >> 32);
+                sc.max_str = 0x7fffffff - (int)(u32)(best & 0xffffffff);
+                sc.max_len = r.len[sc.max_str];
+                sc.max_2nd = gtb_prefix_max(r.score, (u32)sc.max_str);
+            }
+            bool more = tb0_step(r, sc, sink, chain, chain_sc, min_len, abort_score, stop_ratio);
+            WSYNC();
+            if (!more) break;
+        }
+    } else {
+        int nl = gtb_table_wave(r, n, ls);
+        traceback1_emit(r, nl, sink, chain, chain_sc, min_len, abort_score, bestn, stop_ratio, ls);
+    }
+}
+#endif
+template <class Sink>
+LNR_HD inline void gap_traceback(Rec r, u32 n, Sink &sink, i32 *chain, i32 *chain_sc, i32 *cnt, int min_len, int abort_score, int bestn, float stop_ratio, GapCtx &X) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (X.coop && n > 256) { gap_traceback_wave(r, n, sink, chain, chain_sc, cnt, min_len, abort_score, bestn, stop_ratio, *X.ls); return; }
+#endif
+    traceback(r, n, sink, chain, chain_sc, cnt, min_len, abort_score, bestn, stop_ratio, *X.ls);
+}
 
 struct TileSink {
     const u64 *anchors; GVec<u64> *tiles; u32 first_len, nchains; bool to_tiles;
@@ -466,12 +750,26 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
     if (X.ar->ovf) return;
     // (the reference sizes the records without clearing them and sets only record 0's score, length and predecessor: root and leaf of
     // record 0 are whatever the allocator left -- 0 in practice, as here)
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (X.coop) { for (u32 i = threadIdx.x & 63; i < n; i += 64) { r.score[i] = 0; r.score2[i] = 0; r.len[i] = 0; r.p2[i] = 0; r.root[i] = 0; r.leaf[i] = 0; } WSYNC(); }
+    else
+#endif
     for (u32 i = 0; i < n; i++) { r.score[i] = 0; r.score2[i] = 0; r.len[i] = 0; r.p2[i] = 0; r.root[i] = 0; r.leaf[i] = 0; }
     r.score[0] = 0; r.len[0] = 1; r.p2[0] = -1;
     {
     GP(X, 4);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (X.coop) {
+    bool by_columns = false;
+    if (X.coop && X.team > 1 && fn_id && n >= K_GAP_COL_MIN) {
+        GapTeam *tm = X.tm;
+        if ((threadIdx.x & 63) == 0) { tm->anchors = anchors; tm->rec = r; tm->n = n; tm->depth = depth; tm->dx_depth = dx_depth; tm->fn = fn_id; tm->dup = 0; tm->cmd = 2; }
+        __syncthreads();                                         // (A)
+        gap_dp_columns(anchors, n, r, depth, dx_depth, GapDpFn{fn_id}, 0, X.team, &tm->dup);
+        by_columns = tm->dup == 0;                               // (a column held the same anchor twice: the single-wave form below redoes the DP)
+        if (!by_columns) { for (u32 i = threadIdx.x & 63; i < n; i += 64) { r.score[i] = 0; r.score2[i] = 0; r.len[i] = 0; r.p2[i] = 0; r.root[i] = 0; r.leaf[i] = 0; } WSYNC(); r.score[0] = 0; r.len[0] = 1; r.p2[0] = -1; }
+    }
+    if (by_columns) {}
+    else if (X.coop) {
         // every lane runs the read's code with the same data; here the predecessors of anchor i are dealt over the lanes, 64 at a
         // time.  The scan ends at the first j below j_str whose x is dx_depth away: the anchors are x-descending, so that is a
         // threshold in j.  Among equal sums the serial scan (j descending, >=) keeps the smallest j: the key's low word.
@@ -548,7 +846,7 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
     // the output may grow while the records live above it in the arena: collect into a vector allocated before them
     TileSink sink; sink.anchors = anchors; sink.tiles = &out; sink.first_len = 0; sink.nchains = 0; sink.to_tiles = to_tiles;
     out.reserve(out.n + n);
-    traceback(r, n, sink, chain, chain_sc, cnt, min_len, abort_score, bestn, 0.7f, *X.ls);
+    gap_traceback(r, n, sink, chain, chain_sc, cnt, min_len, abort_score, bestn, 0.7f, X);
     (void)fn_id;
     (void)m0;   // (not released: `out` may have been re-allocated above the mark)
 }
@@ -973,8 +1271,8 @@ LNR_HD inline int gap_map_along_chain(const GSeq &ref, const GSeq &seq2, const G
     GVec<u64> hs, anc; hs.init(X.ar, 1024); anc.init(X.ar, 1024);
     u64 a = ch[(u32)i_str], b = ch[(u32)i_end - 1];
     i64 as = (i64)(cord_x(a) - cord_y(a)), ae = (i64)(cord_x(b) - cord_y(b));
-    c_stream(ref, hs, cord_x(a), cord_x(b), step1, shape_len, 0);
-    c_stream(seq2, hs, cord_y(a), cord_y(b), step2, shape_len, 1);
+    c_stream(ref, hs, cord_x(a), cord_x(b), step1, shape_len, 0, X.coop);
+    c_stream(seq2, hs, cord_y(a), cord_y(b), step2, shape_len, 1, X.coop);
     c_create_anchors2(hs, anc, (as < ae ? as : ae) - 30, (as > ae ? as : ae) + 30, X.ls->st, &X);
     gap_sort(anc.p, (long)anc.n, [](const u64 &p, const u64 &q) { return ganc_x(p) > ganc_x(q); }, X);
     stick_main_chain(anc, ch, X.gp.thd_smcn_danchor);
@@ -1083,7 +1381,7 @@ LNR_HD inline void gap_extend_interval_one_side(const GSeq &ref, GVec<u64> &tile
     int od = gp.direction;
     gp.direction = direction;
     GVec<u64> g_hs, anc, chain; g_hs.init(X.ar, 2048); anc.init(X.ar, 2048); chain.init(X.ar, 256);
-    { GP(X, 2); g_stream(ref, X.read, g_hs, gap_str, gap_end, (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2); }
+    { GP(X, 2); g_stream(ref, X.read, g_hs, gap_str, gap_end, (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2, X.coop); }
     g_create_anchors(g_hs, anc, gp.thd_eis_shape_len, direction, 0, 0, X.read.len - 1, gap_str, gap_end, X);
     g_chains_from_anchors(anc, chain, X.read.len, X);
     closest_extension_chain(chain, gap_str, gap_end, true, gp);
@@ -1130,7 +1428,7 @@ LNR_HD inline void gap_map_extends(const GSeq &ref, GVec<u64> &ts1, GVec<u64> &t
         u64 id = cord_id(gs1), strand = cord_strand(gs1);
         u64 x1 = cord_x(gs1) < cord_x(gs2) ? cord_x(gs1) : cord_x(gs2), y1 = cord_y(gs1) < cord_y(gs2) ? cord_y(gs1) : cord_y(gs2);
         u64 x2 = cord_x(ge1), y2 = cord_y(ge1) > cord_y(ge2) ? cord_y(ge1) : cord_y(ge2);                   // (x of gap_end1 twice in the reference)
-        { GP(X, 2); g_stream(ref, X.read, g_hs, create_cord(id, x1, y1, strand), create_cord(id, x2, y2, strand), (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2); }
+        { GP(X, 2); g_stream(ref, X.read, g_hs, create_cord(id, x1, y1, strand), create_cord(id, x2, y2, strand), (u32)gp.thd_eis_shape_len, gp.thd_eis_step1, gp.thd_eis_step2, X.coop); }
         g_create_anchor_pair(g_hs, a1, a2, gp.thd_eis_shape_len, X.read.len - 1, gs1, ge1, gs2, ge2, X);
         int od2 = gp.direction;                                                                             // extendsTilesFromAnchors :3643-3692
         gp.direction = 1;
@@ -1229,7 +1527,7 @@ LNR_HD inline void gap_map_generic(const GSeq &ref, GVec<u64> &ts, GVec<u64> &te
     X.gp.f_rfts_clip = 0;
     if (!cord_strand(gap_str ^ gap_end)) {
         GVec<u64> g_hs, anc; g_hs.init(X.ar, 2048); anc.init(X.ar, 2048);
-        { GP(X, 2); g_stream(ref, X.read, g_hs, gap_str, gap_end, 9, 5, 1); }
+        { GP(X, 2); g_stream(ref, X.read, g_hs, gap_str, gap_end, 9, 5, 1, X.coop); }
         g_create_anchors(g_hs, anc, 9, 0, -(((i64)1 << 62) - 1), ((i64)1 << 62) - 1, X.read.len - 1, gap_str, gap_end, X);
         if (anc.n > 1000) gap_filter_anchors(anc, X);
         gap_tiles_from_anchors2(ref, anc, ts, te, gap_str, gap_end, X.read.len - 1, X);

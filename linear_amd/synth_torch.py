@@ -205,3 +205,37 @@ def sample_reads_multi_cuda(gen: torch.Tensor, offs, n_reads: int, read_len: int
         s += m
     off = torch.arange(n_reads + 1, device=dev, dtype=torch.int64) * read_len
     return out.reshape(-1), off
+
+
+@torch.no_grad()
+def plant_svs_cuda(reads: torch.Tensor, n: int, src_len: int, out_len: int, frac: float, seed: int, chunk: int = 4096) -> tuple[torch.Tensor, torch.Tensor, int]:
+    """BASELINE configs[4]'s read profile: a fraction `frac` of the reads gets ONE planted structural variant of 50 bp - 5 kb in its middle --
+    deletion, insertion of random bases, tandem duplication or inversion, a quarter each -- applied to reads sampled `src_len` long (the slack
+    a deletion eats); every read comes out `out_len` long.  Returns (bases, offsets, number of reads with an SV)."""
+    dev = reads.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    src = reads.view(n, src_len)
+    out = src[:, :out_len].clone()
+    sel = torch.nonzero(torch.rand(n, generator=g, device=dev) < frac).flatten()
+    cpl = torch.tensor([3, 2, 1, 0, 4], dtype=torch.uint8, device=dev)
+    p = torch.arange(out_len, device=dev)[None, :]
+    for s0 in range(0, sel.numel(), chunk):
+        rows = sel[s0:s0 + chunk]
+        k = rows.numel()
+        kind = torch.randint(0, 4, (k, 1), generator=g, device=dev)
+        m = (50 + (torch.rand(k, 1, generator=g, device=dev) ** 2) * 4950).long()
+        cut = torch.randint(6000, out_len - 6000, (k, 1), generator=g, device=dev)
+        a, b = p >= cut, p >= cut + m
+        idx_del = p + m * a
+        idx_ins = torch.where(b, p - m, p)
+        idx_dup = torch.where(a, p - m, p)
+        idx_inv = torch.where(a & ~b, 2 * cut + m - 1 - p, p)
+        idx = torch.where(kind == 0, idx_del, torch.where(kind == 1, idx_ins, torch.where(kind == 2, idx_dup, idx_inv))).clamp_(0, src_len - 1)
+        v = torch.gather(src[rows], 1, idx)
+        rnd = torch.randint(0, 4, (k, out_len), generator=g, device=dev, dtype=torch.uint8)
+        v = torch.where((kind == 1) & a & ~b, rnd, v)
+        v = torch.where((kind == 3) & a & ~b, cpl[v.long()], v)
+        out[rows] = v
+    off = torch.arange(n + 1, device=dev, dtype=torch.int64) * out_len
+    return out.reshape(-1), off, int(sel.numel())

@@ -65,6 +65,27 @@ class FilterDouble:
 
     seed_lookup_batch_dev = filter_batch_dev
 
+    # the host entry point of the timed region (bench.py: lnr_filter_submit / lnr_filter_wait with two batches in flight)
+    def host_alloc(self, nbytes):
+        return np.zeros(nbytes, np.uint8)
+
+    def filter_submit(self, reads, off):
+        self.inflight = getattr(self, "inflight", 0) + 1
+        assert self.inflight <= 2
+        self.n = off.size - 1
+
+    def filter_wait(self, copy=True):
+        assert self.inflight >= 1
+        self.inflight -= 1
+        time.sleep(0.002)
+        return self.n, 0
+
+    def gap_stream(self, set_to=-1):
+        return 0
+
+    def set_gap(self, gap_len, dup=0):
+        pass
+
     def stats(self):
         d = {k: 0 for k in ("reads", "bases", "jobs", "samples", "lookups", "bucket_entries", "anchors", "remap_reads", "cords", "seed_bytes", "prep_ms",
                             "seed_count_ms", "seed_gather_ms", "job_ms", "tail_ms", "total_ms", "seed_count_launches", "seed_gather_launches", "job_launches")}

@@ -465,6 +465,26 @@ def test_gpu_batch_rerun_on_per_read_overflow(case_inputs, monkeypatch):
     f.close()
 
 
+def test_gpu_two_pageable_submits_back_to_back(flt, case_inputs):
+    """lnr_filter_submit twice in a row from PAGEABLE memory (the documented two-in-flight pattern): both batches go through the context's two
+    pinned staging buffers; the second submit must not overwrite a chunk the first one's DMA has not read yet (the "recorded"
+    state of the staging events was call-local).  Batches of different content; both results must equal the one-by-one results."""
+    refs, reads, off = case_inputs("ont")
+    flt.build_index(refs, 4)
+    n = off.size - 1
+    h = n // 2
+    b0 = (np.ascontiguousarray(reads[: int(off[h])]), np.ascontiguousarray(off[: h + 1]))
+    b1 = (np.ascontiguousarray(reads[int(off[h]):]), np.ascontiguousarray((off[h:] - off[h]).astype(np.uint64)))
+    want0, want1 = flt.filter_batch(*b0), flt.filter_batch(*b1)
+    for _ in range(3):
+        flt.filter_submit(*b0)
+        flt.filter_submit(*b1)
+        got0 = flt.filter_wait()
+        got1 = flt.filter_wait()
+        for w, g_ in ((want0, got0), (want1, got1)):
+            assert all(np.array_equal(a, b) for a, b in zip(w, g_))
+
+
 # ---- the gap re-mapper (-g > 0, SURVEY 8 f1): mapGaps + reformCords on the GPU (k_gap)
 @pytest.mark.parametrize("name", ["ont", "edge", "ccs_sv", "rep", "chim"])
 def test_gpu_gap_path_matches_golden(case_inputs, name):
