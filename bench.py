@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the timed CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cli", action="store_true", help="skip the front-end's end-to-end measurement (FASTA files in -> SAM out)")
     ap.add_argument("--seed-only", action="store_true", help="time only stage a7 (seed lookup) -- used for the roofline profile")
     ap.add_argument("--gap", type=int, default=0, help="the reference's -g: 0 = apxMap only (the headline configuration); > 0 = cords go through the gap re-mapper (SURVEY 8 f1)")
     ap.add_argument("--dup", type=int, default=0, help="the reference's -dup (with --gap)")
@@ -499,6 +500,50 @@ def main():
         if not parity_ok:
             log("[bench] PARITY FAILURE on the bench sample")
         chk.close()
+
+    if rank == 0 and world == 1 and not double and not args.seed_only and not args.no_cli and host_genome is not None and args.workload in ("grch38", "chr22", "small"):
+        # ---- the front-end binary end to end: FASTA files in -> .sam out through reader -> GPU -> writer, batch 0 as a read file
+        import re
+        import shutil
+        import tempfile
+        td = tempfile.mkdtemp(prefix="lnr_cli_")
+        try:
+            abc = np.frombuffer(b"ACGTN", np.uint8)
+            t0 = time.time()
+            with open(os.path.join(td, "ref.fa"), "wb") as f:
+                for k, sq in enumerate(host_genome):
+                    f.write(b">chr%d\n" % (k + 1))
+                    f.write(abc[np.minimum(sq, 4)].tobytes())
+                    f.write(b"\n")
+            hr = batches[0][0].cpu().numpy().reshape(args.reads, args.read_len)
+            txt = np.empty((args.reads, args.read_len + 1), np.uint8)
+            txt[:, :-1] = abc[hr]
+            txt[:, -1] = 10
+            with open(os.path.join(td, "reads.fa"), "wb") as f:
+                rows = txt.tobytes()
+                step_b = args.read_len + 1
+                for i in range(args.reads):
+                    f.write(b">read_%d\n" % i)
+                    f.write(rows[i * step_b:(i + 1) * step_b])
+            t_write = time.time() - t0
+            from linear_amd import build as lb2
+            cmd = [lb2.CLI, "filter", os.path.join(td, "reads.fa"), os.path.join(td, "ref.fa"), "-t", str(T), "-g", str(args.gap), "-o", os.path.join(td, "out"), "--block-reads", "20000"] + (["-dup", "1"] if args.dup else [])
+            t0 = time.time()
+            pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            t_cli = time.time() - t0
+            m = re.search(rb"output files out: ([0-9.]+) s = ([0-9.]+) reads/s", pc.stderr)
+            if pc.returncode == 0 and m:
+                out["config"]["cli_end_to_end_reads_per_s"] = float(m.group(2))
+                out["config"]["cli_end_to_end"] = {"reads": args.reads, "read_phase_s": float(m.group(1)), "whole_run_s": round(t_cli, 2), "sam_bytes": os.path.getsize(os.path.join(td, "out.sam")),
+                                                   "what": "linear_amd/linear_filter filter reads.fa ref.fa (plain FASTA, %d reads x %d bp; parallel mapped reader -> lnr_filter_submit / _wait -> writer on -t host threads -> .sam); "
+                                                           "read_phase = first read block fetched .. last text written; whole_run adds genome load + index" % (args.reads, args.read_len)}
+                mb = re.search(rb"Stage busy time\[s\]: ([^\n]*)", pc.stderr)
+                out["config"]["cli_end_to_end"]["stage_busy_s"] = mb.group(1).decode() if mb else None
+                log(f"[bench] front-end end to end: {float(m.group(2)):.0f} reads/s in the read phase ({float(m.group(1)):.2f} s), whole run {t_cli:.1f} s (files written in {t_write:.1f} s); busy: {mb.group(1).decode() if mb else '?'}")
+            else:
+                log("[bench] front-end run failed: " + pc.stderr.decode(errors="replace")[-500:])
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
 
     if rank == 0:
         sys.stdout.flush()

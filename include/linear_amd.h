@@ -56,7 +56,8 @@ typedef struct lnr_opts {
     int32_t device;            /* HIP device ordinal; -1 = current device */
     uint32_t index_type;       /* -i : 1 = DIndex (reference default), 2 = HIndex (index_util.cpp:2593-2610: shape 17/9, one sample per 8 bases) */
     uint32_t feature_type;     /* -f : 2 = 2-mer/48 window features (reference default) */
-    uint32_t preset;           /* -p : 1 (reference default: chain stop ratio 0) */
+    uint32_t preset;           /* -p : 1 (reference default: chain stop ratio 0) or 2 (the same computation; only the writer's CIGAR thresholds differ,
+                                  lnr_writer_set_preset).  -p 0 (stop ratio 0.7 in the anchor traceback) is not built: LNR_ERR_UNSUPPORTED */
     uint32_t gap_len;          /* -g : 0 = apxMap only; > 0 = the cords go through the gap re-mapper (mapGaps + reformCords, gap.cpp:407-576) with this
                                   minimum gap length, mapped as the reference does: 1 -> 50, 2..9 -> 10 (mapper.cpp:207-231) */
     uint32_t dup;              /* -dup : 0 | 1, the duplication add-on of the gap re-mapper (gap.cpp:303-362) */
@@ -136,6 +137,12 @@ lnr_status lnr_index_export(lnr_ctx *ctx, int32_t *dir, uint64_t *hs, int32_t *f
 lnr_status lnr_index_alloc(lnr_ctx *ctx, const lnr_index_info *info, const uint64_t *seq_len /* nseq */);
 lnr_status lnr_index_blob(lnr_ctx *ctx, uint32_t which, void **d_ptr, uint64_t *bytes);
 lnr_status lnr_index_adopt(lnr_ctx *ctx);
+/* One process driving several GPUs (the C++ front-end: one host thread + one context per GPU): moves the index of ctxs[root] into
+ * every other context (created with the same options, no index yet) through lnr_index_alloc / _blob / _adopt.  Contexts on distinct devices:
+ * ncclBroadcast of the four device buffers in place over RCCL / xGMI (librccl is loaded on first use; nothing else in the library needs it);
+ * a context that shares its device with another one gets device-to-device copies.  *seconds (optional): wall time of the exchange, the
+ * receivers' derived tables included.  What a front-end compares it with: lnr_index_build on every context ("every GPU builds its own"). */
+lnr_status lnr_index_broadcast(lnr_ctx *const *ctxs, uint32_t n, uint32_t root, double *seconds);
 
 /* The hot path.  reads_concat = bases of all reads back to back, off[n+1] = start offsets.
  * Host-buffer form (copies in and out over PCIe): */
@@ -143,7 +150,8 @@ lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads_concat, const uin
 /* The same in two halves, so that one context overlaps transfer and compute: lnr_filter_submit starts the upload of a batch on a
  * copy stream and returns; lnr_filter_wait runs the oldest submitted batch and returns its cords.  Up to two batches may be in
  * flight -- submit(k+1) before wait(k) puts the upload of batch k+1 under the kernels of batch k.  The read buffer must stay
- * untouched until the matching lnr_filter_wait returns; results are valid until the next lnr_filter_wait / lnr_filter_batch.
+ * untouched until the matching lnr_filter_wait returns; the host arrays of a result stay valid until the SECOND next result of the context
+ * (two result slots taken in turn: another thread may format batch k while the context runs batch k + 1).
  * A read buffer in pinned host memory (lnr_host_alloc, or the caller's own hipHostMalloc / hipHostRegister) is uploaded by one
  * DMA at link rate; a pageable one goes through the context's pinned staging buffers first. */
 lnr_status lnr_filter_submit(lnr_ctx *ctx, const uint8_t *reads_concat, const uint64_t *off, uint32_t n);
@@ -212,6 +220,10 @@ lnr_status lnr_writer_create(const char *const *genome_ids, const uint64_t *geno
 lnr_status lnr_writer_format(lnr_writer *w, const lnr_cords *cords, const uint64_t *read_len, const char *read_ids, const uint64_t *id_off,
                              int what, uint32_t threads, const char **text, uint64_t *size);
 lnr_status lnr_writer_sam_header(lnr_writer *w, const char *command_line, const char **text, uint64_t *size);
+/* -p (mapper.cpp:173-196): preset 1 splits large diagonal shifts of a CIGAR (thd_DI 80, thd_X 200); presets 0 and 2 leave the reference's
+ * defaults (2^60 - 1: never).  -rg / -sn: the @RG line's ID / SM (mapper.cpp:288-324); both empty by default. */
+lnr_status lnr_writer_set_preset(lnr_writer *w, uint32_t preset);
+lnr_status lnr_writer_set_read_group(lnr_writer *w, const char *read_group, const char *sample_name);
 void lnr_writer_destroy(lnr_writer *w);
 
 #ifdef __cplusplus

@@ -58,7 +58,7 @@ EXPORTS = ["lnr_opts_default", "lnr_create", "lnr_destroy", "lnr_strerror", "lnr
            "lnr_index_export", "lnr_index_alloc", "lnr_index_blob", "lnr_index_adopt", "lnr_filter_batch", "lnr_filter_batch_dev",
            "lnr_cords_to_host", "lnr_seed_lookup_batch", "lnr_seed_lookup_batch_dev", "lnr_last_stats", "lnr_filter_submit", "lnr_filter_wait",
            "lnr_host_alloc", "lnr_host_free", "lnr_reader_open", "lnr_reader_next", "lnr_reader_ids", "lnr_reader_error", "lnr_reader_close",
-           "lnr_writer_create", "lnr_writer_format", "lnr_writer_sam_header", "lnr_writer_destroy", "lnr_last_gaps", "lnr_gap_stream", "lnr_set_gap"]
+           "lnr_writer_create", "lnr_writer_format", "lnr_writer_sam_header", "lnr_writer_destroy", "lnr_last_gaps", "lnr_gap_stream", "lnr_set_gap", "lnr_index_broadcast", "lnr_writer_set_preset", "lnr_writer_set_read_group"]
 
 
 def load_library() -> C.CDLL:

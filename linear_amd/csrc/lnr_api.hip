@@ -9,6 +9,7 @@
 #include "../../include/linear_amd.h"
 
 #include <algorithm>
+#include <dlfcn.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -191,7 +192,8 @@ struct lnr_ctx {
     DevBuf r_off, r_str, r_end;
     std::vector<u64> h_cord_off, h_anchor_off, h_anchors, h_gap_off, h_gap_pairs;
     std::vector<u64> last_gaps_off;      // per-read offsets into ctx->gaps of the last batch (capacity layout)
-    PinBuf h_cords_str, h_cords_end, h_up[2];   // results land in pinned memory (DMA at link rate, no page faults); h_up: upload staging ring
+    PinBuf h_cords_str2[2], h_cords_end2[2], h_up[2];   // results land in pinned memory (DMA at link rate, no page faults), two result slots taken in turn: the
+    std::vector<u64> h_cord_off2[2]; int res_slot = 0;    // arrays handed out stay valid until the SECOND next result (a writer thread formats batch k while k + 1 runs); h_up: upload staging ring
     hipEvent_t ev_up[2] = {nullptr, nullptr};
     std::vector<u32> dbg_r0w;   // round-0 anchors per read (LNR_DEBUG_R1 diagnostic)
     u32 last_n = 0;
@@ -225,6 +227,7 @@ namespace {
         }                                                                                            \
     } while (0)
 #define KCHECK() HIPCK(hipGetLastError())
+#define HIPCK_CTX(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e__); return LNR_ERR_HIP; } } while (0)
 
 template <class T>
 lnr_status upload(lnr_ctx *ctx, DevBuf &b, const std::vector<T> &v) {
@@ -1389,7 +1392,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     *out = nullptr;
     lnr_opts o;
     if (opts) o = *opts; else lnr_opts_default(&o);
-    if ((o.index_type != 1 && o.index_type != 2) || o.feature_type != 2 || o.preset != 1 || o.dup > 1) return LNR_ERR_UNSUPPORTED;
+    if ((o.index_type != 1 && o.index_type != 2) || o.feature_type != 2 || (o.preset != 1 && o.preset != 2) || o.dup > 1) return LNR_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return LNR_ERR_NO_DEVICE; }
     int dev = o.device;
@@ -1675,6 +1678,94 @@ lnr_status lnr_index_adopt(lnr_ctx *ctx) {
     return LNR_OK;
 }
 
+// ---- one process, several GPUs: the index of ctxs[root] into the other contexts (RCCL between devices, device copies inside one)
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (lib) return true;
+        for (const char *nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) { lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        Broadcast = (decltype(Broadcast))dlsym(lib, "ncclBroadcast"); GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd"); GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        return CommInitAll && CommDestroy && Broadcast && GroupStart && GroupEnd;
+    }
+};
+Rccl g_rccl;
+}  // namespace
+
+lnr_status lnr_index_broadcast(lnr_ctx *const *ctxs, uint32_t n, uint32_t root, double *seconds) {
+    if (!ctxs || n == 0 || root >= n) return LNR_ERR_ARG;
+    for (uint32_t i = 0; i < n; i++) if (!ctxs[i]) return LNR_ERR_ARG;
+    lnr_ctx *src = ctxs[root];
+    if (!src->has_index) { src->err = "lnr_index_broadcast: the root context has no index"; return LNR_ERR_NO_INDEX; }
+    auto t0 = std::chrono::steady_clock::now();
+    lnr_status s;
+    for (uint32_t i = 0; i < n; i++) {
+        if (i == root) continue;
+        if (ctxs[i]->opts.index_type != src->opts.index_type) { ctxs[i]->err = "lnr_index_broadcast: contexts with different index types"; return LNR_ERR_ARG; }
+        if ((s = lnr_index_alloc(ctxs[i], &src->info, src->seq_len.data())) != LNR_OK) return s;
+    }
+    // one representative context per device (the root for its own); RCCL between the representatives
+    std::vector<uint32_t> rep;
+    rep.push_back(root);
+    for (uint32_t i = 0; i < n; i++) {
+        bool seen = false;
+        for (uint32_t r : rep) seen = seen || ctxs[r]->device == ctxs[i]->device;
+        if (!seen) rep.push_back(i);
+    }
+    { DevGuard dg_(src->device); HIPCK_CTX(src, hipStreamSynchronize(src->stream)); }
+    if (rep.size() > 1) {
+        if (!g_rccl.load()) { src->err = "lnr_index_broadcast: librccl could not be loaded"; return LNR_ERR_HIP; }
+        std::vector<int> devs;
+        for (uint32_t r : rep) devs.push_back(ctxs[r]->device);
+        std::vector<void *> comms(rep.size(), nullptr);
+        int rc = g_rccl.CommInitAll(comms.data(), (int)rep.size(), devs.data());
+        if (rc != 0) { src->err = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"); return LNR_ERR_HIP; }
+        for (uint32_t which = 0; which < 4 && rc == 0; which++) {
+            g_rccl.GroupStart();
+            for (size_t k = 0; k < rep.size() && rc == 0; k++) {
+                lnr_ctx *c = ctxs[rep[k]];
+                void *p = nullptr; uint64_t bytes = 0;
+                if (lnr_index_blob(c, which, &p, &bytes) != LNR_OK) { rc = -1; break; }
+                (void)hipSetDevice(c->device);
+                rc = g_rccl.Broadcast(p, p, (size_t)bytes, /* ncclUint8 */ 1, /* root = rep[0] */ 0, comms[k], c->stream);
+            }
+            int rc2 = g_rccl.GroupEnd();
+            if (rc == 0) rc = rc2;
+        }
+        for (size_t k = 0; k < rep.size(); k++) { lnr_ctx *c = ctxs[rep[k]]; (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+        for (void *cm : comms) if (cm) g_rccl.CommDestroy(cm);
+        (void)hipSetDevice(src->device);
+        if (rc != 0) { src->err = std::string("ncclBroadcast: ") + (rc > 0 && g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"); return LNR_ERR_HIP; }
+    }
+    // contexts that share a device with a representative: device-to-device copies from it
+    for (uint32_t i = 0; i < n; i++) {
+        if (i == root) continue;
+        bool is_rep = false; uint32_t from = root;
+        for (uint32_t r : rep) { if (r == i) is_rep = true; if (ctxs[r]->device == ctxs[i]->device) from = r; }
+        if (!is_rep) {
+            DevGuard dg_(ctxs[i]->device);
+            for (uint32_t which = 0; which < 4; which++) {
+                void *ps = nullptr, *pd = nullptr; uint64_t b1 = 0, b2 = 0;
+                if (lnr_index_blob(ctxs[from], which, &ps, &b1) != LNR_OK || lnr_index_blob(ctxs[i], which, &pd, &b2) != LNR_OK || b1 != b2) return LNR_ERR_INTERNAL;
+                HIPCK_CTX(ctxs[i], hipMemcpyAsync(pd, ps, b1, hipMemcpyDeviceToDevice, ctxs[i]->stream));
+            }
+            HIPCK_CTX(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) if (i != root && (s = lnr_index_adopt(ctxs[i])) != LNR_OK) return s;
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return LNR_OK;
+}
+
 lnr_status lnr_filter_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_off, uint32_t n, lnr_cords_dev *out) {
     if (!ctx || !d_off || (n && !d_reads)) return LNR_ERR_ARG;
     DevGuard dg_(ctx->device);
@@ -1720,15 +1811,19 @@ lnr_status lnr_cords_to_host(lnr_ctx *ctx, lnr_cords *out) {
     if (!ctx || !out) return LNR_ERR_ARG;
     DevGuard dg_(ctx->device);
     u64 tot = ctx->last_ncords;
-    if (!ctx->h_cords_str.ensure(std::max<u64>(tot * 8, 16)) || !ctx->h_cords_end.ensure(std::max<u64>(tot * 8, 16))) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+    const int rs = ctx->res_slot;
+    ctx->res_slot ^= 1;
+    PinBuf &hs_ = ctx->h_cords_str2[rs], &he_ = ctx->h_cords_end2[rs];
+    if (!hs_.ensure(std::max<u64>(tot * 8, 16)) || !he_.ensure(std::max<u64>(tot * 8, 16))) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
     if (ctx->h_cord_off.size() != (size_t)ctx->last_n + 1) ctx->h_cord_off.assign((size_t)ctx->last_n + 1, 0);
+    ctx->h_cord_off2[rs] = ctx->h_cord_off;
     if (tot) {
-        HIPCK(hipMemcpyAsync(ctx->h_cords_str.p, ctx->r_str.p, tot * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCK(hipMemcpyAsync(ctx->h_cords_end.p, ctx->r_end.p, tot * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipMemcpyAsync(hs_.p, ctx->r_str.p, tot * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipMemcpyAsync(he_.p, ctx->r_end.p, tot * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCK(hipStreamSynchronize(ctx->stream));
     }
     out->n_reads = ctx->last_n; out->n_cords = tot;
-    out->cord_off = ctx->h_cord_off.data(); out->cords_str = ctx->h_cords_str.as<u64>(); out->cords_end = ctx->h_cords_end.as<u64>();
+    out->cord_off = ctx->h_cord_off2[rs].data(); out->cords_str = hs_.as<u64>(); out->cords_end = he_.as<u64>();
     return LNR_OK;
 }
 void *lnr_host_alloc(size_t bytes) {

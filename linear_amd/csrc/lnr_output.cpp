@@ -145,7 +145,8 @@ struct Writer {
     std::vector<std::string> gid;
     std::vector<u64> glen;
     std::string text;
-    u64 thd_large_X = 8000; i64 thd_DI = 80, thd_X = 200;      // mapper.cpp:465,185-186
+    u64 thd_large_X = 8000; i64 thd_DI = 80, thd_X = 200;      // mapper.cpp:465,185-186 (preset 1)
+    std::string rg, sn;                                        // -rg / -sn
 };
 
 void sam_read(const Writer &w, const u64 *cs, const u64 *ce, u64 n, u64 L, const char *qname, std::string &out, std::vector<Rec> &recs) {
@@ -263,10 +264,22 @@ lnr_status lnr_writer_sam_header(lnr_writer *wr, const char *command_line, const
     std::string &o = wr->w.text;
     o.clear();
     for (size_t i = 0; i < wr->w.gid.size(); i++) { o += "@SQ\tSN:"; o += wr->w.gid[i]; o += "\tLN:"; put_u(o, wr->w.glen[i]); o += '\n'; }
-    o += "@RG\tID:\tSM:\n@PG\tID:M1-3\tPN:Linear\tCL:";
+    o += "@RG\tID:"; o += wr->w.rg; o += "\tSM:"; o += wr->w.sn; o += "\n@PG\tID:M1-3\tPN:Linear\tCL:";
     o += command_line ? command_line : "";
     o += '\n';
     *text = o.data(); *size = o.size();
+    return LNR_OK;
+}
+
+lnr_status lnr_writer_set_preset(lnr_writer *wr, uint32_t preset) {
+    if (!wr || preset > 2) return LNR_ERR_ARG;
+    if (preset == 1) { wr->w.thd_DI = 80; wr->w.thd_X = 200; }                     // mapper.cpp:181-186
+    else { wr->w.thd_DI = ((i64)1 << 60) - 1; wr->w.thd_X = ((i64)1 << 60) - 1; }  // FIOParms::FIOParms f_io.cpp:14-22
+    return LNR_OK;
+}
+lnr_status lnr_writer_set_read_group(lnr_writer *wr, const char *read_group, const char *sample_name) {
+    if (!wr) return LNR_ERR_ARG;
+    wr->w.rg = read_group ? read_group : ""; wr->w.sn = sample_name ? sample_name : "";
     return LNR_OK;
 }
 

@@ -340,7 +340,7 @@ def test_gpu_linear_filter_cli_end_to_end(case_inputs, tmp_path):
         for i in range(n):
             f.write(b">" + rid[i].encode() + b"\n" + abc[reads[int(off[i]):int(off[i + 1])]].tobytes() + b"\n")
     for block in (1000, 17):
-        p = subprocess.run([lb.CLI, "filter", str(tmp_path / "reads.fa"), str(tmp_path / "ref.fa"), "-t", str(T), "-g", "0", "-o", str(tmp_path / "out"), "-ot", "3", "-b", str(block)],
+        p = subprocess.run([lb.CLI, "filter", str(tmp_path / "reads.fa"), str(tmp_path / "ref.fa"), "-t", str(T), "-g", "0", "-o", str(tmp_path / "out"), "-ot", "3", "--block-reads", str(block)],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, p.stderr.decode()[-1000:]
         sam = open(tmp_path / "out.sam", "rb").read().split(b"\n")
@@ -560,7 +560,8 @@ def test_gpu_linear_filter_cli_equals_the_real_program(name, tmp_path):
     g = np.load(os.path.join(GOLD, f"cli_{name}.npz"))
     rp, gp, _, _ = cases.write_fasta_case(tmp_path, refs, reads, off)
     for mode, flags in cases.CLI_MODES.items():
-        for block in (["-b", "23"] if mode == "g50dup1" else []), :
+        for block in (["--block-reads", "23", "--gpus", "2", "--devices", "0,0"] if mode == "g50dup1" else []), :      # (two contexts on the one GPU: two calculators,
+                                                                                                                             # the index moved by lnr_index_broadcast, the gap stream across them)
             p = subprocess.run([lb.CLI, "filter", rp, gp, "-t", "1", "-ot", "3", "-o", str(tmp_path / "out")] + flags + list(block), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
             assert p.returncode == 0, p.stderr.decode()[-1000:]
             sam, want = open(tmp_path / "out.sam", "rb").read(), g[f"sam_{mode}"].tobytes()

@@ -78,3 +78,41 @@ def test_reader_limits_and_superset(tmp_path):
     r.close()
     with pytest.raises(LnrError):
         Reader(str(tmp_path / "missing.fa"))
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "fastq", "fastq_multiline"])
+def test_parallel_and_serial_parsers_agree(tmp_path, fmt, monkeypatch):
+    """plain files go through the mapped, multi-threaded parser; the byte-wise serial parser (what gzip input uses, pinned to SeqAn's reader above)
+    must give the same records, ordinals and ids for any block size and thread count -- multi-line records, CRLF, blanks, lower case, IUPAC codes,
+    empty records, '>' and '@' inside header and quality lines; multi-line FASTQ makes the parallel path hand over to the serial one mid-file."""
+    from linear_amd import build as lb
+    lb.build()
+    rng = np.random.default_rng(17)
+    abc = np.frombuffer(b"ACGTacgtNnRYKMU", np.uint8)
+    path = tmp_path / ("x." + fmt)
+    with open(path, "wb") as f:
+        for i in range(1500):
+            L = int(rng.integers(0, 900)) if i % 97 else 0
+            s = abc[rng.integers(0, abc.size, L)].tobytes()
+            eol = b"\r\n" if i % 5 == 0 else b"\n"
+            if fmt == "fasta":
+                w = int(rng.integers(20, 200))
+                body = eol.join(s[k:k + w] for k in range(0, max(L, 1), w)) if i % 3 else s
+                if i % 11 == 0:
+                    body = body.replace(b"A", b"A ", 1)
+                f.write(b">rd%d > x @ y" % i + eol + body + eol + (eol if i % 7 == 0 else b""))
+            else:
+                q = bytes(rng.integers(33, 74, L, dtype=np.uint8).tolist())        # '@' (64) and '>' (62) occur in qualities
+                if fmt == "fastq_multiline" and i > 700 and L > 50:
+                    f.write(b"@rd%d" % i + eol + s[:30] + eol + s[30:] + eol + b"+" + eol + q[:40] + eol + q[40:] + eol)
+                else:
+                    f.write(b"@rd%d desc" % i + eol + s + eol + b"+" + (b"rd%d" % i if i % 2 else b"") + eol + q + eol)
+    monkeypatch.setenv("LNR_READER_SERIAL", "1")
+    want = read_all(str(path), 1 << 22, 100000)
+    monkeypatch.delenv("LNR_READER_SERIAL")
+    assert want[1].size - 1 == 1500
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("LNR_READER_THREADS", threads)
+        for cap, mr in ((1 << 22, 100000), (5000, 7), (1000, 1), (40000, 64)):
+            got = read_all(str(path), cap, mr)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]) and got[2] == want[2], (threads, cap, mr)
