@@ -147,11 +147,14 @@ lnr_status lnr_index_broadcast(lnr_ctx *const *ctxs, uint32_t n, uint32_t root, 
 /* The hot path.  reads_concat = bases of all reads back to back, off[n+1] = start offsets.
  * Host-buffer form (copies in and out over PCIe): */
 lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads_concat, const uint64_t *off, uint32_t n, lnr_cords *out);
-/* The same in two halves, so that one context overlaps transfer and compute: lnr_filter_submit starts the upload of a batch on a
- * copy stream and returns; lnr_filter_wait runs the oldest submitted batch and returns its cords.  Up to two batches may be in
- * flight -- submit(k+1) before wait(k) puts the upload of batch k+1 under the kernels of batch k.  The read buffer must stay
- * untouched until the matching lnr_filter_wait returns; the host arrays of a result stay valid until the SECOND next result of the context
- * (two result slots taken in turn: another thread may format batch k while the context runs batch k + 1).
+/* The same in two halves, so that one context overlaps transfers and compute: lnr_filter_submit starts the upload of a batch on a copy
+ * stream and returns; lnr_filter_wait hands out the cords of the oldest submitted batch.  Up to THREE batches may be in flight, and with
+ * the pattern   submit(0); submit(1); loop { submit(k + 2); wait(k); }   the GPU never idles: lnr_filter_wait(k) starts the download of
+ * batch k's cords (batch k was computed during the previous wait) and computes batch k + 1 while they travel; the upload of batch k + 2
+ * runs under those kernels.  (submit(k + 1); wait(k) works as well: upload overlapped, download not.)  The read buffer must stay untouched
+ * until the lnr_filter_wait that RETURNS its batch has returned; the host arrays of a result stay valid until the SECOND next result of the
+ * context (two result slots taken in turn: another thread may format batch k while the context runs on).  lnr_last_stats reports the batch
+ * handed out last.  lnr_gap_stream(set >= 0) and lnr_set_gap need an idle context (nothing in flight).
  * A read buffer in pinned host memory (lnr_host_alloc, or the caller's own hipHostMalloc / hipHostRegister) is uploaded by one
  * DMA at link rate; a pageable one goes through the context's pinned staging buffers first. */
 lnr_status lnr_filter_submit(lnr_ctx *ctx, const uint8_t *reads_concat, const uint64_t *off, uint32_t n);

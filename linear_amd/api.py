@@ -227,16 +227,17 @@ class Filter:
         return a
 
     def filter_submit(self, reads: np.ndarray, off: np.ndarray):
-        """Starts the upload of a batch (at most two in flight); reads/off must stay alive and unchanged until filter_wait."""
+        """Starts the upload of a batch (at most three in flight); reads/off must stay alive and unchanged until the filter_wait that returns it."""
         assert reads.dtype == np.uint8 and reads.flags.c_contiguous and off.dtype == np.uint64 and off.flags.c_contiguous
         self._inflight = getattr(self, "_inflight", [])
-        self._inflight.append((reads, off))
         self._ck(self.lib.lnr_filter_submit(self.h, C.c_void_p(reads.ctypes.data), _p(off, _u64p), off.size - 1))
+        self._inflight.append((reads, off))
 
     def filter_wait(self, copy: bool = True):
         out = LnrCords()
         self._ck(self.lib.lnr_filter_wait(self.h, C.byref(out)))
-        self._inflight.pop(0)
+        if getattr(self, "_inflight", None):
+            self._inflight.pop(0)
         return self._cords_np(out) if copy else (out.n_reads, out.n_cords)
 
     @staticmethod

@@ -7,7 +7,7 @@
 //                  with -o one output for all read files
 //   pipeline       process3 / p_ThreadProcess src/linear.cpp:68-91, src/parallel_io.cpp:372-608 -- ONE fetcher, calculators, ONE printer, output in
 //                  input order -- here: a reader thread (FASTA / FASTQ(.gz) -> pinned blocks), one calculator thread + one lnr_ctx PER GPU (blocks dealt in
-//                  order, two blocks in flight per GPU: the next block's upload runs under the current block's kernels), a writer thread that restores
+//                  order, three blocks in flight per GPU: upload, kernels and download of consecutive blocks overlap), a writer thread that restores
 //                  the file order and formats on -t host threads.
 //   several GPUs   --gpus N (extension): the index is built once on the first GPU and moved to the others with RCCL (lnr_index_broadcast, north_star;
 //                  --index-mode build = every GPU builds its own instead; both times are printed).  Reads shard, nothing else is exchanged.
@@ -129,6 +129,7 @@ template <class T> struct Queue {
     std::mutex m; std::condition_variable cv; std::deque<T> q; bool closed = false;
     void push(T v) { { std::lock_guard<std::mutex> l(m); q.push_back(v); } cv.notify_one(); }
     bool pop(T &v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; v = q.front(); q.pop_front(); return true; }
+    bool try_pop(T &v) { std::lock_guard<std::mutex> l(m); if (q.empty()) return false; v = q.front(); q.pop_front(); return true; }
     void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
 };
 struct Shared {
@@ -233,7 +234,7 @@ int main(int argc, char **argv) {
     // ---- the pipeline
     Shared sh;
     sh.written_upto.assign(G, 0);
-    const unsigned NB = 3 * G + 2;
+    const unsigned NB = 4 * G + 2;
     std::vector<Block> blocks(NB);
     for (auto &b : blocks) {
         b.cap = (uint64_t)o.block_reads * 12000 + (1u << 20);
@@ -273,46 +274,51 @@ int main(int argc, char **argv) {
         }
         sh.ready.close();
     });
-    // calculators: one per GPU, two blocks in flight each
-    auto run_block = [&](unsigned g, Block *b, uint64_t my_count) -> bool {
-        // the result slot this wait will fill was handed out two results ago: the writer must be through with that block
-        { std::unique_lock<std::mutex> l(sh.m); sh.cv.wait(l, [&] { return sh.failed || my_count < 2 || sh.written_upto[g] + 2 > my_count; }); if (sh.failed) return false; }
-        bool serial = false;
-        if (o.gap_len) {
-            std::unique_lock<std::mutex> l(sh.m);
-            sh.cv.wait(l, [&] { return sh.failed || sh.ext || sh.turn == b->seq; });
-            if (sh.failed) return false;
-            serial = !sh.ext;
-            lnr_gap_stream(ctx[g], sh.ext ? 1 : 0, nullptr);
-        }
-        double tg0 = now();
-        lnr_status s = lnr_filter_wait(ctx[g], &b->cords);
-        us_gpu += (uint64_t)((now() - tg0) * 1e6);
-        if (s != LNR_OK) { sh.fail(std::string("filter: ") + lnr_strerror(s) + " (" + lnr_last_error(ctx[g]) + ")"); return false; }
-        if (serial) {
-            int st = 0;
-            lnr_gap_stream(ctx[g], -1, &st);
-            std::lock_guard<std::mutex> l(sh.m);
-            if (st) sh.ext = 1;
-            sh.turn = b->seq + 1;
-            sh.cv.notify_all();
-        }
-        b->worker = (int)g;
-        { std::lock_guard<std::mutex> l(sh.m); sh.done[b->seq] = b; }
-        sh.cv.notify_all();
-        return true;
-    };
+    // calculators: one per GPU.  Free-running (no gap re-mapper, or the read stream has "extended"): three blocks in flight -- lnr_filter_wait hands
+    // out block k while it computes k + 1 and the upload of k + 2 runs.  Before that (-g > 0, stream not extended yet): one block at a time, strictly
+    // in file order across all GPUs, each starting from the state the block before left.
     std::vector<std::thread> workers;
     for (unsigned g = 0; g < G; g++) workers.emplace_back([&, g] {
-        Block *cur = nullptr, *nxt = nullptr;
-        uint64_t count = 0;
-        if (!sh.ready.pop(cur)) return;
-        if (lnr_filter_submit(ctx[g], cur->bases, cur->off.data(), cur->n) != LNR_OK) { sh.fail(std::string("submit: ") + lnr_last_error(ctx[g])); return; }
-        while (cur && !sh.failed) {
-            nxt = nullptr;
-            if (sh.ready.pop(nxt)) { if (lnr_filter_submit(ctx[g], nxt->bases, nxt->off.data(), nxt->n) != LNR_OK) { sh.fail(std::string("submit: ") + lnr_last_error(ctx[g])); return; } }
-            if (!run_block(g, cur, count++)) return;
-            cur = nxt;
+        std::deque<Block *> fl;                 // submitted, not handed out yet
+        uint64_t count = 0;                     // results this context has handed out
+        bool eof = false, free_run = o.gap_len == 0;
+        while (!sh.failed) {
+            size_t depth = free_run ? 3 : 1;
+            while (!eof && fl.size() < depth) {
+                Block *b = nullptr;
+                if (fl.empty()) { if (!sh.ready.pop(b)) { eof = true; break; } }
+                else if (!sh.ready.try_pop(b)) break;
+                if (!free_run) {                 // (the context is idle here: depth 1)
+                    std::unique_lock<std::mutex> l(sh.m);
+                    sh.cv.wait(l, [&] { return sh.failed || sh.ext || sh.turn == b->seq; });
+                    if (sh.failed) return;
+                    if (sh.ext) free_run = true;
+                    l.unlock();
+                    if (lnr_gap_stream(ctx[g], free_run ? 1 : 0, nullptr) != LNR_OK) { sh.fail(std::string("gap stream: ") + lnr_last_error(ctx[g])); return; }
+                }
+                if (lnr_filter_submit(ctx[g], b->bases, b->off.data(), b->n) != LNR_OK) { sh.fail(std::string("submit: ") + lnr_last_error(ctx[g])); return; }
+                fl.push_back(b);
+            }
+            if (fl.empty()) break;
+            Block *b = fl.front();
+            fl.pop_front();
+            // the result slot this wait fills was handed out two results ago: the writer must be through with that block
+            { std::unique_lock<std::mutex> l(sh.m); sh.cv.wait(l, [&] { return sh.failed || count < 2 || sh.written_upto[g] + 2 > count; }); if (sh.failed) return; }
+            double tg0 = now();
+            lnr_status s = lnr_filter_wait(ctx[g], &b->cords);
+            us_gpu += (uint64_t)((now() - tg0) * 1e6);
+            if (s != LNR_OK) { sh.fail(std::string("filter: ") + lnr_strerror(s) + " (" + lnr_last_error(ctx[g]) + ")"); return; }
+            count++;
+            if (!free_run) {
+                int st = 0;
+                lnr_gap_stream(ctx[g], -1, &st);
+                std::lock_guard<std::mutex> l(sh.m);
+                if (st) { sh.ext = 1; free_run = true; }
+                sh.turn = b->seq + 1;
+            }
+            b->worker = (int)g;
+            { std::lock_guard<std::mutex> l(sh.m); sh.done[b->seq] = b; }
+            sh.cv.notify_all();
         }
     });
     // writer: the one printer, in file order (parallel_io.cpp:522-569)

@@ -3,7 +3,8 @@
 //
 // There is no CPU execution path in this library: every stage runs in a HIP kernel, and every entry
 // point fails (LNR_ERR_NO_DEVICE / LNR_ERR_HIP) when no GPU is usable.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>   // device-wide radix sort of the HIndex build (-i 2, once per index): AMD's native primitives library, no CUB layer
 #include "lnr_kernels.hip"
 #include "lnr_gap_args.h"
 #include "../../include/linear_amd.h"
@@ -52,6 +53,7 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     template <class T> T *as() const { return (T *)p; }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(hp, o.hp); std::swap(hcap, o.hcap); }
 };
 
 // pinned host staging (device-to-host copies from pageable memory run at a fraction of the link rate)
@@ -158,15 +160,22 @@ struct lnr_ctx {
     DevBuf hx_nkeys, hx_nvals; u32 hx_nnodes = 0; u64 hx_empty_dir = 0;   // HIndex (-i 2): dir = hdir[2^18] (head of the block of X, -1: none), hs = ysa, nodes of the large blocks
     DevBuf gap_arena, gap_flag, gap_next, d_seq_len, gap_prof, gap_first;
     int gap_ext = 0;        // the read stream's state: 1 once a read of this context's stream went through mapExtend / mapExtends (lnr_gap_stream)   // the gap re-mapper (-g > 0): arenas of its workers, per-read retry flags, the two work counters
+    DevBuf bh;              // header words of the bucket lines as a dense table (k_ix_lines; LNR_SEED_BH=0 turns it off for A/B runs)
+    int use_bh = 0;        // (measured on the GRCh38 stand-in, same box, two runs each: 3.07 - 3.12 ms per launch with the table, 2.97 - 3.00 without: the early line fetch warms L2 / MALL for the DMA)
     DevBuf g, dir, hs, f2, d_seq_off, d_f2_off, bm, bl, ov;   // derived from dir / hs on every GPU: bm = bucket-non-empty bitmap, bl = bucket lines, ov = their aligned overflow lines (k_ix_lines)
     // ---- batch inputs / per-read arrays
     // host-buffer entry points: two input slots, so that the upload of the next batch (copy stream) runs under the kernels of
     // the current one (lnr_filter_submit / lnr_filter_wait)
-    DevBuf in_reads[2], in_off[2];
-    PinBuf h_off[2];
-    hipStream_t s_copy = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr};
-    u32 in_n[2] = {0, 0};
+    DevBuf in_reads[3], in_off[3];       // three input slots: one batch computed ahead + two uploads pending (lnr_filter_submit / lnr_filter_wait)
+    PinBuf h_off[3];
+    hipStream_t s_copy = nullptr, s_down = nullptr;   // uploads / result downloads, each on a stream of its own
+    hipEvent_t ev_in[3] = {nullptr, nullptr, nullptr}, ev_down = nullptr, ev_done = nullptr;
+    // the batch that has been computed but not handed out yet (lnr_filter_wait computes the NEXT submitted batch while the results of the
+    // one it returns travel to the host), and the second set of device result buffers it lives in
+    struct Pre { bool valid = false; lnr_status st = LNR_OK; u32 n = 0; u64 tot = 0; lnr_stats stats; std::vector<u64> coff; const void *d_str = nullptr, *d_end = nullptr; std::string err; } pre;
+    DevBuf rB_off, rB_str, rB_end;
+    lnr_stats stats_pub;                 // statistics of the batch handed out last (what lnr_last_stats reports)
+    u32 in_n[3] = {0, 0, 0};
     int in_head = 0, in_count = 0;
     DevBuf rlen, rks, nf, f1_off, f1, pk, nm, pk_off;
     DevBuf cords, out_str, out_end, cords_off, cords_cap, ncords, nout, read_err;
@@ -272,8 +281,9 @@ lnr_status build_seed_view(lnr_ctx *ctx) {
     if (nov < 0) { ctx->err = "overflow lines of the bucket view exceed 2^31"; return LNR_ERR_LIMIT; }
     ENSURE(ctx->ov, ((u64)nov + 1) * 128);
     ENSURE(ctx->bl, nb * 128);
+    if (ctx->use_bh) ENSURE(ctx->bh, nb * 8 + 16);
     hipLaunchKernelGGL(k_ix_lines, dim3((u32)((nb * 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dir.as<i32>(), ctx->hs.as<u64>(), ovoff.as<i32>(), nb, ctx->bl.as<ulonglong2>(),
-                       ctx->ov.as<u64>());
+                       ctx->ov.as<u64>(), ctx->use_bh ? ctx->bh.as<u64>() : (u64 *)nullptr);
     KCHECK();
     HIPCK(hipStreamSynchronize(ctx->stream));                 // ovoff / tmp go out of scope
     return LNR_OK;
@@ -309,9 +319,9 @@ lnr_status hx_derive(lnr_ctx *ctx) {
         hipLaunchKernelGGL(k_hx_nodes_fill_blk, dim3(1u << HX_XBITS), dim3(256), 0, ctx->stream, ctx->hs.as<u64>(), ctx->dir.as<i32>(), flag.as<i32>(), excl.as<i32>(), k_in.as<u64>(), v_in.as<u32>());
         KCHECK();
         size_t tb = 0;   // stable sort by (X, Y20): equal keys keep ysa order, the lookup takes the first
-        HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in.as<u64>(), ctx->hx_nkeys.as<u64>(), v_in.as<u32>(), ctx->hx_nvals.as<u32>(), nn, 0, 20 + HX_XBITS, ctx->stream));
+        HIPCK(rocprim::radix_sort_pairs(nullptr, tb, k_in.as<u64>(), ctx->hx_nkeys.as<u64>(), v_in.as<u32>(), ctx->hx_nvals.as<u32>(), (size_t)nn, 0u, (unsigned)(20 + HX_XBITS), ctx->stream));
         ENSURE(cub, tb + 16);
-        HIPCK(hipcub::DeviceRadixSort::SortPairs(cub.p, tb, k_in.as<u64>(), ctx->hx_nkeys.as<u64>(), v_in.as<u32>(), ctx->hx_nvals.as<u32>(), nn, 0, 20 + HX_XBITS, ctx->stream));
+        HIPCK(rocprim::radix_sort_pairs(cub.p, tb, k_in.as<u64>(), ctx->hx_nkeys.as<u64>(), v_in.as<u32>(), ctx->hx_nvals.as<u32>(), (size_t)nn, 0u, (unsigned)(20 + HX_XBITS), ctx->stream));
         HIPCK(hipStreamSynchronize(ctx->stream));
     }
     HIPCK(hipStreamSynchronize(ctx->stream));
@@ -407,11 +417,11 @@ lnr_status build_hindex(lnr_ctx *ctx, const u64 *len, u32 nseq, u32 T) {
     // blocks by X ascending, bodies of a block descending (_sort_YSA_Block :600-611): sort by body descending, then stable by X.
     // (The reference's block sort is stable in file order, but the bodies of a block are re-sorted as whole words afterwards.)
     size_t tb1 = 0, tb2 = 0;
-    HIPCK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb1, bodies.as<u64>(), bodies2.as<u64>(), Xs.as<u32>(), Xs2.as<u32>(), (int)n, 0, 64, ctx->stream));
-    HIPCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, Xs2.as<u32>(), Xs.as<u32>(), bodies2.as<u64>(), bodies.as<u64>(), (int)n, 0, HX_XBITS, ctx->stream));
+    HIPCK(rocprim::radix_sort_pairs_desc(nullptr, tb1, bodies.as<u64>(), bodies2.as<u64>(), Xs.as<u32>(), Xs2.as<u32>(), (size_t)n, 0u, 64u, ctx->stream));
+    HIPCK(rocprim::radix_sort_pairs(nullptr, tb2, Xs2.as<u32>(), Xs.as<u32>(), bodies2.as<u64>(), bodies.as<u64>(), (size_t)n, 0u, (unsigned)HX_XBITS, ctx->stream));
     ENSURE(cub, std::max(tb1, tb2) + 16);
-    HIPCK(hipcub::DeviceRadixSort::SortPairsDescending(cub.p, tb1, bodies.as<u64>(), bodies2.as<u64>(), Xs.as<u32>(), Xs2.as<u32>(), (int)n, 0, 64, ctx->stream));
-    HIPCK(hipcub::DeviceRadixSort::SortPairs(cub.p, tb2, Xs2.as<u32>(), Xs.as<u32>(), bodies2.as<u64>(), bodies.as<u64>(), (int)n, 0, HX_XBITS, ctx->stream));
+    HIPCK(rocprim::radix_sort_pairs_desc(cub.p, tb1, bodies.as<u64>(), bodies2.as<u64>(), Xs.as<u32>(), Xs2.as<u32>(), (size_t)n, 0u, 64u, ctx->stream));
+    HIPCK(rocprim::radix_sort_pairs(cub.p, tb2, Xs2.as<u32>(), Xs.as<u32>(), bodies2.as<u64>(), bodies.as<u64>(), (size_t)n, 0u, (unsigned)HX_XBITS, ctx->stream));
     ENSURE(flag, (n + 1) * 4 + 16); ENSURE(cntX, ((size_t)1 << HX_XBITS) * 4);
     HIPCK(hipMemsetAsync(cntX.p, 0, ((size_t)1 << HX_XBITS) * 4, ctx->stream));
     HIPCK(hipMemsetAsync(flag.as<i32>() + n, 0, 4, ctx->stream));
@@ -572,7 +582,8 @@ lnr_status seed_jobs(lnr_ctx *ctx, JobSet &S, const HostJobs &hj, hipStream_t st
             hipLaunchKernelGGL(k_seed_hindex, dim3(nj), dim3(64), 0, st, J, R, ctx->hs.as<u64>(), ctx->info.hs_len, ctx->hx_empty_dir, ctx->dir.as<i32>(), ctx->hx_nkeys.as<u64>(), ctx->hx_nvals.as<u32>(), ctx->hx_nnodes, nj, O,
                                S.est_x16);
         else
-        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), ctx->seed_lds_pad, st, J, R, ctx->bl.as<ulonglong2>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->ov.as<u64>(), nj, O, S.est_x16);
+        hipLaunchKernelGGL(k_seed_fused, dim3(nj), dim3(64), ctx->seed_lds_pad, st, J, R, ctx->bl.as<ulonglong2>(), use_bm ? ctx->bm.as<u32>() : (const u32 *)nullptr, ctx->ov.as<u64>(), nj, O, S.est_x16,
+                           ctx->use_bh ? ctx->bh.as<u64>() : (const u64 *)nullptr);
         KCHECK();
         S.t_seed.stop(st);
         if (f1_reads && attempt == 0) { lnr_status fs = launch_f1(ctx, f1_reads); if (fs != LNR_OK) return fs; }   // (beside the seed kernel instead: measured no faster)
@@ -1092,7 +1103,12 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         // the gap re-mapper on the final cords (k_gap): every read with small arenas, then the flagged reads with large ones
         u32 maxlen = 0;
         for (u32 i = 0; i < n; i++) maxlen = std::max(maxlen, B.len[i]);
-        const u64 budget = (u64)48 << 30;
+        // arena budget of the gap re-mapper's workers: 48 GiB of the 288, never more than lnr_opts.scratch_budget (when given) nor than 80 % of what
+        // is free on the device beside the arena already held -- a second context on the GPU gets fewer workers instead of LNR_ERR_NOMEM
+        u64 budget = (u64)48 << 30;
+        if (ctx->opts.scratch_budget && ctx->opts.scratch_budget < budget) budget = ctx->opts.scratch_budget;
+        { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) { u64 avail = (u64)(((double)fr + (double)ctx->gap_arena.cap) * 0.8); if (avail < budget) budget = avail; } else (void)hipGetLastError(); }
+        if (budget < ((u64)1 << 30)) budget = (u64)1 << 30;
         u64 arena1 = align_up(((u64)512 << 10) * ctx->cap_scale + 16ULL * maxlen + sizeof(LeaderScratch) + 65536, 256);
         u64 arena2 = std::max<u64>(((u64)ctx->gap_arena2_mb << 20) * ctx->cap_scale, arena1 * 2);
         u64 arena3 = std::max<u64>(((u64)64 << 20) * ctx->cap_scale, arena2 * 2);
@@ -1409,6 +1425,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (const char *e = getenv("LNR_CAP_SHRINK")) { long v = atol(e); if (v >= 1 && v <= 4096) ctx->cap_shrink = (u32)v; }
     if (const char *e = getenv("LNR_GAP_MODE")) ctx->gap_mode = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LNR_SEED_BH")) ctx->use_bh = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LNR_GAP_WAVES")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) ctx->gap_waves = (u32)v; }
     if (const char *e = getenv("LNR_GAP_ARENA2_MB")) { long v = atol(e); if (v >= 1 && v <= 1024) ctx->gap_arena2_mb = (u32)v; }
     if (const char *e = getenv("LNR_GAP_TEAM")) ctx->gap_team = atoi(e) ? 1 : 0;
@@ -1442,7 +1459,9 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     ok = ok && hipStreamCreateWithFlags(&ctx->s_multi[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ctx->s_bulk[1], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->s_tail, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; k < 2 && ok; k++) ok = hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->ev_down, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 3 && ok; k++) ok = hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming) == hipSuccess;
     ctx->s_bulk[0] = ctx->s_multi[0];
     if (getenv("LNR_LANE0_BULK_STREAM")) ok = ok && hipStreamCreateWithFlags(&ctx->s_bulk[0], hipStreamNonBlocking) == hipSuccess;   // experiment: own stream for lane 0's single-wave kernel
     ctx->s_multi[1] = ctx->stream;
@@ -1472,7 +1491,10 @@ void lnr_destroy(lnr_ctx *ctx) {
     }
     if (ctx->s_tail) { (void)hipStreamSynchronize(ctx->s_tail); (void)hipStreamDestroy(ctx->s_tail); }
     if (ctx->s_copy) { (void)hipStreamSynchronize(ctx->s_copy); (void)hipStreamDestroy(ctx->s_copy); }
-    for (int k = 0; k < 2; k++) if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
+    if (ctx->s_down) { (void)hipStreamSynchronize(ctx->s_down); (void)hipStreamDestroy(ctx->s_down); }
+    if (ctx->ev_down) (void)hipEventDestroy(ctx->ev_down);
+    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+    for (int k = 0; k < 3; k++) if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
     if (ctx->s_bulk[0] && ctx->s_bulk[0] != ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_bulk[0]);
     if (ctx->s_multi[0]) (void)hipStreamDestroy(ctx->s_multi[0]);
     if (ctx->s_bulk[1]) (void)hipStreamDestroy(ctx->s_bulk[1]);
@@ -1769,7 +1791,9 @@ lnr_status lnr_index_broadcast(lnr_ctx *const *ctxs, uint32_t n, uint32_t root, 
 lnr_status lnr_filter_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_off, uint32_t n, lnr_cords_dev *out) {
     if (!ctx || !d_off || (n && !d_reads)) return LNR_ERR_ARG;
     DevGuard dg_(ctx->device);
+    if (ctx->in_count || ctx->pre.valid) { ctx->err = "batches submitted with lnr_filter_submit are still in flight"; return LNR_ERR_ARG; }
     lnr_status st_ = filter_dev(ctx, d_reads, d_off, n, out);
+    ctx->stats_pub = ctx->stats;
     return st_;
 }
 lnr_status lnr_last_gaps(lnr_ctx *ctx, lnr_gaps *out) {
@@ -1837,27 +1861,70 @@ lnr_status lnr_filter_submit(lnr_ctx *ctx, const uint8_t *reads, const uint64_t 
     if (!ctx) return LNR_ERR_ARG;
     DevGuard dg_(ctx->device);
     if (!ctx->has_index) { ctx->err = "no index"; return LNR_ERR_NO_INDEX; }
-    if (ctx->in_count >= 2) { ctx->err = "two batches already in flight: call lnr_filter_wait first"; return LNR_ERR_ARG; }
-    int slot = (ctx->in_head + ctx->in_count) & 1;
+    if (ctx->in_count + (ctx->pre.valid ? 1 : 0) >= 3) { ctx->err = "three batches already in flight: call lnr_filter_wait first"; return LNR_ERR_ARG; }
+    int slot = (ctx->in_head + ctx->in_count) % 3;
     lnr_status s = submit_reads(ctx, slot, reads, off, n);
     if (s != LNR_OK) return s;
     ctx->in_count++;
     return LNR_OK;
 }
+namespace {
+// runs the oldest submitted batch; its results stay on the device (ctx->pre) until lnr_filter_wait hands them out
+lnr_status compute_submitted(lnr_ctx *ctx) {
+    int slot = ctx->in_head;
+    ctx->in_head = (ctx->in_head + 1) % 3; ctx->in_count--;
+    lnr_ctx::Pre &P = ctx->pre;
+    P.valid = true; P.tot = 0; P.n = ctx->in_n[slot];
+    hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev_in[slot], 0);
+    P.st = e == hipSuccess ? filter_dev(ctx, ctx->in_reads[slot].as<u8>(), ctx->in_off[slot].as<u64>(), ctx->in_n[slot], nullptr, ctx->h_off[slot].as<u64>()) : LNR_ERR_HIP;
+    P.err = ctx->err;
+    P.stats = ctx->stats;
+    if (P.st == LNR_OK) {
+        P.tot = ctx->last_ncords;
+        if (ctx->h_cord_off.size() != (size_t)P.n + 1) ctx->h_cord_off.assign((size_t)P.n + 1, 0);
+        P.coff = ctx->h_cord_off;
+        P.d_str = ctx->r_str.p; P.d_end = ctx->r_end.p;
+    }
+    return P.st;
+}
+}  // namespace
 lnr_status lnr_filter_wait(lnr_ctx *ctx, lnr_cords *out) {
     if (!ctx || !out) return LNR_ERR_ARG;
     DevGuard dg_(ctx->device);
-    if (ctx->in_count == 0) { ctx->err = "no batch in flight"; return LNR_ERR_ARG; }
-    int slot = ctx->in_head;
-    ctx->in_head ^= 1; ctx->in_count--;
-    HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_in[slot], 0));
-    lnr_status s = filter_dev(ctx, ctx->in_reads[slot].as<u8>(), ctx->in_off[slot].as<u64>(), ctx->in_n[slot], nullptr, ctx->h_off[slot].as<u64>());
-    if (s != LNR_OK) return s;
-    return lnr_cords_to_host(ctx, out);
+    if (!ctx->pre.valid) {
+        if (ctx->in_count == 0) { ctx->err = "no batch in flight"; return LNR_ERR_ARG; }
+        compute_submitted(ctx);
+    }
+    // the batch to hand out: its download starts now, on the download stream ...
+    lnr_ctx::Pre P = std::move(ctx->pre);
+    ctx->pre = lnr_ctx::Pre();
+    if (P.st != LNR_OK) { ctx->err = P.err; return P.st; }
+    const int rs = ctx->res_slot;
+    ctx->res_slot ^= 1;
+    PinBuf &hs_ = ctx->h_cords_str2[rs], &he_ = ctx->h_cords_end2[rs];
+    if (!hs_.ensure(std::max<u64>(P.tot * 8, 16)) || !he_.ensure(std::max<u64>(P.tot * 8, 16))) { ctx->err = "pinned host allocation failed"; return LNR_ERR_NOMEM; }
+    ctx->h_cord_off2[rs].swap(P.coff);
+    if (P.tot) {
+        HIPCK(hipEventRecord(ctx->ev_done, ctx->stream));
+        HIPCK(hipStreamWaitEvent(ctx->s_down, ctx->ev_done, 0));
+        HIPCK(hipMemcpyAsync(hs_.p, P.d_str, P.tot * 8, hipMemcpyDeviceToHost, ctx->s_down));
+        HIPCK(hipMemcpyAsync(he_.p, P.d_end, P.tot * 8, hipMemcpyDeviceToHost, ctx->s_down));
+    }
+    HIPCK(hipEventRecord(ctx->ev_down, ctx->s_down));
+    // ... and the next submitted batch is computed meanwhile, into the other set of device result buffers
+    if (ctx->in_count > 0) {
+        ctx->r_off.swap(ctx->rB_off); ctx->r_str.swap(ctx->rB_str); ctx->r_end.swap(ctx->rB_end);
+        compute_submitted(ctx);
+    }
+    HIPCK(hipEventSynchronize(ctx->ev_down));
+    ctx->stats_pub = P.stats;
+    out->n_reads = P.n; out->n_cords = P.tot;
+    out->cord_off = ctx->h_cord_off2[rs].data(); out->cords_str = hs_.as<u64>(); out->cords_end = he_.as<u64>();
+    return LNR_OK;
 }
 lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *off, uint32_t n, lnr_cords *out) {
     if (!ctx || !out) return LNR_ERR_ARG;
-    if (ctx->in_count) { ctx->err = "batches submitted with lnr_filter_submit are still in flight"; return LNR_ERR_ARG; }
+    if (ctx->in_count || ctx->pre.valid) { ctx->err = "batches submitted with lnr_filter_submit are still in flight"; return LNR_ERR_ARG; }
     lnr_status s = lnr_filter_submit(ctx, reads, off, n);
     if (s != LNR_OK) return s;
     return lnr_filter_wait(ctx, out);
@@ -1866,17 +1933,20 @@ lnr_status lnr_filter_batch(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *
 lnr_status lnr_seed_lookup_batch_dev(lnr_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_off, uint32_t n) {
     if (!ctx || !d_off || (n && !d_reads)) return LNR_ERR_ARG;
     DevGuard dg_(ctx->device);
-    return seed_dev(ctx, d_reads, d_off, n, false);
+    lnr_status st_ = seed_dev(ctx, d_reads, d_off, n, false);
+    ctx->stats_pub = ctx->stats;
+    return st_;
 }
 lnr_status lnr_seed_lookup_batch(lnr_ctx *ctx, const uint8_t *reads, const uint64_t *off, uint32_t n, lnr_anchors *out) {
     if (!ctx || !out) return LNR_ERR_ARG;
     DevGuard dg_(ctx->device);
     if (!ctx->has_index) { ctx->err = "no index"; return LNR_ERR_NO_INDEX; }
-    if (ctx->in_count) { ctx->err = "batches submitted with lnr_filter_submit are still in flight"; return LNR_ERR_ARG; }
+    if (ctx->in_count || ctx->pre.valid) { ctx->err = "batches submitted with lnr_filter_submit are still in flight"; return LNR_ERR_ARG; }
     lnr_status s = submit_reads(ctx, 0, reads, off, n);
     if (s != LNR_OK) return s;
     HIPCK(hipStreamWaitEvent(ctx->stream, ctx->ev_in[0], 0));
     if ((s = seed_dev(ctx, ctx->in_reads[0].as<u8>(), ctx->in_off[0].as<u64>(), n, true)) != LNR_OK) return s;
+    ctx->stats_pub = ctx->stats;
     out->n_reads = n; out->n_anchors = ctx->h_anchor_off[n];
     out->anchor_off = ctx->h_anchor_off.data(); out->anchors = ctx->h_anchors.data();
     return LNR_OK;
@@ -1903,6 +1973,7 @@ lnr_status lnr_prof_read(lnr_ctx *ctx, unsigned long long *out16) {
 
 lnr_status lnr_gap_stream(lnr_ctx *ctx, int set, int *state) {
     if (!ctx || set > 1) return LNR_ERR_ARG;
+    if (set >= 0 && (ctx->in_count || ctx->pre.valid)) { ctx->err = "lnr_gap_stream: batches are in flight (the next one may have been computed already)"; return LNR_ERR_ARG; }
     if (set >= 0) ctx->gap_ext = set;
     if (state) *state = ctx->gap_ext;
     return LNR_OK;
@@ -1910,13 +1981,14 @@ lnr_status lnr_gap_stream(lnr_ctx *ctx, int set, int *state) {
 
 lnr_status lnr_set_gap(lnr_ctx *ctx, uint32_t gap_len, uint32_t dup) {
     if (!ctx || dup > 1) return LNR_ERR_ARG;
+    if (ctx->in_count || ctx->pre.valid) { ctx->err = "lnr_set_gap: batches are in flight"; return LNR_ERR_ARG; }
     ctx->opts.gap_len = gap_len; ctx->opts.dup = dup; ctx->gap_ext = 0;
     return LNR_OK;
 }
 
 lnr_status lnr_last_stats(const lnr_ctx *ctx, lnr_stats *st) {
     if (!ctx || !st) return LNR_ERR_ARG;
-    *st = ctx->stats;
+    *st = ctx->stats_pub;
     return LNR_OK;
 }
 

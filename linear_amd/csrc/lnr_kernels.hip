@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(256) k_ix_ovcount(const i32 *dir, u64 nbuckets
     u32 dl = b < nbuckets ? (u32)(dir[b + 1] - dir[b]) : 0u;
     novl[b] = dl > BL_INLINE ? (i32)((dl - BL_INLINE + 15) >> 4) : 0;
 }
-__global__ void __launch_bounds__(256) k_ix_lines(const i32 *dir, const u64 *hs, const i32 *ovoff, u64 nbuckets, ulonglong2 *bl, u64 *ov) {
+__global__ void __launch_bounds__(256) k_ix_lines(const i32 *dir, const u64 *hs, const i32 *ovoff, u64 nbuckets, ulonglong2 *bl, u64 *ov, u64 *bh) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per 16-byte part of a line
     u64 b = t >> 3;
     if (b >= nbuckets) return;
@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(256) k_ix_lines(const i32 *dir, const u64 *hs,
         else w[k] = slot - 1 < dl ? hs[(i64)ds + (i64)(slot - 1)] : 0ULL;
     }
     bl[t] = make_ulonglong2(w[0], w[1]);
+    if (part == 0 && bh) bh[b] = w[0];                       // the header words on their own: what the seed kernel looks at one chunk ahead
     if (dl > BL_INLINE) {                                    // the eight threads of the bucket copy its overflow run
         u32 m = dl - BL_INLINE, mpad = ((m + 15) >> 4) << 4;
         for (u32 i = part; i < mpad; i += 8) ov[(u64)o0 * 16 + i] = i < m ? hs[(i64)ds + BL_INLINE + (i64)i] : 0ULL;
@@ -578,7 +579,7 @@ __device__ inline u32 y_nomatch_push(u32 acc, u32 word, u32 Y) {
     return __builtin_amdgcn_alignbit(acc, d, 31);
 }
 __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, const ulonglong2 *bl, const u32 *bm /* null: table too dense to pay */, const u64 *ov, u32 njobs,
-                                                   SeedOutArrays O, u32 est_per_sample_x16) {
+                                                   SeedOutArrays O, u32 est_per_sample_x16, const u64 *bh /* header words of the bucket lines, densely (null: read them from bl) */) {
     __shared__ uint4 s_rec[64];                // per sample: X, bucket start, bucket length, Y | strand << 8
     __shared__ u32 s_mk[64];                   // sample (lane + 1) whose first line has this number within the round
     __shared__ u64 s_src[64];                  // source address of the round's 64 lines (for the lanes that fetch them)
@@ -656,7 +657,10 @@ __global__ void __launch_bounds__(64) k_seed_fused(JobArrays J, ReadArrays R, co
         looks += (u32)__popcll(__ballot(look));
         u32 xg = o.X >> BM_GROUP_LOG2;
         bool fetch = look && (!bm || ((bm[xg >> 5] >> (xg & 31)) & 1));
-        hdr = fetch ? bl[(u64)o.X * 8].x : 0ULL;
+        // the header comes from the dense table `bh` (8 bytes per bucket): read out of the bucket line itself it brought the whole 128-byte line
+        // on chip one chunk early, and at GRCh38 scale that line was gone from L2 again when the LDS-DMA of step 2 asked for it -- every
+        // bucket line crossed the fabric twice (round 2: 1.78 x the algorithmic bytes)
+        hdr = fetch ? (bh ? bh[o.X] : bl[(u64)o.X * 8].x) : 0ULL;
     };
 #ifndef SEED_PREFETCH
 #define SEED_PREFETCH 1

@@ -71,7 +71,7 @@ class FilterDouble:
 
     def filter_submit(self, reads, off):
         self.inflight = getattr(self, "inflight", 0) + 1
-        assert self.inflight <= 2
+        assert self.inflight <= 3
         self.n = off.size - 1
 
     def filter_wait(self, copy=True):

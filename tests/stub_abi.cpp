@@ -14,7 +14,7 @@
 
 struct lnr_ctx {
     lnr_opts opts; bool has_index = false; int ext = 0;
-    struct Sub { const uint8_t *reads; const uint64_t *off; uint32_t n; } q[2];
+    struct Sub { const uint8_t *reads; const uint64_t *off; uint32_t n; } q[3];
     int head = 0, count = 0, slot = 0;
     std::vector<uint64_t> coff[2], cs[2], ce[2];
     std::string err;
@@ -27,20 +27,20 @@ lnr_status lnr_create(const lnr_opts *o, lnr_ctx **out) { *out = new lnr_ctx(); 
 void lnr_destroy(lnr_ctx *c) { delete c; }
 lnr_status lnr_index_build(lnr_ctx *c, const uint8_t *const *, const uint64_t *, uint32_t, uint32_t) { c->has_index = true; return LNR_OK; }
 lnr_status lnr_index_broadcast(lnr_ctx *const *cs, uint32_t n, uint32_t root, double *sec) { if (!cs[root]->has_index) return LNR_ERR_NO_INDEX; for (uint32_t i = 0; i < n; i++) cs[i]->has_index = true; if (sec) *sec = 0; return LNR_OK; }
-lnr_status lnr_gap_stream(lnr_ctx *c, int set, int *state) { if (set >= 0) c->ext = set; if (state) *state = c->ext; return LNR_OK; }
+lnr_status lnr_gap_stream(lnr_ctx *c, int set, int *state) { if (set >= 0 && c->count) { c->err = "in flight"; return LNR_ERR_ARG; } if (set >= 0) c->ext = set; if (state) *state = c->ext; return LNR_OK; }
 void *lnr_host_alloc(size_t b) { return malloc(b ? b : 16); }
 void lnr_host_free(void *p) { free(p); }
 lnr_status lnr_filter_submit(lnr_ctx *c, const uint8_t *reads, const uint64_t *off, uint32_t n) {
     if (!c->has_index) return LNR_ERR_NO_INDEX;
-    if (c->count >= 2) return LNR_ERR_ARG;
-    c->q[(c->head + c->count) & 1] = {reads, off, n};
+    if (c->count >= 3) return LNR_ERR_ARG;
+    c->q[(c->head + c->count) % 3] = {reads, off, n};
     c->count++;
     return LNR_OK;
 }
 lnr_status lnr_filter_wait(lnr_ctx *c, lnr_cords *out) {
     if (!c->count) return LNR_ERR_ARG;
     lnr_ctx::Sub s = c->q[c->head];
-    c->head ^= 1; c->count--;
+    c->head = (c->head + 1) % 3; c->count--;
     int rs = c->slot; c->slot ^= 1;
     std::vector<uint64_t> &coff = c->coff[rs], &cs = c->cs[rs], &ce = c->ce[rs];
     coff.assign(1, 0); cs.clear(); ce.clear();

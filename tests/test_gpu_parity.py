@@ -243,8 +243,9 @@ def test_gpu_reads_that_begin_inside_an_n_run(oracle_lib):
 
 
 def test_gpu_submit_wait_pipeline_and_pinned_input(case_inputs):
-    """lnr_filter_submit / lnr_filter_wait with two batches in flight, one from pinned memory (lnr_host_alloc: direct DMA) and one
-    from a pageable numpy array (staged): the cords of each batch equal the reference's, in submission order."""
+    """lnr_filter_submit / lnr_filter_wait with three batches in flight (a wait hands out batch k while it computes batch k + 1 and the upload of
+    k + 2 runs), from pinned memory (lnr_host_alloc: direct DMA) and from a pageable numpy array (staged): the cords of each batch equal the
+    reference's, in submission order; a fourth submit is refused; the gap stream cannot be set while batches are in flight."""
     from linear_amd import Filter, LnrError
     refs, reads, off = case_inputs("ont")
     g = np.load(os.path.join(GOLD, "ont_T4.npz"))
@@ -260,14 +261,24 @@ def test_gpu_submit_wait_pipeline_and_pinned_input(case_inputs):
     for _ in range(2):
         f.filter_submit(pin, o1)
         f.filter_submit(r2, o2)
+        f.filter_submit(pin, o1)
         with pytest.raises(LnrError):
-            f.filter_submit(r2, o2)          # a third batch in flight is refused
+            f.filter_submit(r2, o2)          # a fourth batch in flight is refused
+        with pytest.raises(LnrError):
+            f.gap_stream(0)                  # (the next batch may have been computed already)
         c1 = f.filter_wait()
+        f.filter_submit(r2, o2)              # the pipeline stays three deep: 1 handed out, 2 computed ahead, 3 + 4 uploading
         c2 = f.filter_wait()
+        c3 = f.filter_wait()
+        c4 = f.filter_wait()
+        with pytest.raises(LnrError):
+            f.filter_wait()                  # nothing in flight any more
         coff, cs, ce = g["cord_off"], g["cords_str"], g["cords_end"]
         k = int(coff[h])
-        assert np.array_equal(c1[0], coff[: h + 1]) and np.array_equal(c1[1], cs[:k]) and np.array_equal(c1[2], ce[:k])
-        assert np.array_equal(c2[0], coff[h:] - coff[h]) and np.array_equal(c2[1], cs[k:]) and np.array_equal(c2[2], ce[k:])
+        for c in (c1, c3):
+            assert np.array_equal(c[0], coff[: h + 1]) and np.array_equal(c[1], cs[:k]) and np.array_equal(c[2], ce[:k])
+        for c in (c2, c4):
+            assert np.array_equal(c[0], coff[h:] - coff[h]) and np.array_equal(c[1], cs[k:]) and np.array_equal(c[2], ce[k:])
     with pytest.raises(LnrError):
         f.filter_wait()
     bad = np.array([0, 10, 5], dtype=np.uint64)
@@ -463,6 +474,46 @@ def test_gpu_batch_rerun_on_per_read_overflow(case_inputs, monkeypatch):
         f.filter_batch(reads, off)
     assert e.value.status == -8 and "overflow" in str(e.value)
     f.close()
+
+
+@pytest.mark.parametrize("gap_len,dup", [(0, 0), (50, 1)])
+def test_gpu_seqan_side_binding_on_the_gpu(case_inputs, tmp_path, gap_len, dup):
+    """integration/gpu_filter.h -- the file INTEGRATION.md tells a maintainer of the reference to add: SeqAn StringSet<String<Dna5>> in, StringSet<String<
+    uint64_t>> out -- executed on the GPU: tests/_build/gpufilter_driver is compiled against the reference's vendored SeqAn headers by
+    __graft_entry__.build() where the reference tree is (here it is only run).  Two filterBlock calls on one binding; cords equal the goldens."""
+    import struct
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "_build", "gpufilter_driver")
+    if not os.path.exists(exe):
+        if os.path.exists("/root/reference/seqan/include/seqan/sequence.h"):
+            import __graft_entry__ as ge
+            ge.build()
+        else:
+            pytest.fail("tests/_build/gpufilter_driver is missing: __graft_entry__.build() makes it where /root/reference is present")
+    refs, reads, off = case_inputs("edge")
+    n = off.size - 1
+    with open(tmp_path / "case.bin", "wb") as f:
+        f.write(struct.pack("<I", len(refs)))
+        for r in refs:
+            f.write(struct.pack("<Q", r.size)); f.write(np.ascontiguousarray(r, np.uint8).tobytes())
+        f.write(struct.pack("<I", n))
+        for i in range(n):
+            rd = reads[int(off[i]):int(off[i + 1])]
+            f.write(struct.pack("<Q", rd.size)); f.write(np.ascontiguousarray(rd, np.uint8).tobytes())
+    T = 1 if gap_len else 3
+    p = subprocess.run([exe, str(tmp_path / "case.bin"), str(tmp_path / "out.bin"), str(T), str(gap_len), str(dup)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stderr.decode()[-500:])
+    g = np.load(os.path.join(GOLD, "edge_g50_T1.npz" if gap_len else "edge_T3.npz"))
+    sfx = f"_dup{dup}" if gap_len else ""
+    coff, cs, ce = g["cord_off" + sfx], g["cords_str" + sfx], g["cords_end" + sfx]
+    raw = open(tmp_path / "out.bin", "rb").read()
+    assert struct.unpack_from("<I", raw, 0)[0] == n
+    pos = 4
+    for i in range(n):
+        k = struct.unpack_from("<Q", raw, pos)[0]; pos += 8
+        a = np.frombuffer(raw, np.uint64, k, pos); pos += 8 * k
+        b = np.frombuffer(raw, np.uint64, k, pos); pos += 8 * k
+        assert k == int(coff[i + 1] - coff[i]) and np.array_equal(a, cs[int(coff[i]):int(coff[i + 1])]) and np.array_equal(b, ce[int(coff[i]):int(coff[i + 1])]), i
 
 
 def test_gpu_two_pageable_submits_back_to_back(flt, case_inputs):
