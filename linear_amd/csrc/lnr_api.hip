@@ -158,7 +158,7 @@ struct lnr_ctx {
     u32 overflow_reruns = 0;
     u32 seed_lds_pad = 0;   // diagnostic (LNR_SEED_LDS_PAD): dynamic LDS the seed kernel does not use, to lower its waves per CU
     DevBuf hx_nkeys, hx_nvals; u32 hx_nnodes = 0; u64 hx_empty_dir = 0;   // HIndex (-i 2): dir = hdir[2^18] (head of the block of X, -1: none), hs = ysa, nodes of the large blocks
-    DevBuf gap_arena, gap_flag, gap_next, d_seq_len, gap_prof, gap_first;
+    DevBuf gap_arena, gap_flag, gap_next, d_seq_len, gap_prof, gap_first, gap_list, gap_rank;
     int gap_ext = 0;        // the read stream's state: 1 once a read of this context's stream went through mapExtend / mapExtends (lnr_gap_stream)   // the gap re-mapper (-g > 0): arenas of its workers, per-read retry flags, the two work counters
     DevBuf bh;              // header words of the bucket lines as a dense table (k_ix_lines; LNR_SEED_BH=0 turns it off for A/B runs)
     int use_bh = 0;        // (measured on the GRCh38 stand-in, same box, two runs each: 3.07 - 3.12 ms per launch with the table, 2.97 - 3.00 without: the early line fetch warms L2 / MALL for the DMA)
@@ -210,6 +210,7 @@ struct lnr_ctx {
     lnr_stats stats{};
     Timer t_prep, t_job, t_tail, t_total, t_gap;
     int gap_mode = 1, gap_team = 1; u32 gap_waves = 16384, gap_arena2_mb = 64;   // LNR_GAP_TEAM=0: one wave per flagged read, no helper waves   // LNR_GAP_MODE=1: the first launch of k_gap runs one wave per read as well (LNR_GAP_WAVES of them)
+    u32 gap_cap_ms = 0;    // first launch of the gap re-mapper: milliseconds after which a read is handed to the team launch (LNR_GAP_CAP_MS, 0 = never)
     u64 gap_work_cap = 3000000;   // pair evaluations of the chain DPs one lane spends on a read before the read goes to the wave-per-read launch (LNR_GAP_WORK_CAP)
 };
 
@@ -1130,8 +1131,8 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         G.arena = (char *)ctx->gap_arena.p;
         G.prof = nullptr;
 #ifdef LNR_GAP_DEVPROF
-        ENSURE(ctx->gap_prof, (96 + (size_t)n) * 8);
-        HIPCK(hipMemsetAsync(ctx->gap_prof.p, 0, (96 + (size_t)n) * 8, ctx->stream));
+        ENSURE(ctx->gap_prof, (96 + 3 * (size_t)n) * 8);
+        HIPCK(hipMemsetAsync(ctx->gap_prof.p, 0, (96 + 3 * (size_t)n) * 8, ctx->stream));
         G.prof = ctx->gap_prof.as<unsigned long long>();
 #endif
         G.gap_len_min = ctx->opts.gap_len == 1 ? 50 : (ctx->opts.gap_len < 10 ? 10 : ctx->opts.gap_len);   // mapper.cpp:438-453
@@ -1139,6 +1140,9 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         ctx->t_gap.start(ctx->stream);
         ENSURE(ctx->gap_first, 64);
         G.first_ext = ctx->gap_first.as<u32>();
+        ENSURE(ctx->gap_rank, ((size_t)n + 16) * 4);
+        ENSURE(ctx->gap_list, ((size_t)n + 16) * 4);
+        G.list = ctx->gap_list.as<u32>() + 16; G.list_n = ctx->gap_list.as<u32>();
         // one "ladder" = the three launches (small arenas for every read of [lo, hi), then the flagged reads with larger ones)
         auto ladder = [&](u32 lo, u32 hi, u32 ext_from, int probe) -> hipError_t {
             hipError_t e = hipMemsetAsync(ctx->gap_next.p, 0, 256, ctx->stream);
@@ -1146,12 +1150,17 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
             u32 m = hi - lo;
             G.lo = lo; G.n = hi; G.ext_from = ext_from; G.probe = probe;
             G.work_cap = ctx->gap_work_cap;
+            if ((e = launch_gap_rank(G.nout, G.off, lo, hi, ctx->gap_rank.as<u32>(), ctx->stream)) != hipSuccess) return e;
+            G.order = ctx->gap_rank.as<u32>();
+            G.cap_ticks = (u64)ctx->gap_cap_ms * 100000ULL;
             G.arena_bytes = arena1; G.next = ctx->gap_next.as<u32>(); G.big = 0; G.last = 0; G.coop = ctx->gap_mode;
             u32 v1 = std::min<u32>(w1, (u32)align_up(m, 64));
             if ((e = launch_gap(G, 0, ctx->gap_mode ? v1 : v1 / 64, ctx->stream)) != hipSuccess) return e;
-            G.work_cap = ~0ULL;
+            G.work_cap = ~0ULL; G.cap_ticks = 0;
+            if ((e = launch_gap_order(G.gap_flag, lo, hi, ctx->gap_list.as<u32>() + 16, ctx->gap_list.as<u32>(), ctx->stream)) != hipSuccess) return e;
             G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1; G.coop = 1;
             if ((e = launch_gap(G, ctx->gap_team, std::min(w2, m), ctx->stream)) != hipSuccess) return e;
+            if ((e = launch_gap_order(G.gap_flag, lo, hi, ctx->gap_list.as<u32>() + 16, ctx->gap_list.as<u32>(), ctx->stream)) != hipSuccess) return e;
             G.arena_bytes = arena3; G.next = ctx->gap_next.as<u32>() + 24; G.last = 1;
             return launch_gap(G, ctx->gap_team, std::min(w3, m), ctx->stream);
         };
@@ -1186,6 +1195,25 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
                 const unsigned long long *w = hp + 48 + 16 * L;
                 fprintf(stderr, "[gap prof]    slowest read: index %llu, length %llu, cords in %llu, arena high-water %llu bytes\n", w[10], w[11], w[12], w[13]);
                 for (int k = 0; k < 10; k++) fprintf(stderr, "[gap prof]    %-26s %10.1f ms  %5.1f %%   slowest read: %8.1f ms\n", nm[k], q[k] / 1e5, q[11] ? 100.0 * q[k] / q[11] : 0.0, w[k] / 1e5);
+            }
+            fprintf(stderr, "[gap prof] first launch: at most %llu workers (waves) alive at once\n", hp[95]);
+            {   // reads in flight over the first launch's duration (start / end ticks of every read, 10 ns)
+                std::vector<unsigned long long> se(2 * (size_t)n);
+                HIPCK(hipMemcpy(se.data(), (char *)ctx->gap_prof.p + (96 + (size_t)n) * 8, 2 * (size_t)n * 8, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ULL, t1 = 0;
+                for (u32 i = 0; i < n; i++) if (se[i]) { t0 = std::min(t0, se[i]); t1 = std::max(t1, se[n + i]); }
+                if (t1 > t0) {
+                    const int NBK = 20;
+                    std::vector<double> busy(NBK, 0.0);
+                    double span = (double)(t1 - t0), bw = span / NBK;
+                    for (u32 i = 0; i < n; i++) if (se[i]) {
+                        double a = (double)(se[i] - t0), b = (double)(se[n + i] - t0);
+                        for (int k = (int)(a / bw); k < NBK && k * bw < b; k++) busy[k] += std::min(b, (k + 1) * bw) - std::max(a, k * bw);
+                    }
+                    fprintf(stderr, "[gap prof] first launch: %.1f ms from the first read's start to the last read's end; mean reads in flight per twentieth:", span / 1e5);
+                    for (int k = 0; k < NBK; k++) fprintf(stderr, " %.0f", busy[k] / bw);
+                    fprintf(stderr, "\n");
+                }
             }
             std::vector<unsigned long long> pr(n);
             HIPCK(hipMemcpy(pr.data(), (char *)ctx->gap_prof.p + 96 * 8, (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -1425,6 +1453,7 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (const char *e = getenv("LNR_CAP_SHRINK")) { long v = atol(e); if (v >= 1 && v <= 4096) ctx->cap_shrink = (u32)v; }
     if (const char *e = getenv("LNR_GAP_MODE")) ctx->gap_mode = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LNR_GAP_CAP_MS")) { long v = atol(e); if (v >= 0 && v <= 100000) ctx->gap_cap_ms = (u32)v; }
     if (const char *e = getenv("LNR_SEED_BH")) ctx->use_bh = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LNR_GAP_WAVES")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) ctx->gap_waves = (u32)v; }
     if (const char *e = getenv("LNR_GAP_ARENA2_MB")) { long v = atol(e); if (v >= 1 && v <= 1024) ctx->gap_arena2_mb = (u32)v; }

@@ -29,6 +29,11 @@ struct GapArgs {
     // gap_util.cpp:4052,4091; read by chainTiles :1188).  Reads [lo, n) are processed; those with index >= ext_from start "extended".
     // probe: nothing is written back -- the launch only finds the first read that extends (atomicMin into *first_ext).
     u32 lo; u32 ext_from; int probe; u32 *first_ext;
+    // the launches for the flagged reads take them from a list ordered heaviest first (k_gap_order: gap_flag[r] - 1 = the arena request that did not
+    // fit, in KiB) -- launched in index order the read that alone sets the launch's duration started as late as a third of the way in
+    const u32 *list; const u32 *list_n;
+    u64 cap_ticks;           // first launch: a read still busy after this many 10 ns ticks is left to the team launch (0 = no limit)
+    const u32 *order;        // first launch: reads [lo, n) by decreasing uncovered length (k_gap_rank) -- the long ones start first, the launch's tail is short ones
 };
 
 #ifndef K_GAP_TEAM
@@ -36,5 +41,10 @@ struct GapArgs {
 #endif
 // launches k_gap (team = 0: one wave per workgroup) or k_gap_team (K_GAP_TEAM waves per workgroup) on `grid` workgroups
 hipError_t launch_gap(const GapArgs &A, int team, unsigned grid, hipStream_t stream);
+// the flagged reads of [lo, n) into list[0 .. *list_n), heaviest first (one workgroup; more than GAP_LIST_SORT_MAX stay in index order)
+#define GAP_LIST_SORT_MAX 4096
+hipError_t launch_gap_order(const u32 *gap_flag, unsigned lo, unsigned n, u32 *list, u32 *list_n, hipStream_t stream);
+// order[0 .. n - lo) = the reads of [lo, n) by decreasing (read length - 96 x cords): what is left uncovered is what the gap re-mapper works on
+hipError_t launch_gap_rank(const u32 *nout, const u64 *off, unsigned lo, unsigned n, u32 *order, hipStream_t stream);
 
 }  // namespace lnr

@@ -15,14 +15,14 @@ namespace lnr {
 
 // ---- arena + growable array of the gap path: temporaries of one gap are released together (mark / release)
 struct GArena {
-    char *base; u64 off, cap, hw; int ovf;
+    char *base; u64 off, cap, hw, want = 0; int ovf;   // want: the request that did not fit (what the next launch orders the flagged reads by)
     // the first 64 bytes are the dump: what a vector that could not be allocated points at (capacity 0), so that a stray element
     // access after an overflow stays inside the arena.  ovf: 1 = out of memory, 2 = over the work budget (both: the read is redone
     // with a larger arena / by the cooperative form, or reported)
     LNR_HD void init(void *b, u64 c) { base = (char *)b; off = 64; cap = c; ovf = c < 64 ? 1 : 0; hw = 0; }
     LNR_HD void *get(u64 bytes) {
         bytes = (bytes + 15) & ~15ULL;
-        if (ovf || off + bytes > cap) { if (!ovf) ovf = 1; return (void *)base; }   // (raw users check ovf before touching the block; GVec falls back to capacity 0)
+        if (ovf || off + bytes > cap) { if (!ovf) { ovf = 1; want = bytes; } return (void *)base; }   // (raw users check ovf before touching the block; GVec falls back to capacity 0)
         void *r = base + off; off += bytes; if (off > hw) hw = off; return r;
     }
     LNR_HD u64 mark() const { return off; }
@@ -116,6 +116,7 @@ struct GapCtx {                                           // one read
     FeatView f1[2]; GenomeFeat gf;
     GapParms gp;
     u64 work = 0, work_cap = ~0ULL;                       // pair evaluations of the chain DPs so far / the budget (over it: ar->ovf = 2)
+    u64 deadline = 0;                                     // device, first launch: wall_clock64() after which the read is given up and left to the team launch (ovf = 2); 0 = none
     int coop = 0;                                         // device: all 64 lanes of the wave run this read together (k_gap, second launch)
     int team = 0; struct GapTeam *tm = nullptr;           // device: helper waves of the workgroup for the long rows of the chain DP (k_gap_team)
 #ifdef LNR_GAP_DEVPROF
@@ -124,6 +125,15 @@ struct GapCtx {                                           // one read
     LNR_HD GSeq ref(u64 id) const { GSeq s; s.p = g + seq_off[id]; s.len = seq_len[id]; return s; }
 };
 
+// The first launch runs one wave per read and ends when its slowest read does: a read that is still busy after the deadline is abandoned there
+// (like one that outgrew its arena: ovf = 2, its apxMap cords stay) and redone by the team launch, which has idle CUs to spare while the handful
+// of truly heavy reads set its duration.  Which launch a read ends up in does not change its result.
+LNR_HD inline bool gap_late(GapCtx &X) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (X.deadline && !X.ar->ovf && wall_clock64() > X.deadline) X.ar->ovf = 2;
+#endif
+    return X.ar->ovf != 0;
+}
 #if defined(LNR_GAP_DEVPROF) && defined(__HIP_DEVICE_COMPILE__)
 struct GpScope { GapCtx &X; int i; unsigned long long t0; __device__ GpScope(GapCtx &x, int k) : X(x), i(k), t0(wall_clock64()) {} __device__ ~GpScope() { X.prof[i] += wall_clock64() - t0; } };
 #define GP(X, k) GpScope _gp_scope(X, k)
@@ -131,6 +141,18 @@ struct GpScope { GapCtx &X; int i; unsigned long long t0; __device__ GpScope(Gap
 #define GP(X, k) do {} while (0)
 #endif
 
+// the comparators of the gap path's sorts as ONE type (the team form of the sort hands it to the helper waves through LDS)
+struct GapCmp {
+    int kind; u64 mask;      // 1 stranchor ascending (filterGapAnchors), 2 x descending (chains), 3 masked word ascending (k-mer list), 4 word ascending
+    LNR_HD bool operator()(const u64 &a, const u64 &b) const {
+        switch (kind) {
+            case 1: return ganc_stranchor(a) < ganc_stranchor(b);
+            case 2: return ganc_x(a) > ganc_x(b);
+            case 3: return (a & mask) < (b & mask);
+            default: return a < b;
+        }
+    }
+};
 // std::sort of the gap path.  Host and lane-per-read form: ref_sort (libstdc++'s introsort, serial).  Wave-per-read form: the same
 // algorithm with the partitions of the large ranges done by all 64 lanes and the small ranges finished one per lane
 // (gap_sort_wave, lnr_kernels.hip: the list formulation of ref_sort.h) -- same permutation, ties included.
@@ -258,7 +280,10 @@ struct GAncBand {
         return t < base + acc && t >= lo;
     }
 };
-LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, int p2, int k, u64 rvcp, i64 lower, i64 upper, u64 gap_str, u64 gap_end, int direction, const GapParms &gp, int coop = 0) {
+#if defined(__HIPCC__)
+__device__ inline bool gap_join_team(GapCtx &X, const GVec<u64> &g_hs, GVec<u64> &out, int p1, int p2, int k, int kind, u64 rvcp, i64 lower, i64 upper, const GAncBand *B);
+#endif
+LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, int p2, int k, u64 rvcp, i64 lower, i64 upper, u64 gap_str, u64 gap_end, int direction, const GapParms &gp, int coop = 0, GapCtx *Xp = nullptr) {
     if (out.ar->ovf) return;
     GAncBand B;
     B.direction = direction; B.lower = lower; B.upper = upper; B.strand = cord_strand(gap_str);
@@ -267,6 +292,7 @@ LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, 
     B.d_anchor = (i64)((1LL << 7) * gp.thd_gmsa_d_anchor_rate);
 #if defined(__HIP_DEVICE_COMPILE__)
     if (coop) {                                              // the block's (reference k-mer, read k-mer) pairs, 64 at a time in pair order (i major)
+        if (Xp && gap_join_team(*Xp, g_hs, out, p1, p2, k, 0, rvcp, 0, 0, &B)) return;   // (a big block on a team: all waves)
         const int lane = (int)(threadIdx.x & 63);
         const u32 ni = (u32)(p2 - p1), nj = (u32)(k - p2), np = ni * nj;
         for (u32 pb = 0; pb < np; pb += 64) {
@@ -293,7 +319,7 @@ LNR_HD inline void g_set_anchors(const GVec<u64> &g_hs, GVec<u64> &out, int p1, 
 }
 template <class F> LNR_HD inline void g_hs_blocks(GVec<u64> &g_hs, int shape_len, GapCtx &X, F &&emit) {
     u64 mask = (1ULL << (2 * shape_len + 33)) - 1;
-    { GP(X, 0); gap_sort(g_hs.p, (long)g_hs.n, [mask](const u64 &a, const u64 &b) { return (a & mask) < (b & mask); }, X); }
+    { GP(X, 0); gap_sort(g_hs.p, (long)g_hs.n, GapCmp{3, mask}, X); }
     GP(X, 1);
     int p1 = 0, p2 = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -325,17 +351,17 @@ template <class F> LNR_HD inline void g_hs_blocks(GVec<u64> &g_hs, int shape_len
     }
 }
 LNR_HD inline void g_create_anchors(GVec<u64> &g_hs, GVec<u64> &anchors, int shape_len, int direction, i64 lower, i64 upper, u64 rvcp, u64 gap_str, u64 gap_end, GapCtx &X) {
-    g_hs_blocks(g_hs, shape_len, X, [&](int p1, int p2, int k) { g_set_anchors(g_hs, anchors, p1, p2, k, rvcp, lower, upper, gap_str, gap_end, direction, X.gp, X.coop); });
+    g_hs_blocks(g_hs, shape_len, X, [&](int p1, int p2, int k) { g_set_anchors(g_hs, anchors, p1, p2, k, rvcp, lower, upper, gap_str, gap_end, direction, X.gp, X.coop, &X); });
 }
 LNR_HD inline void g_create_anchor_pair(GVec<u64> &g_hs, GVec<u64> &a1, GVec<u64> &a2, int shape_len, u64 rvcp, u64 gs1, u64 ge1, u64 gs2, u64 ge2, GapCtx &X) {
     g_hs_blocks(g_hs, shape_len, X, [&](int p1, int p2, int k) {
-        g_set_anchors(g_hs, a1, p1, p2, k, rvcp, 0, 0, gs1, ge1, 1, X.gp, X.coop);
-        g_set_anchors(g_hs, a2, p1, p2, k, rvcp, 0, 0, gs2, ge2, -1, X.gp, X.coop);
+        g_set_anchors(g_hs, a1, p1, p2, k, rvcp, 0, 0, gs1, ge1, 1, X.gp, X.coop, &X);
+        g_set_anchors(g_hs, a2, p1, p2, k, rvcp, 0, 0, gs2, ge2, -1, X.gp, X.coop, &X);
     });
 }
 LNR_HD inline void c_create_anchors2(GVec<u64> &g_hs, GVec<u64> &out, i64 lower, i64 upper, SortStack &st, GapCtx *Xp = nullptr) {
     int p1 = 0, p2 = 0;
-    if (Xp) gap_sort(g_hs.p, (long)g_hs.n, [](const u64 &a, const u64 &b) { return a < b; }, *Xp);
+    if (Xp) gap_sort(g_hs.p, (long)g_hs.n, GapCmp{4, 0}, *Xp);
     else ref_sort(g_hs.p, (long)g_hs.n, [](const u64 &a, const u64 &b) { return a < b; }, st);
 #if defined(__HIP_DEVICE_COMPILE__)
     if (Xp && Xp->coop) {
@@ -352,7 +378,9 @@ LNR_HD inline void c_create_anchors2(GVec<u64> &g_hs, GVec<u64> &out, i64 lower,
                 int k = (int)base + bb;
                 if ((m1 >> bb) & 1) { p2 = k; continue; }
                 if (out.ar->ovf) return;
-                const u32 ni = (u32)(p2 - p1), nj = (u32)(k - p2), np = p2 > p1 && k > p2 ? ni * nj : 0;
+                const u32 ni = (u32)(p2 - p1), nj = (u32)(k - p2);
+                u32 np = p2 > p1 && k > p2 ? ni * nj : 0;
+                if (np && gap_join_team(*Xp, g_hs, out, p1, p2, k, 1, 0, lower, upper, nullptr)) np = 0;   // (a big block on a team)
                 for (u32 pb = 0; pb < np; pb += 64) {
                     u32 q = pb + lane;
                     u32 qi = q / nj, qj = q - qi * nj;
@@ -479,6 +507,35 @@ LNR_HD inline int gap_block_score3(u64 c11, u64 c12, u64 c21, u64 c22, u64 L, in
     return (int)(100 - s_da - m * (m + 450) / 2000);
 }
 
+// ---- the three DP scores as functions of (dx, dy) of a same-strand pair that passed the cheap tests of the column DP (gap_dp_columns): what
+// gap_anchor_score1_pos / gap_anchor_score2_pos / gap_clip_score compute behind their rejections (da = |dx - dy| because the strands are equal).
+// fn 1: dx >= 0, 0 <= dy < 245, da < 64;  fn 2: 0 <= dy < 128, da < 64, dx < 4096;  fn 5: 1 <= dy < 31, da < 59.  tests/test_gap_shim_cpu.py
+// compares them with the anchor forms over those boxes.
+LNR_HD inline int gap_score_delta(int fn, u32 dx, u32 dy) {
+    u32 da = dx > dy ? dx - dy : dy - dx;
+    if (fn == 1) {
+        u32 m = dy > 50 ? dy : 50, derr = (100u * da) / m;
+        i32 s_derr = derr < 10 ? 0 : (derr < 15 ? (i32)(10 + 2 * derr) : (i32)(derr * derr / 10 + 40));
+        i32 s_dy = dy < 100 ? (i32)(dy / 4) : (dy < 200 ? (i32)(dy / 3) - 9 : (i32)dy - 145);
+        return 100 - s_dy - s_derr;
+    }
+    if (fn == 2) {
+        u32 m = dx > dy ? dx : dy; if (m < 50) m = 50;
+        u32 derr = (100u * da) / m;
+        i32 s_derr = derr < 5 ? (i32)(4 * derr) : (derr < 10 ? (i32)(6 * derr) - 10 : (i32)(derr * derr - 5 * derr));
+        return 100 - (i32)(dy * (dy + 300) / 300) - s_derr;
+    }
+    i32 s_da = da < 2 ? (i32)(30 + 5 * da) : (da < 5 ? (i32)(36 + 2 * da) : (i32)(41 + da));
+    return 100 - (i32)(dy * (12 * dy + 650) / 450) - s_da;
+}
+// the cheap tests: is (dx, dy) inside the box outside of which the score cannot be positive, and not one of the rejected near pairs
+LNR_HD inline bool gap_score_box(int fn, u32 dx, i32 dy) {
+    u32 da = (i32)dx > dy ? dx - (u32)dy : (u32)dy - dx;
+    if (fn == 1) return (u32)dy < 245u && da < 64u && !(dx < 8 && (i32)dx != dy);
+    if (fn == 2) return (u32)dy < 128u && da < 64u && dx < 4096u && !((dx < 8 || dy < 8) && (i32)dx != dy);
+    return (u32)(dy - 1) < 30u && da < 59u && !((dx < 3 || dy < 3) && (i32)dx != dy);
+}
+
 // ---- X-drop on a chain by gap lengths (dropChainGapX gap_util.cpp:757-803), on tiles
 LNR_HD inline void drop_chain_gap_x(GVec<u64> &ch, int direction, const GapParms &gp) {
     int n = (int)ch.n;
@@ -509,7 +566,14 @@ LNR_HD inline int gap_dp_score(int fn, u64 a, u64 b) { return fn == 2 ? gap_anch
 #ifndef K_GAP_TEAM_ROW
 #define K_GAP_TEAM_ROW 2048   // predecessors of the previous row from which a row is dealt over the team (two barriers per row)
 #endif
-struct GapTeam { const u64 *anchors; const i32 *score; u64 ai, dx_depth; int i, j_str, fn, cmd; u64 part[16]; Rec rec; u32 n, depth; int dup; };   // cmd: 0 exit, 1 one long row, 2 a whole DP by columns
+struct GStage { u32 x, y, z, w; };
+struct GapTeam { const u64 *anchors; const i32 *score; u64 ai, dx_depth; int i, j_str, fn, cmd; u64 part[16]; Rec rec; u32 n, depth; int dup; u32 ncols; u32 *xs, *ys;
+                 u64 *s_a; u32 *s_L, *s_R; u64 *s_tasks; const u64 *s_queue; u32 s_nq, s_next; GapCmp s_cmp;     // cmd 3: the ranges of a big sort dealt over the waves
+                 const u64 *j_hs; u64 *j_out; u32 j_p1, j_p2, j_k; int j_kind, j_pass; u64 j_rvcp; i64 j_lower, j_upper; GAncBand j_band;   // cmd 4: the pairs of a big k-mer block
+                 GStage stage[16][128]; };   // cmd: 0 exit, 1 one long row, 2 a whole DP by columns; xs / ys: x and y | strand << 24 of the anchors; stage: per wave, the pairs that passed the cheap tests
+#ifndef K_GAP_COL_MEAN
+#define K_GAP_COL_MEAN 12     // mean anchors per column from which the column form pays (one workgroup barrier per column)
+#endif
 #ifndef K_GAP_COL_MIN
 #define K_GAP_COL_MIN 1024    // anchors from which a chain DP is run column by column on the whole team
 #endif
@@ -555,47 +619,90 @@ __device__ inline u64 gap_dp_row_share(const u64 *anchors, const i32 *rscore, u6
 // or i - depth, i - 1], of which [c0, i - 1] cannot score; ties keep the smallest j (the key's low word).  Identical anchor words inside a
 // column (never produced by the joins; checked all the same) set *dup and the caller falls back to the single-wave form.
 template <class Score>
-__device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 depth, u64 dx_depth, Score score, int w, int nw, int *dup) {
+__device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 depth, u64 dx_depth, Score score, int fn, int w, int nw, GapTeam *tm) {
     const int lane = (int)(threadIdx.x & 63);
+    u32 *XS = tm->xs, *YS = tm->ys;
+    GStage *stage = tm->stage[w];
+    // x and y | strand << 24 of every anchor, once: the scan below then costs a dozen 32-bit instructions per predecessor, and only the pairs
+    // inside the box of the score function (a few per cent) are staged in LDS and scored, 64 at a time
+    u32 myc = 0;
+    for (u32 i = (u32)w * 64 + (u32)lane; i < n; i += (u32)nw * 64) {
+        u64 a = anchors[i];
+        u32 x = (u32)ganc_x(a);
+        XS[i] = x; YS[i] = (u32)ganc_y(a) | ((u32)ganc_strand(a) << 24);
+        myc += (i == 0 || (u32)ganc_x(anchors[i - 1]) != x) ? 1u : 0u;
+    }
+    myc = wave_sum(myc);
+    if (lane == 0 && myc) atomicAdd(&tm->ncols, myc);
+    __syncthreads();
+    // columns of a few anchors each would be one workgroup barrier per few rows: the single-wave form (the last 64 records in registers) is the
+    // better one there -- every wave sees the same count and leaves; wave 0 then runs that form (dup = 2: not a duplicate, just "not by columns")
+    if ((u64)tm->ncols * K_GAP_COL_MEAN > (u64)n) { if (w == 0 && lane == 0) tm->dup = 2; __syncthreads(); return; }
+    const u32 dxd = (u32)dx_depth;
     u32 c0 = 0;
     while (c0 < n) {
-        const u64 x0 = ganc_x(anchors[c0]);
+        const u32 x0 = XS[c0];
         u32 c1 = c0 + 1;
         for (;;) {
             u32 idx = c1 + (u32)lane;
-            bool same = idx < n && ganc_x(anchors[idx]) == x0;
+            bool same = idx < n && XS[idx] == x0;
             u64 m = __ballot(!same);
             if (m) { c1 += (u32)__builtin_ctzll(m); break; }
             c1 += 64;
         }
         for (u32 i = c0 + (u32)w; i < c1; i += (u32)nw) {
             const u64 ai = anchors[i];
+            const u32 ysi = YS[i];
             const int j_str = (int)i - (int)depth < 0 ? 0 : (int)i - (int)depth;
             bool twin = false;
             for (u32 jb = c0; jb < i; jb += 64) { u32 j = jb + (u32)lane; twin = twin || (j < i && anchors[j] == ai); }
-            if (__any(twin)) { if (lane == 0) *dup = 1; }
+            if (__any(twin)) { if (lane == 0) tm->dup = 1; }
             u64 key = 0;
+            {   // the last `depth` predecessors whatever their distance (those of this column cannot score): the anchor form of the score
+                int j = (int)c0 - 1 - lane;
+                if (j >= j_str && j >= 0) {
+                    int sc = score(anchors[j], ai);
+                    if (sc > 0) key = ((u64)(u32)(sc + r.score[j]) << 32) | (u64)(0xffffffffu - (u32)j);
+                }
+            }
+            u32 nst = 0;
+            auto flush = [&](u32 cnt) {                        // the first cnt (<= 64) staged pairs are scored
+                WLDS();
+                GStage e = stage[lane];
+                if ((u32)lane < cnt) {
+                    int sc = gap_score_delta(fn, e.x, e.y);
+                    if (sc > 0) { u64 k = ((u64)(u32)(sc + (i32)e.z) << 32) | (u64)(0xffffffffu - e.w); key = k > key ? k : key; }
+                }
+                if (nst > cnt) { GStage t = stage[64 + lane]; WLDS(); if ((u32)lane < nst - cnt) stage[lane] = t; }
+                nst -= cnt;
+                WLDS();
+            };
             for (int jb = (int)c0 - 1; jb >= 0; jb -= 256) {
-                u64 av[4]; i32 sv[4];
+                u32 xv[4], yv[4]; i32 sv[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     int j2 = jb - 64 * u - lane;
-                    av[u] = j2 >= 0 ? anchors[j2] : 0;
-                    sv[u] = j2 >= 0 ? r.score[j2] : 0;
+                    xv[u] = j2 >= 0 ? XS[j2] : 0u; yv[u] = j2 >= 0 ? YS[j2] : 0u; sv[u] = j2 >= 0 ? r.score[j2] : 0;
                 }
                 bool stop = false;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     int j2 = jb - 64 * u - lane;
-                    bool ok = j2 >= 0 && (j2 >= j_str || ganc_x(av[u]) - x0 < dx_depth);
-                    if (ok) {
-                        int sc = score(av[u], ai);
-                        if (sc > 0) { u64 k = ((u64)(u32)(sc + sv[u]) << 32) | (u64)(0xffffffffu - (u32)j2); key = k > key ? k : key; }
+                    u32 dx = xv[u] - x0;
+                    bool ok = j2 >= 0 && dx < dxd;
+                    i32 dy = (i32)(yv[u] - ysi);                 // (another strand: bit 24 differs, far outside every box)
+                    bool pass = ok && gap_score_box(fn, dx, dy);
+                    u64 m = __ballot(pass);
+                    if (m) {
+                        if (pass) { GStage e_; e_.x = dx; e_.y = (u32)dy; e_.z = (u32)sv[u]; e_.w = (u32)j2; stage[nst + (u32)__popcll(m & ((1ULL << lane) - 1))] = e_; }
+                        nst += (u32)__popcll(m);
+                        if (nst >= 64) flush(64);
                     }
                     stop = stop || !ok;
                 }
                 if (__any(stop)) break;
             }
+            if (nst) flush(nst);
             for (int m = 32; m; m >>= 1) { u64 o = __shfl_xor(key, m); key = o > key ? o : key; }
             if (lane == 0) {
                 if (key) {
@@ -608,11 +715,71 @@ __device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 dept
         c0 = c1;
     }
 }
+// ---- the (reference k-mer, read k-mer) pairs of one big block on the team (cmd 4): wave w takes the w-th contiguous share of the pair indices
+// (i major, as the serial loops), pass 1 counts the pairs it keeps, pass 2 writes them behind the shares before it -- the output is in pair order
+#ifndef K_GAP_JOIN_TEAM_MIN
+#define K_GAP_JOIN_TEAM_MIN 65536
+#endif
+__device__ inline void gap_join_team_share(GapTeam *tm, int w, int nw, int pass) {
+    const u32 lane = threadIdx.x & 63;
+    const u64 ni = tm->j_p2 - tm->j_p1, nj = tm->j_k - tm->j_p2, np = ni * nj;
+    const u64 lo = np * (u64)w / (u64)nw, hi = np * (u64)(w + 1) / (u64)nw;
+    const u64 *hs = tm->j_hs;
+    u64 base = 0;
+    if (pass == 2) for (int v = 0; v < w; v++) base += tm->part[v];
+    u64 run = 0;
+    for (u64 pb = lo; pb < hi; pb += 64) {
+        u64 q = pb + lane;
+        bool in = q < hi;
+        u64 qi = q / nj, qj = q - qi * nj;
+        u64 hi_ = in ? hs[tm->j_p1 + qi] : 0, hj_ = in ? hs[tm->j_p2 + qj] : 0, a;
+        bool kp;
+        if (tm->j_kind == 0) { a = ganc_make(hi_, hj_, tm->j_rvcp); kp = in && tm->j_band.keep(a); }
+        else { i64 d = (i64)(hi_ & ((1ULL << 30) - 1)) - (i64)(hj_ & ((1ULL << 30) - 1)); kp = in && tm->j_lower <= d && d < tm->j_upper; a = canc_make(hi_, hj_); }
+        u64 m = __ballot(kp);
+        if (pass == 2 && kp) tm->j_out[base + run + (u64)__popcll(m & ((1ULL << lane) - 1))] = a;
+        run += (u64)__popcll(m);
+    }
+    if (pass == 1 && lane == 0) tm->part[w] = run;
+}
+// wave 0's side of cmd 4; returns false when the team is not used (the caller runs the single-wave loop)
+__device__ inline bool gap_join_team(GapCtx &X, const GVec<u64> &g_hs, GVec<u64> &out, int p1, int p2, int k, int kind, u64 rvcp, i64 lower, i64 upper, const GAncBand *B) {
+    if (X.team <= 1 || (u64)(p2 - p1) * (u64)(k - p2) < K_GAP_JOIN_TEAM_MIN) return false;
+    GapTeam *tm = X.tm;
+    if ((threadIdx.x & 63) == 0) {
+        tm->j_hs = g_hs.p; tm->j_p1 = (u32)p1; tm->j_p2 = (u32)p2; tm->j_k = (u32)k; tm->j_kind = kind; tm->j_rvcp = rvcp; tm->j_lower = lower; tm->j_upper = upper;
+        if (B) tm->j_band = *B;
+        tm->j_pass = 1; tm->cmd = 4;
+    }
+    __syncthreads();                                             // (A)
+    gap_join_team_share(tm, 0, X.team, 1);
+    __syncthreads();                                             // (B1) the counts are posted
+    u64 total = 0;
+    for (int v = 0; v < X.team; v++) total += tm->part[v];
+    out.reserve(out.n + (u32)total);
+    bool fits = (u64)out.n + total <= out.cap;
+    if ((threadIdx.x & 63) == 0) { tm->j_out = out.p + out.n; tm->j_pass = fits ? 2 : 0; }
+    __syncthreads();                                             // (B2)
+    if (fits) gap_join_team_share(tm, 0, X.team, 2);
+    __syncthreads();                                             // (B3)
+    if (fits) out.n += (u32)total;
+    return true;
+}
+__device__ void gap_sort_team_share(GapTeam *tm);             // (lnr_gap_kernels.hip: the queued ranges of a big sort, one at a time per wave)
 __device__ inline void gap_team_helper_loop(GapTeam *tm, int wave, int nw) {
     for (;;) {
         __syncthreads();                                         // (A) a command is posted
         if (tm->cmd == 0) break;
-        if (tm->cmd == 2) { gap_dp_columns(tm->anchors, tm->n, tm->rec, tm->depth, tm->dx_depth, GapDpFn{tm->fn}, wave, nw, &tm->dup); continue; }
+        if (tm->cmd == 3) { gap_sort_team_share(tm); __syncthreads(); continue; }
+        if (tm->cmd == 4) {
+            gap_join_team_share(tm, wave, nw, 1);
+            __syncthreads();                                     // (B1)
+            __syncthreads();                                     // (B2) wave 0 has reserved the output
+            if (tm->j_pass == 2) gap_join_team_share(tm, wave, nw, 2);
+            __syncthreads();                                     // (B3)
+            continue;
+        }
+        if (tm->cmd == 2) { gap_dp_columns(tm->anchors, tm->n, tm->rec, tm->depth, tm->dx_depth, GapDpFn{tm->fn}, tm->fn, wave, nw, tm); continue; }
         u64 key = gap_dp_row_share(tm->anchors, tm->score, tm->ai, tm->i, tm->j_str, tm->dx_depth, GapDpFn{tm->fn}, wave, nw);
         if ((threadIdx.x & 63) == 0) tm->part[wave] = key;
         __syncthreads();                                         // (B) the shares are posted
@@ -760,11 +927,13 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
     GP(X, 4);
 #if defined(__HIP_DEVICE_COMPILE__)
     bool by_columns = false;
-    if (X.coop && X.team > 1 && fn_id && n >= K_GAP_COL_MIN) {
+    u32 *xs_ = nullptr;
+    if (X.coop && X.team > 1 && fn_id && n >= K_GAP_COL_MIN) { xs_ = (u32 *)X.ar->get((u64)n * 8); if (X.ar->ovf) return; }
+    if (xs_) {
         GapTeam *tm = X.tm;
-        if ((threadIdx.x & 63) == 0) { tm->anchors = anchors; tm->rec = r; tm->n = n; tm->depth = depth; tm->dx_depth = dx_depth; tm->fn = fn_id; tm->dup = 0; tm->cmd = 2; }
+        if ((threadIdx.x & 63) == 0) { tm->anchors = anchors; tm->rec = r; tm->n = n; tm->depth = depth; tm->dx_depth = dx_depth; tm->fn = fn_id; tm->dup = 0; tm->ncols = 0; tm->xs = xs_; tm->ys = xs_ + n; tm->cmd = 2; }
         __syncthreads();                                         // (A)
-        gap_dp_columns(anchors, n, r, depth, dx_depth, GapDpFn{fn_id}, 0, X.team, &tm->dup);
+        gap_dp_columns(anchors, n, r, depth, dx_depth, GapDpFn{fn_id}, fn_id, 0, X.team, tm);
         by_columns = tm->dup == 0;                               // (a column held the same anchor twice: the single-wave form below redoes the DP)
         if (!by_columns) { for (u32 i = threadIdx.x & 63; i < n; i += 64) { r.score[i] = 0; r.score2[i] = 0; r.len[i] = 0; r.p2[i] = 0; r.root[i] = 0; r.leaf[i] = 0; } WSYNC(); r.score[0] = 0; r.len[0] = 1; r.p2[0] = -1; }
     }
@@ -781,6 +950,7 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
         i32 ws = 0, wl = 0, wr = 0;
         u32 far_prev = 0;
         for (int i = 0; i < (int)n; i++) {
+            if ((i & 1023) == 0 && gap_late(X)) return;
             if ((i & 63) == 0) blk = (u32)(i + lane) < n ? anchors[i + lane] : 0;
             int j_str = i - (int)depth < 0 ? 0 : i - (int)depth;
             u64 ai = __shfl(blk, i & 63), xi = ganc_x(ai), key = 0;
@@ -946,7 +1116,7 @@ LNR_HD inline void gap_chain_tiles(GVec<u64> &tiles, u64 L, u64 gap_size, GapCtx
 }
 LNR_HD inline void g_chains_from_anchors(GVec<u64> &anchors, GVec<u64> &tiles, u64 L, GapCtx &X) {   // g_CreateChainsFromAnchors_ gap_util.cpp:1191-1222
     if (X.ar->ovf) return;
-    { GP(X, 3); gap_sort(anchors.p, (long)anchors.n, [](const u64 &a, const u64 &b) { return ganc_x(a) > ganc_x(b); }, X); }
+    { GP(X, 3); gap_sort(anchors.p, (long)anchors.n, GapCmp{2, 0}, X); }
     int fn = X.gp.chn1_fn;
     gap_chain_anchors(anchors.p, anchors.n, tiles, true, 20, 80, 20, X.gp.chn1_min_len, X.gp.chn1_abort, [fn](u64 a, u64 b) { return fn == 2 ? gap_anchor_score2_pos(a, b) : gap_anchor_score1_pos(a, b); }, X, fn == 2 ? 2 : 1);
     gap_chain_tiles(tiles, L, 100, X);
@@ -1274,7 +1444,7 @@ LNR_HD inline int gap_map_along_chain(const GSeq &ref, const GSeq &seq2, const G
     c_stream(ref, hs, cord_x(a), cord_x(b), step1, shape_len, 0, X.coop);
     c_stream(seq2, hs, cord_y(a), cord_y(b), step2, shape_len, 1, X.coop);
     c_create_anchors2(hs, anc, (as < ae ? as : ae) - 30, (as > ae ? as : ae) + 30, X.ls->st, &X);
-    gap_sort(anc.p, (long)anc.n, [](const u64 &p, const u64 &q) { return ganc_x(p) > ganc_x(q); }, X);
+    gap_sort(anc.p, (long)anc.n, GapCmp{2, 0}, X);
     stick_main_chain(anc, ch, X.gp.thd_smcn_danchor);
     GVec<u64> first; first.init(X.ar, anc.n + 16);
     // bestn 1: only the first chain is wanted; it is collected as anchors and turned into tiles below (chn_ext_clip_metric1: min length 1, abort 0)
@@ -1492,7 +1662,46 @@ LNR_HD inline void gap_filter_anchors(GVec<u64> &a, GapCtx &X) {                
     GVec<UP> list; list.init(X.ar);
     if (a.n > 1) {
         a[0] = 0;
-        gap_sort(a.p, (long)a.n, [](const u64 &p, const u64 &q) { return ganc_stranchor(p) < ganc_stranchor(q); }, X);
+        gap_sort(a.p, (long)a.n, GapCmp{1, 0}, X);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (X.coop) {
+            // the walk over the sorted anchors, 64 elements per step.  Inside a block that started at b the running "median" anchor the serial
+            // loop compares element i with is a[(b + i - 1) >> 1] -- set by the step before, which was a continuation or the block's start -- so
+            // the continuation test of every element of the block is known from (b, i) alone; the block ends at the first element that fails it.
+            const u32 n = a.n, lane = threadIdx.x & 63;
+            u64 b = 1, count = 1, min_y = ganc_y(a[1]), max_y = min_y;        // (the serial loop's first step: element 1 opens a block, nothing is listed)
+            u32 i0 = 2;
+            while (i0 < n) {
+                u32 i = i0 + lane;
+                bool in = i < n;
+                u64 ai = in ? a.p[i] : 0, ak = in ? a.p[(u32)((b + i - 1) >> 1)] : 0;
+                u64 y = ganc_y(ai);
+                u64 dy2 = (u64)gabs((i64)(y - ganc_y(ak)));
+                bool cont = in && ganc_stranchor(ai) - ganc_stranchor(ak) < dy2;
+                u64 mfail = __ballot(in && !cont);
+                u32 nin = n - i0 < 64 ? n - i0 : 64;
+                u32 f = mfail ? (u32)__builtin_ctzll(mfail) : nin;          // elements of this step before f continue the block
+                u64 ly = lane < f ? y : min_y, hy = lane < f ? y : max_y;
+                for (int m = 32; m; m >>= 1) { u64 o1 = __shfl_xor(ly, m), o2 = __shfl_xor(hy, m); ly = o1 < ly ? o1 : ly; hy = o2 > hy ? o2 : hy; }
+                if (ly < min_y) min_y = ly;
+                if (hy > max_y) max_y = hy;
+                count += f;
+                bool last_cont = !mfail && i0 + nin == n;                    // the array ends inside the block: the serial loop closes it at i = n - 1
+                if (mfail || last_cont) {
+                    u64 iend = mfail ? (u64)i0 + f : (u64)n - 1;
+                    u64 acc = ((max_y - min_y) * 20) >> 10; if (acc < 20) acc = 20;
+                    if (count > acc) { UP e; e.first = b; e.second = iend; list.push(e); }
+                    if (!mfail) break;
+                    b = iend; count = 1;
+                    u64 yf = ganc_y(a.p[(u32)iend]);
+                    min_y = yf; max_y = yf;
+                    i0 = (u32)iend + 1;
+                    if (i0 >= n) break;                                      // (the failing element was the last one: it opened a block of its own, count 1)
+                } else i0 += nin;
+            }
+        } else
+#endif
+        {
         u64 ak2 = a[1], block_str = 1, count = 0, min_y = ~0ULL, max_y = 0;
         for (u32 i = 1; i < a.n; i++) {
             u64 y = ganc_y(a[i]);
@@ -1504,6 +1713,7 @@ LNR_HD inline void gap_filter_anchors(GVec<u64> &a, GapCtx &X) {                
                 if (count > acc) { UP e; e.first = block_str; e.second = i; list.push(e); }
                 block_str = i; ak2 = a[i]; min_y = y; max_y = y; count = 1;
             }
+        }
         }
     }
     if (!list.empty()) {
@@ -1519,6 +1729,26 @@ LNR_HD inline void gap_filter_anchors(GVec<u64> &a, GapCtx &X) {                
         }
     }
     u32 it = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (X.coop) {
+        // the in-place copy of the kept blocks, 64 elements per step.  The serial loop reads a[j] after it wrote a[it]: inside one step that only
+        // matters when the destination runs less than 64 elements ahead of the source (an element written by this very step would be read by it);
+        // such a step is taken element by element.
+        const u32 lane = threadIdx.x & 63;
+        for (u32 i = 0; i < list.n; i++) {
+            u64 j = list[i].first, je = list[i].second;
+            while (j < je) {
+                u32 m = je - j < 64 ? (u32)(je - j) : 64u;
+                if ((u64)it > j && (u64)it - j < 64) { for (u32 t = 0; t < m; t++) a.p[it + t] = a.p[(u32)j + t]; }
+                else { u64 v = lane < m ? a.p[(u32)j + lane] : 0; WSYNC(); if (lane < m) a.p[it + lane] = v; }
+                WSYNC();
+                it += m; j += m;
+            }
+        }
+        a.n = it;
+        return;
+    }
+#endif
     for (u32 i = 0; i < list.n; i++) for (u64 j = list[i].first; j < list[i].second; j++) a[it++] = a[(u32)j];
     a.n = it;
 }
@@ -1685,6 +1915,7 @@ LNR_HD inline int gap_map_gaps(GVec<u64> &cs, GVec<u64> &ce, GArena &keep, GapCt
     gather_blocks(cs.p, cs.n, &str_ends, sep, 1, cs.n, L, (u64)cord_gap, (u64)block_size, 0);
     gather_gaps_y(str_ends.p, str_ends.n, gaps, L, (u64)cord_gap, *X.ls);
     for (u32 i = 1; i < cs.n; i++) {
+        if (gap_late(X)) return 1;
         u64 slen = X.seq_len[cord_id(cs[i])];
         gp.read_len = L; gp.ref_len = slen;
         if (is_end(cs[i - 1])) {                                                                 // the block's first cord: towards the read's start

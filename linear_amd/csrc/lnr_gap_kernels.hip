@@ -9,23 +9,21 @@
 namespace lnr {
 #define SORT_SMALL 32
 // ---- gap_sort_wave: introsort_xdesc_wave for any element type and comparator, the scratch taken from the read's arena.  The array,
-// the swap-candidate lists and the task list live in global memory; the explicit stack is wave-uniform private state (this kernel has
-// one wave per workgroup and registers to spare).  Falls back to the serial ref_sort when the arena cannot hold the lists.
-template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp comp, GapCtx &X) {
+// the swap-candidate lists and the task list live in global memory; the explicit stack is wave-uniform private state.  Falls back to the serial
+// ref_sort when the arena cannot hold the lists.
+// gap_sort_core sorts a[first0, last0) the way std::sort's introsort loop + final insertion sort do (ref_sort.h), with the partitions of the
+// ranges above SORT_SMALL done by all 64 lanes and the small ranges finished one per lane.  Everything a range needs lies at the range's own
+// indices of Lbuf / Rbuf / tasks, so several waves can work on disjoint ranges of one array at once.  Ranges of at most `cutoff` elements are
+// not sorted here but appended to `queue` (first | last << 28 | depth << 56): the team form deals them over the waves afterwards -- what
+// introsort does with a range depends on that range (and its depth budget) alone.
+template <class T, class Comp> __device__ void gap_sort_core(T *a, u32 first0, u32 last0, int depth0, Comp comp, u32 *Lbuf, u32 *Rbuf, u64 *tasks, u32 cutoff, u64 *queue, u32 *nqueue) {
     const int lane = lane_id();
-    u64 m0 = X.ar->mark();
-    u32 *Lbuf = (u32 *)X.ar->get((u64)n * 4), *Rbuf = (u32 *)X.ar->get((u64)n * 4);
-    u64 *tasks = (u64 *)X.ar->get(((u64)n + 64) * 8);
-    if (X.ar->ovf) {                                         // (the overflow stands: the read is redone with a larger arena)
-        ref_sort(a, (long)n, comp, X.ls->st);
-        return;
-    }
     int stk_first[64], stk_last[64], stk_depth[64];
-    int sp = 0, lg = 0;
-    for (u32 t = n; t > 1; t >>= 1) lg++;
-    stk_first[0] = 0; stk_last[0] = (int)n; stk_depth[0] = lg * 2;
+    int sp = 0;
+    stk_first[0] = (int)first0; stk_last[0] = (int)last0; stk_depth[0] = depth0;
     sp = 1;
-    u32 ntasks = 0;
+    u64 *tk = tasks + first0;
+    u32 ntasks = 0, nq = nqueue ? *nqueue : 0;
     WSYNC();
     while (sp > 0) {
         --sp;
@@ -33,13 +31,18 @@ template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp c
         int depth = stk_depth[sp];
         while (true) {
             if (last - first <= SORT_SMALL) {
-                if (lane == 0) tasks[ntasks] = (u64)first | ((u64)last << 28) | ((u64)depth << 56);
+                if (lane == 0) tk[ntasks] = (u64)first | ((u64)last << 28) | ((u64)depth << 56);
                 ntasks++;
                 break;
             }
             if (depth == 0) {
-                if (lane == 0) tasks[ntasks] = (u64)first | ((u64)last << 28) | (1ULL << 63);
+                if (lane == 0) tk[ntasks] = (u64)first | ((u64)last << 28) | (1ULL << 63);
                 ntasks++;
+                break;
+            }
+            if (last - first <= cutoff) {                                     // (team form, wave 0: left for the waves)
+                if (lane == 0) queue[nq] = (u64)first | ((u64)last << 28) | ((u64)depth << 56);
+                nq++;
                 break;
             }
             --depth;
@@ -52,6 +55,7 @@ template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp c
             WSYNC();                                                          // every lane has read the four before one of them is overwritten
             if (lane == 0) { a[first] = vp; a[pick] = vf; }
             u32 lo = first + 1, nL = 0, nR = 0;
+            u32 *Lb = Lbuf + first, *Rb = Rbuf + first;
             for (u32 base = lo; base < last; base += 128) {
                 T v2[2];
 #pragma unroll
@@ -65,19 +69,19 @@ template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp c
                     bool fL = in && !comp(x, vp);           // the left scan stops here
                     bool fR = in && !comp(vp, x);           // the right scan stops here
                     u64 mL = __ballot(fL), mR = __ballot(fR);
-                    if (fL) Lbuf[nL + __popcll(mL & lanemask_lt())] = i;
-                    if (fR) Rbuf[nR + __popcll(mR & lanemask_lt())] = i;
+                    if (fL) Lb[nL + __popcll(mL & lanemask_lt())] = i;
+                    if (fR) Rb[nR + __popcll(mR & lanemask_lt())] = i;
                     nL += (u32)__popcll(mL); nR += (u32)__popcll(mR);
                 }
             }
             WSYNC();
             u32 lim = nL < nR ? nL : nR, cnt = 0;
-            for (u32 k = lane; k < lim; k += 64) cnt += Lbuf[k] < Rbuf[nR - 1 - k] ? 1u : 0u;
+            for (u32 k = lane; k < lim; k += 64) cnt += Lb[k] < Rb[nR - 1 - k] ? 1u : 0u;
             u32 K = wave_sum(cnt);
-            for (u32 k = lane; k < K; k += 64) { u32 i = Lbuf[k], j = Rbuf[nR - 1 - k]; T t = a[i]; a[i] = a[j]; a[j] = t; }
+            for (u32 k = lane; k < K; k += 64) { u32 i = Lb[k], j = Rb[nR - 1 - k]; T t = a[i]; a[i] = a[j]; a[j] = t; }
             u32 cut = last;
-            if (K < nL) cut = Lbuf[K];
-            if (K >= 1) { u32 r = Rbuf[nR - K]; cut = r < cut ? r : cut; }
+            if (K < nL) cut = Lb[K];
+            if (K >= 1) { u32 r = Rb[nR - K]; cut = r < cut ? r : cut; }
             WSYNC();
             stk_first[sp] = (int)cut; stk_last[sp] = (int)last; stk_depth[sp] = depth;
             ++sp;
@@ -88,12 +92,59 @@ template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp c
     for (u32 b = 0; b < ntasks; b += 64) {                   // the deferred ranges, one per lane
         u32 t = b + (u32)lane;
         if (t < ntasks) {
-            u64 v = tasks[t];
+            u64 v = tk[t];
             if (v >> 63) rs_heap_sort(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), comp);
             else rs_finish_range<16>(a, (long)(v & 0xfffffff), (long)((v >> 28) & 0xfffffff), (int)((v >> 56) & 0x7f), comp);
         }
     }
     WSYNC();
+    if (nqueue) *nqueue = nq;
+}
+// the team's share of a big sort: ranges from the queue, one at a time per wave (cmd 3)
+__device__ void gap_sort_team_share(GapTeam *tm) {
+    for (;;) {
+        u32 k = 0;
+        if (lane_id() == 0) k = atomicAdd(&tm->s_next, 1u);
+        k = (u32)__shfl((int)k, 0);
+        if (k >= tm->s_nq) break;
+        u64 v = tm->s_queue[k];
+        gap_sort_core<u64, GapCmp>(tm->s_a, (u32)(v & 0xfffffff), (u32)((v >> 28) & 0xfffffff), (int)((v >> 56) & 0x7f), tm->s_cmp, tm->s_L, tm->s_R, tm->s_tasks, 0, nullptr, nullptr);
+    }
+}
+#ifndef K_GAP_SORT_TEAM_MIN
+#define K_GAP_SORT_TEAM_MIN 16384
+#endif
+template <class T, class Comp> struct GapSortTeam { static __device__ bool run(T *, u32, Comp, GapCtx &, u32 *, u32 *, u64 *, int) { return false; } };
+template <> struct GapSortTeam<u64, GapCmp> {
+    // wave 0 partitions from the top down to ranges of n / 64 elements (at least 2048) and queues them; all waves of the team then sort queued ranges
+    static __device__ bool run(u64 *a, u32 n, GapCmp comp, GapCtx &X, u32 *Lbuf, u32 *Rbuf, u64 *tasks, int lg2) {
+        if (X.team <= 1 || n < K_GAP_SORT_TEAM_MIN) return false;
+        u32 cutoff = n / 64 > 2048 ? n / 64 : 2048;
+        u64 *queue = (u64 *)X.ar->get(((u64)n / SORT_SMALL + 512) * 8);       // (queued ranges are disjoint and longer than SORT_SMALL: at most n / 33 of them)
+        if (X.ar->ovf) return false;
+        u32 nq = 0;
+        gap_sort_core<u64, GapCmp>(a, 0, n, lg2 * 2, comp, Lbuf, Rbuf, tasks, cutoff, queue, &nq);
+        GapTeam *tm = X.tm;
+        if (lane_id() == 0) { tm->s_a = a; tm->s_L = Lbuf; tm->s_R = Rbuf; tm->s_tasks = tasks; tm->s_queue = queue; tm->s_nq = nq; tm->s_next = 0; tm->s_cmp = comp; tm->cmd = 3; }
+        __syncthreads();                                                      // (A)
+        gap_sort_team_share(tm);
+        __syncthreads();                                                      // (B)
+        return true;
+    }
+};
+template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp comp, GapCtx &X) {
+    u64 m0 = X.ar->mark();
+    u32 *Lbuf = (u32 *)X.ar->get((u64)n * 4), *Rbuf = (u32 *)X.ar->get((u64)n * 4);
+    u64 *tasks = (u64 *)X.ar->get(((u64)n + 64) * 8);
+    if (X.ar->ovf) {                                         // (the overflow stands: the read is redone with a larger arena)
+        ref_sort(a, (long)n, comp, X.ls->st);
+        return;
+    }
+    if (gap_late(X)) return;
+    int lg = 0;
+    for (u32 t = n; t > 1; t >>= 1) lg++;
+    if (!GapSortTeam<T, Comp>::run(a, n, comp, X, Lbuf, Rbuf, tasks, lg))
+        gap_sort_core<T, Comp>(a, 0, n, lg * 2, comp, Lbuf, Rbuf, tasks, 0, nullptr, nullptr);
     X.ar->release(m0);
 }
 
@@ -102,12 +153,18 @@ template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp c
 #endif
 __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
     u32 worker = A.coop ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef LNR_GAP_DEVPROF
+    if (A.prof && threadIdx.x == 0 && !A.big) { unsigned long long c = atomicAdd(A.prof + 94, 1ULL) + 1; atomicMax(A.prof + 95, c); }   // workers of the first launch alive at once
+#endif
     char *mine = A.arena + (u64)worker * A.arena_bytes;
     for (;;) {
         u32 r;
         if (A.coop) { r = threadIdx.x == 0 ? atomicAdd(A.next, 1u) : 0u; r = (u32)__shfl((int)r, 0); }
         else r = atomicAdd(A.next, 1u);
-        r += A.lo;
+        if (A.big) {                                                 // the flagged reads, heaviest first
+            if (r >= *A.list_n) break;
+            r = A.list[r];
+        } else { if (r >= A.n - A.lo) break; r = A.order ? A.order[r] : r + A.lo; }
         if (r >= A.n) break;
         if (A.big && !A.gap_flag[r]) continue;
         if (A.big && threadIdx.x == 0) atomicAdd(A.next + 8, 1u);   // (statistics: reads of the second launch)
@@ -120,10 +177,17 @@ __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
         u64 keep_bytes = ((u64)A.cords_cap[r] * 16 + (u64)nc * 64 + 8192) * 2;
         char *kp = (char *)all.get(keep_bytes);
         bool bad = all.ovf != 0;
+        u64 ar_want = 0;
         if (!bad) {
             const u8 *src = A.reads + A.off[r];
-            for (u64 k = 0; k < L; k++) { u8 b = src[k]; b = b > 4 ? 4 : b; rd[k] = b; rc[L - 1 - k] = b == 4 ? 4 : 3 - b; }
-            for (u32 k = 0; k < 64; k++) { rd[L + k] = 0; rc[L + k] = 0; }
+            if (A.coop) {                                            // (the wave's lanes share the copy; every lane reads the arrays afterwards)
+                for (u64 k = threadIdx.x & 63; k < L; k += 64) { u8 b = src[k]; b = b > 4 ? 4 : b; rd[k] = b; rc[L - 1 - k] = b == 4 ? 4 : 3 - b; }
+                rd[L + (threadIdx.x & 63)] = 0; rc[L + (threadIdx.x & 63)] = 0;
+                WSYNC();
+            } else {
+                for (u64 k = 0; k < L; k++) { u8 b = src[k]; b = b > 4 ? 4 : b; rd[k] = b; rc[L - 1 - k] = b == 4 ? 4 : 3 - b; }
+                for (u32 k = 0; k < 64; k++) { rd[L + k] = 0; rc[L + k] = 0; }
+            }
             GArena keep; keep.init(kp, keep_bytes);
             GArena ar; ar.init(mine + all.off, A.arena_bytes - all.off);
             GapCtx X;
@@ -136,6 +200,7 @@ __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
             const bool ext_in = r >= A.ext_from;
             if (ext_in) X.gp.thd_cts_major_limit = 3;
             X.coop = A.coop; X.work_cap = A.work_cap; X.team = team; X.tm = tm;
+            X.deadline = A.cap_ticks ? wall_clock64() + A.cap_ticks : 0;
             u64 *os = A.out_str + A.cords_off[r], *oe = A.out_end + A.cords_off[r];
             GVec<u64> cs, ce; cs.init(&keep, nc * 2 + 64); ce.init(&keep, nc * 2 + 64);
             for (u32 i = 0; i < nc; i++) { cs.push(os[i]); ce.push(oe[i]); }
@@ -151,10 +216,12 @@ __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
                 for (int k = 0; k < 10; k++) atomicAdd(pp + k, X.prof[k]);
                 atomicAdd(pp + 11, t_read); atomicAdd(pp + 12, 1ULL);
                 A.prof[96 + r] = t_read | ((unsigned long long)(A.big + A.last) << 56);      // per-read time of the launch that did the read
+                if (!A.big) { A.prof[96 + A.n + r] = wall_clock64() - t_read; A.prof[96 + 2 * (unsigned long long)A.n + r] = wall_clock64(); }   // first launch: start and end tick of the read
                 if (atomicMax(pp + 15, t_read) < t_read) { unsigned long long *ps = A.prof + 48 + 16 * (A.big + A.last); for (int k = 0; k < 10; k++) ps[k] = X.prof[k]; ps[10] = r; ps[11] = L; ps[12] = nc; ps[13] = ar.hw; }
             }
 #endif
             bad = rc_ != 0 || ar.ovf || keep.ovf || cs.n > A.cords_cap[r] || cs.n != ce.n;
+            ar_want = ar.want > keep.want ? ar.want : keep.want;
             if (!bad) {
                 if (!ext_in && X.gp.thd_cts_major_limit == 3 && threadIdx.x == (A.coop ? 0u : threadIdx.x)) atomicMin(A.first_ext, r);
                 if (!A.probe) {
@@ -163,9 +230,13 @@ __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
                 }
             }
         }
-        A.gap_flag[r] = bad ? 1 : 0;
+        u64 wkib = (all.want > ar_want ? all.want : ar_want) >> 10;
+        A.gap_flag[r] = bad ? 1u + (u32)(wkib < 0x3fffffffu ? wkib : 0x3fffffffu) : 0u;
         if (A.last && bad) A.read_err[r] = 5;
     }
+#ifdef LNR_GAP_DEVPROF
+    if (A.prof && threadIdx.x == 0 && !A.big) atomicAdd(A.prof + 94, ~0ULL);
+#endif
 }
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(K_GAP_WAVES, K_GAP_WAVES))) k_gap(GapArgs A) { gap_worker(A, nullptr, 1); }
 // The launches for the flagged reads: K_GAP_TEAM waves per read.  Wave 0 is the worker; the others only serve the long rows of its
@@ -179,6 +250,77 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * K_GAP_TEAM, 64 *
 }
 
 
+// flagged reads of [lo, n) -> list, heaviest first: one workgroup collects them (ballot compaction, index order) and, up to GAP_LIST_SORT_MAX of
+// them, sorts (weight descending, index ascending) with a bitonic network in LDS
+__global__ void __launch_bounds__(1024) k_gap_order(const u32 *gap_flag, u32 lo, u32 n, u32 *list, u32 *list_n) {
+    __shared__ u64 key[GAP_LIST_SORT_MAX];
+    __shared__ u32 s_cnt, s_wave[16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (u32 base = lo; base < n; base += 1024) {
+        u32 r = base + tid;
+        u32 f = r < n ? gap_flag[r] : 0u;
+        u64 m = __ballot(f != 0);
+        if (lane == 0) s_wave[wv] = (u32)__popcll(m);
+        __syncthreads();
+        u32 before = s_cnt;
+        for (u32 w = 0; w < wv; w++) before += s_wave[w];
+        if (f) {
+            u32 pos = before + (u32)__popcll(m & ((1ULL << lane) - 1));
+            list[pos] = r;
+            if (pos < GAP_LIST_SORT_MAX) key[pos] = ((u64)(0xffffffffu - f) << 32) | r;      // ascending key = weight descending, then index ascending
+        }
+        __syncthreads();
+        if (tid == 0) { u32 t = 0; for (u32 w = 0; w < 16; w++) t += s_wave[w]; s_cnt += t; }
+        __syncthreads();
+    }
+    const u32 cnt = s_cnt;
+    if (tid == 0) *list_n = cnt;
+    if (cnt < 2 || cnt > GAP_LIST_SORT_MAX) return;
+    u32 P = 1;
+    while (P < cnt) P <<= 1;
+    for (u32 i = cnt + tid; i < P; i += 1024) key[i] = ~0ULL;
+    __syncthreads();
+    for (u32 k = 2; k <= P; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 i = tid; i < P; i += 1024) {
+                u32 x = i ^ j;
+                if (x > i) {
+                    u64 a = key[i], b = key[x];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) { key[i] = b; key[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (u32 i = tid; i < cnt; i += 1024) list[i] = (u32)key[i];
+}
+__global__ void __launch_bounds__(1024) k_gap_rank(const u32 *nout, const u64 *off, u32 lo, u32 n, u32 *order) {
+    __shared__ u32 bin[1024];
+    const u32 tid = threadIdx.x;
+    bin[tid] = 0;
+    __syncthreads();
+    auto key = [&](u32 r) -> u32 {
+        u64 L = off[r + 1] - off[r], cov = 96ULL * nout[r];
+        u64 unc = L > cov ? L - cov : 0;
+        u32 k = (u32)(unc >> 5);
+        return 1023u - (k < 1023u ? k : 1023u);              // bin 0 = the most uncovered
+    };
+    for (u32 r = lo + tid; r < n; r += 1024) atomicAdd(&bin[key(r)], 1u);
+    __syncthreads();
+    if (tid == 0) { u32 acc = 0; for (u32 b = 0; b < 1024; b++) { u32 c = bin[b]; bin[b] = acc; acc += c; } }
+    __syncthreads();
+    for (u32 r = lo + tid; r < n; r += 1024) order[atomicAdd(&bin[key(r)], 1u)] = r;
+}
+hipError_t launch_gap_rank(const u32 *nout, const u64 *off, unsigned lo, unsigned n, u32 *order, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gap_rank, dim3(1), dim3(1024), 0, stream, nout, off, lo, n, order);
+    return hipGetLastError();
+}
+hipError_t launch_gap_order(const u32 *gap_flag, unsigned lo, unsigned n, u32 *list, u32 *list_n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gap_order, dim3(1), dim3(1024), 0, stream, gap_flag, lo, n, list, list_n);
+    return hipGetLastError();
+}
 hipError_t launch_gap(const GapArgs &A, int team, unsigned grid, hipStream_t stream) {
     if (team) hipLaunchKernelGGL(k_gap_team, dim3(grid), dim3(64 * K_GAP_TEAM), 0, stream, A);
     else hipLaunchKernelGGL(k_gap, dim3(grid), dim3(64), 0, stream, A);

@@ -376,6 +376,25 @@ static i64 map_read_g_lim(void *h, const u8 *read, u64 len, u32 gap_len, int f_d
     S.ce.assign(ce.p, ce.p + ce.n);
     return (i64)S.cs.size();
 }
+// the column DP's (dx, dy) forms against the anchor forms: over x2 = base, x1 = base + dx, y2 = ybase, y1 = ybase + dy for every (dx, dy) of the
+// rectangle, same strand and opposite strands.  Returns the number of pairs where "positive?" or the positive value differ.
+u64 hs_gap_delta_check(int fn, u32 dx_max, i32 dy_lo, i32 dy_hi) {
+    auto anchor = [](u64 x, u64 y, u64 strand) { return (strand << 50) | ((((x - y + G_ANCHOR_ZERO) & ((1ULL << 30) - 1))) << 20) | y; };
+    u64 bad = 0;
+    const u64 xb = 50000, yb = 3000;
+    for (u32 dx = 0; dx <= dx_max; dx++)
+        for (i32 dy = dy_lo; dy <= dy_hi; dy++)
+            for (int st = 0; st < 4; st++) {
+                u64 a1 = anchor(xb + dx, (u64)((i64)yb + dy), (u64)(st & 1)), a2 = anchor(xb, yb, (u64)(st >> 1));
+                int lit = gap_dp_score(fn, a1, a2);
+                u32 ys1 = (u32)ganc_y(a1) | ((u32)ganc_strand(a1) << 24), ys2 = (u32)ganc_y(a2) | ((u32)ganc_strand(a2) << 24);
+                u32 ddx = (u32)ganc_x(a1) - (u32)ganc_x(a2);
+                i32 ddy = (i32)(ys1 - ys2);
+                int alt = gap_score_box(fn, ddx, ddy) ? gap_score_delta(fn, ddx, (u32)ddy) : -1;
+                if ((lit > 0) != (alt > 0) || (lit > 0 && lit != alt)) bad++;
+            }
+    return bad;
+}
 int hs_gap_score(int which, u64 a, u64 b, u64 c, u64 d, u64 read_len, int strand) {
     switch (which) {
         case 1: return gap_anchor_score1(a, b);

@@ -292,3 +292,15 @@ def test_product_positive_only_chain_scores_agree_with_the_literal_ones():
             assert (got == want) if want > 0 else (got <= 0), (lit, dx, dy, want, got)
             npos += want > 0
     assert npos > 10000
+
+
+def test_column_dp_delta_scores_equal_the_anchor_scores():
+    """the team's column DP (lnr_gap_hd.h gap_dp_columns) scores a predecessor from (dx, dy) behind a box test; over every (dx, dy) of a rectangle
+    around the boxes, on equal and on opposite strands: positive exactly where the anchor forms (what the serial DP and the oracle-pinned host path use)
+    are positive, and the same value there."""
+    sh = shimlib.Shim([synth.random_ref(5000, 1)], 1)
+    f = sh.lib.hs_gap_delta_check
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_int, C.c_uint32, C.c_int32, C.c_int32]
+    for fn, dxm in ((1, 400), (2, 4300), (5, 200)):
+        assert f(fn, dxm, -6, 320) == 0, fn
