@@ -158,7 +158,7 @@ struct lnr_ctx {
     u32 overflow_reruns = 0;
     u32 seed_lds_pad = 0;   // diagnostic (LNR_SEED_LDS_PAD): dynamic LDS the seed kernel does not use, to lower its waves per CU
     DevBuf hx_nkeys, hx_nvals; u32 hx_nnodes = 0; u64 hx_empty_dir = 0;   // HIndex (-i 2): dir = hdir[2^18] (head of the block of X, -1: none), hs = ysa, nodes of the large blocks
-    DevBuf gap_arena, gap_flag, gap_next, d_seq_len, gap_prof, gap_first, gap_list, gap_rank;
+    DevBuf gap_arena, gap_flag, gap_next, d_seq_len, gap_prof, gap_first, gap_list, gap_rank, gap_weight;
     int gap_ext = 0;        // the read stream's state: 1 once a read of this context's stream went through mapExtend / mapExtends (lnr_gap_stream)   // the gap re-mapper (-g > 0): arenas of its workers, per-read retry flags, the two work counters
     DevBuf bh;              // header words of the bucket lines as a dense table (k_ix_lines; LNR_SEED_BH=0 turns it off for A/B runs)
     int use_bh = 0;        // (measured on the GRCh38 stand-in, same box, two runs each: 3.07 - 3.12 ms per launch with the table, 2.97 - 3.00 without: the early line fetch warms L2 / MALL for the DMA)
@@ -210,6 +210,8 @@ struct lnr_ctx {
     lnr_stats stats{};
     Timer t_prep, t_job, t_tail, t_total, t_gap;
     int gap_mode = 1, gap_team = 1; u32 gap_waves = 16384, gap_arena2_mb = 64;   // LNR_GAP_TEAM=0: one wave per flagged read, no helper waves   // LNR_GAP_MODE=1: the first launch of k_gap runs one wave per read as well (LNR_GAP_WAVES of them)
+    int gap_fused = 1; u32 gap_teams = 96, ncu = 0;   // the fused first stage (k_gap_all): LNR_GAP_FUSED=0 falls back to the three launches; LNR_GAP_TEAMS = team workgroups
+    u32 gap_heavy_w = 60000;   // weight (k_gap_weight) from which a read is expected to need a team (LNR_GAP_HEAVY_W)
     u32 gap_cap_ms = 0;    // first launch of the gap re-mapper: milliseconds after which a read is handed to the team launch (LNR_GAP_CAP_MS, 0 = never)
     u64 gap_work_cap = 3000000;   // pair evaluations of the chain DPs one lane spends on a read before the read goes to the wave-per-read launch (LNR_GAP_WORK_CAP)
 };
@@ -1117,7 +1119,10 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         if (ctx->gap_mode) w1 = std::min<u32>(w1, ctx->gap_waves);
         u32 w2 = (u32)std::min<u64>(std::min<u64>(n, ctx->gap_waves), std::max<u64>(1, budget / arena2));   // waves of the second launch
         u32 w3 = (u32)std::min<u64>(n, std::max<u64>(1, (budget / 2) / arena3));
-        ENSURE(ctx->gap_arena, std::max(std::max((u64)w1 * arena1, (u64)w2 * arena2), (u64)w3 * arena3));
+        const bool fused = ctx->gap_fused && ctx->gap_mode && ctx->gap_team;
+        const u32 ncu = ctx->ncu ? ctx->ncu : 256, nteams = std::min<u32>(ctx->gap_teams, ncu / 2);
+        u64 fused_bytes = fused ? (u64)nteams * arena2 + (u64)ncu * 16 * arena1 : 0;     // (a small chunk runs fewer teams and more single waves: bounded by every CU full of single waves)
+        ENSURE(ctx->gap_arena, std::max(std::max(std::max((u64)w1 * arena1, (u64)w2 * arena2), (u64)w3 * arena3), fused_bytes));
         ENSURE(ctx->gap_flag, (size_t)n * 4);
         ENSURE(ctx->gap_next, 256);
         HIPCK(hipMemsetAsync(ctx->gap_next.p, 0, 256, ctx->stream));
@@ -1141,6 +1146,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         ENSURE(ctx->gap_first, 64);
         G.first_ext = ctx->gap_first.as<u32>();
         ENSURE(ctx->gap_rank, ((size_t)n + 16) * 4);
+        ENSURE(ctx->gap_weight, ((size_t)n + 16) * 4);
         ENSURE(ctx->gap_list, ((size_t)n + 16) * 4);
         G.list = ctx->gap_list.as<u32>() + 16; G.list_n = ctx->gap_list.as<u32>();
         // one "ladder" = the three launches (small arenas for every read of [lo, hi), then the flagged reads with larger ones)
@@ -1150,16 +1156,30 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
             u32 m = hi - lo;
             G.lo = lo; G.n = hi; G.ext_from = ext_from; G.probe = probe;
             G.work_cap = ctx->gap_work_cap;
-            if ((e = launch_gap_rank(G.nout, G.off, lo, hi, ctx->gap_rank.as<u32>(), ctx->stream)) != hipSuccess) return e;
-            G.order = ctx->gap_rank.as<u32>();
+            if ((e = launch_gap_weight(G.reads, G.off, G.out_str, G.cords_off, G.nout, lo, hi, ctx->gap_weight.as<u32>(), ctx->stream)) != hipSuccess) return e;
+            if ((e = launch_gap_rank(ctx->gap_weight.as<u32>(), lo, hi, ctx->gap_rank.as<u32>() + 16, ctx->gap_rank.as<u32>(), ctx->gap_heavy_w, ctx->stream)) != hipSuccess) return e;
+            G.order = ctx->gap_rank.as<u32>() + 16;
             G.cap_ticks = (u64)ctx->gap_cap_ms * 100000ULL;
-            G.arena_bytes = arena1; G.next = ctx->gap_next.as<u32>(); G.big = 0; G.last = 0; G.coop = ctx->gap_mode;
-            u32 v1 = std::min<u32>(w1, (u32)align_up(m, 64));
-            if ((e = launch_gap(G, 0, ctx->gap_mode ? v1 : v1 / 64, ctx->stream)) != hipSuccess) return e;
-            G.work_cap = ~0ULL; G.cap_ticks = 0;
-            if ((e = launch_gap_order(G.gap_flag, lo, hi, ctx->gap_list.as<u32>() + 16, ctx->gap_list.as<u32>(), ctx->stream)) != hipSuccess) return e;
-            G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1; G.coop = 1;
-            if ((e = launch_gap(G, ctx->gap_team, std::min(w2, m), ctx->stream)) != hipSuccess) return e;
+            G.next = ctx->gap_next.as<u32>(); G.big = 0; G.last = 0; G.coop = ctx->gap_mode;
+            if (fused) {
+                // one launch: teams on the reads expected to be heavy + on what the single waves hand over, single waves on the rest
+                if ((e = hipMemsetAsync(ctx->gap_list.p, 0, ((size_t)n + 16) * 4, ctx->stream)) != hipSuccess) return e;
+                G.nteams = std::min<u32>(nteams, std::max<u32>(1, m / 8));
+                u32 bulk_wg = std::min<u32>(ncu > G.nteams ? ncu - G.nteams : 1, (m + 15) / 16);
+                G.nbulk_waves = bulk_wg * 16; G.arena_bytes = arena1; G.arena2_bytes = arena2;
+                G.n_heavy = ctx->gap_rank.as<u32>(); G.q = ctx->gap_list.as<u32>() + 16;
+                G.coop = 1;
+                if ((e = launch_gap_all(G, G.nteams + bulk_wg, ctx->stream)) != hipSuccess) return e;
+            } else {
+                G.arena_bytes = arena1;
+                u32 v1 = std::min<u32>(w1, (u32)align_up(m, 64));
+                if ((e = launch_gap(G, 0, ctx->gap_mode ? v1 : v1 / 64, ctx->stream)) != hipSuccess) return e;
+                G.work_cap = ~0ULL; G.cap_ticks = 0;
+                if ((e = launch_gap_order(G.gap_flag, lo, hi, ctx->gap_list.as<u32>() + 16, ctx->gap_list.as<u32>(), ctx->stream)) != hipSuccess) return e;
+                G.arena_bytes = arena2; G.next = ctx->gap_next.as<u32>() + 8; G.big = 1; G.coop = 1;
+                if ((e = launch_gap(G, ctx->gap_team, std::min(w2, m), ctx->stream)) != hipSuccess) return e;
+            }
+            G.work_cap = ~0ULL; G.cap_ticks = 0; G.big = 1; G.coop = 1;
             if ((e = launch_gap_order(G.gap_flag, lo, hi, ctx->gap_list.as<u32>() + 16, ctx->gap_list.as<u32>(), ctx->stream)) != hipSuccess) return e;
             G.arena_bytes = arena3; G.next = ctx->gap_next.as<u32>() + 24; G.last = 1;
             return launch_gap(G, ctx->gap_team, std::min(w3, m), ctx->stream);
@@ -1193,10 +1213,26 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
                 const unsigned long long *q = hp + 16 * L;
                 fprintf(stderr, "[gap prof] launch %d: reads %llu, lane/wave time %.1f ms in total, slowest read %.1f ms\n", L, q[12], q[11] / 1e5, q[15] / 1e5);
                 const unsigned long long *w = hp + 48 + 16 * L;
-                fprintf(stderr, "[gap prof]    slowest read: index %llu, length %llu, cords in %llu, arena high-water %llu bytes\n", w[10], w[11], w[12], w[13]);
+                fprintf(stderr, "[gap prof]    slowest read: index %llu, length %llu, cords in %llu, arena high-water %llu bytes; its longest chain DP: %.1f ms, %llu anchors, score fn %llu, %s\n", w[10], w[11], w[12], w[13],
+                        (double)(w[14] & ((1ULL << 56) - 1)) / 1e5, hp[90 + L], (w[14] >> 56) & 15, (w[14] >> 60) ? "by columns" : "single wave");
                 for (int k = 0; k < 10; k++) fprintf(stderr, "[gap prof]    %-26s %10.1f ms  %5.1f %%   slowest read: %8.1f ms\n", nm[k], q[k] / 1e5, q[11] ? 100.0 * q[k] / q[11] : 0.0, w[k] / 1e5);
             }
             fprintf(stderr, "[gap prof] first launch: at most %llu workers (waves) alive at once\n", hp[95]);
+            {   // how well the weight predicts: weights of the reads the team launch did, and of the slowest / all reads of the first launch
+                std::vector<u32> wt(n); std::vector<unsigned long long> pr0(n);
+                HIPCK(hipMemcpy(wt.data(), ctx->gap_weight.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+                HIPCK(hipMemcpy(pr0.data(), (char *)ctx->gap_prof.p + 96 * 8, (size_t)n * 8, hipMemcpyDeviceToHost));
+                std::vector<u32> wh, wl; std::vector<std::pair<double, u32> > slow;
+                for (u32 i = 0; i < n; i++) { if (!pr0[i]) continue; if ((pr0[i] >> 56) >= 1) wh.push_back(wt[i]); else { wl.push_back(wt[i]); slow.push_back({(double)(pr0[i] & ((1ULL << 56) - 1)) / 1e5, wt[i]}); } }
+                std::sort(wh.begin(), wh.end()); std::sort(wl.begin(), wl.end()); std::sort(slow.begin(), slow.end());
+                if (!wh.empty() && !wl.empty()) {
+                    fprintf(stderr, "[gap prof] weight of team-launch reads: min %u p10 %u p50 %u p90 %u max %u | of first-launch reads: p50 %u p90 %u p99 %u p99.9 %u max %u\n", wh[0], wh[wh.size() / 10], wh[wh.size() / 2], wh[wh.size() * 9 / 10], wh.back(),
+                            wl[wl.size() / 2], wl[wl.size() * 9 / 10], wl[wl.size() * 99 / 100], wl[(size_t)(wl.size() * 0.999)], wl.back());
+                    fprintf(stderr, "[gap prof] slowest first-launch reads (ms : weight):");
+                    for (size_t k = 0; k < 16 && k < slow.size(); k++) fprintf(stderr, " %.0f:%u", slow[slow.size() - 1 - k].first, slow[slow.size() - 1 - k].second);
+                    fprintf(stderr, "\n");
+                }
+            }
             {   // reads in flight over the first launch's duration (start / end ticks of every read, 10 ns)
                 std::vector<unsigned long long> se(2 * (size_t)n);
                 HIPCK(hipMemcpy(se.data(), (char *)ctx->gap_prof.p + (96 + (size_t)n) * 8, 2 * (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -1453,6 +1489,10 @@ lnr_status lnr_create(const lnr_opts *opts, lnr_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LNR_ERR_HIP; }
     if (const char *e = getenv("LNR_CAP_SHRINK")) { long v = atol(e); if (v >= 1 && v <= 4096) ctx->cap_shrink = (u32)v; }
     if (const char *e = getenv("LNR_GAP_MODE")) ctx->gap_mode = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LNR_GAP_FUSED")) ctx->gap_fused = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("LNR_GAP_TEAMS")) { long v = atol(e); if (v >= 1 && v <= 4096) ctx->gap_teams = (u32)v; }
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) ctx->ncu = (u32)pr.multiProcessorCount; else (void)hipGetLastError(); }
+    if (const char *e = getenv("LNR_GAP_HEAVY_W")) { long v = atol(e); if (v >= 1) ctx->gap_heavy_w = (u32)v; }
     if (const char *e = getenv("LNR_GAP_CAP_MS")) { long v = atol(e); if (v >= 0 && v <= 100000) ctx->gap_cap_ms = (u32)v; }
     if (const char *e = getenv("LNR_SEED_BH")) ctx->use_bh = atoi(e) ? 1 : 0;
     if (const char *e = getenv("LNR_GAP_WAVES")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) ctx->gap_waves = (u32)v; }

@@ -32,6 +32,11 @@ struct GapArgs {
     // the launches for the flagged reads take them from a list ordered heaviest first (k_gap_order: gap_flag[r] - 1 = the arena request that did not
     // fit, in KiB) -- launched in index order the read that alone sets the launch's duration started as late as a third of the way in
     const u32 *list; const u32 *list_n;
+    // the fused first stage (k_gap_all): nteams workgroups are teams (arena2_bytes each, at the start of `arena`), the others hold 16 single-wave
+    // workers each (arena_bytes each, behind the teams' arenas).  Teams take the reads expected to be heavy (the first *n_heavy of `order`) and
+    // whatever the single waves hand over through the queue q (ctl words in `next`: 0 next light read, 1 next heavy read, 2 queue tail, 3 queue
+    // head, 4 single waves through, 5 all of them through, 16 reads done by teams)
+    u32 nteams, nbulk_waves; u64 arena2_bytes; const u32 *n_heavy; u32 *q;
     u64 cap_ticks;           // first launch: a read still busy after this many 10 ns ticks is left to the team launch (0 = no limit)
     const u32 *order;        // first launch: reads [lo, n) by decreasing uncovered length (k_gap_rank) -- the long ones start first, the launch's tail is short ones
 };
@@ -41,10 +46,14 @@ struct GapArgs {
 #endif
 // launches k_gap (team = 0: one wave per workgroup) or k_gap_team (K_GAP_TEAM waves per workgroup) on `grid` workgroups
 hipError_t launch_gap(const GapArgs &A, int team, unsigned grid, hipStream_t stream);
+hipError_t launch_gap_all(const GapArgs &A, unsigned grid, hipStream_t stream);     // the fused first stage: A.nteams team workgroups + (grid - A.nteams) x 16 single waves
 // the flagged reads of [lo, n) into list[0 .. *list_n), heaviest first (one workgroup; more than GAP_LIST_SORT_MAX stay in index order)
 #define GAP_LIST_SORT_MAX 4096
 hipError_t launch_gap_order(const u32 *gap_flag, unsigned lo, unsigned n, u32 *list, u32 *list_n, hipStream_t stream);
-// order[0 .. n - lo) = the reads of [lo, n) by decreasing (read length - 96 x cords): what is left uncovered is what the gap re-mapper works on
-hipError_t launch_gap_rank(const u32 *nout, const u64 *off, unsigned lo, unsigned n, u32 *order, hipStream_t stream);
+// weight[r] = pairs of equal 9-mers inside the stretches of read r that its cords leave uncovered (hashed into 4096 bins): what the gap re-mapper's
+// k-mer joins and chain DPs will be busy with -- a read over a tandem repeat or a homopolymer run scores 10^5 .. 10^7, an ordinary one a few hundred
+hipError_t launch_gap_weight(const u8 *reads, const u64 *off, const u64 *out_str, const u64 *cords_off, const u32 *nout, unsigned lo, unsigned n, u32 *weight, hipStream_t stream);
+// order[0 .. n - lo) = the reads of [lo, n) by decreasing weight (1024 logarithmic bins); *n_heavy = how many of them weigh heavy_w or more
+hipError_t launch_gap_rank(const u32 *weight, unsigned lo, unsigned n, u32 *order, u32 *n_heavy, u32 heavy_w, hipStream_t stream);
 
 }  // namespace lnr

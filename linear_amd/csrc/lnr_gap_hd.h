@@ -121,6 +121,7 @@ struct GapCtx {                                           // one read
     int team = 0; struct GapTeam *tm = nullptr;           // device: helper waves of the workgroup for the long rows of the chain DP (k_gap_team)
 #ifdef LNR_GAP_DEVPROF
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ticks per phase (diagnostic build, tools/measure/gap_prof.sh)
+    unsigned long long dp_t = 0, dp_n = 0, dp_mode = 0, dp_fn = 0;          // the read's longest chain DP: ticks, anchors, 1 = by columns, score function
 #endif
     LNR_HD GSeq ref(u64 id) const { GSeq s; s.p = g + seq_off[id]; s.len = seq_len[id]; return s; }
 };
@@ -925,6 +926,11 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
     r.score[0] = 0; r.len[0] = 1; r.p2[0] = -1;
     {
     GP(X, 4);
+#if defined(LNR_GAP_DEVPROF) && defined(__HIP_DEVICE_COMPILE__)
+    struct DpT { GapCtx &X; u32 n; int fn; bool *bc; unsigned long long t0; __device__ ~DpT() { unsigned long long t = wall_clock64() - t0; if (t > X.dp_t) { X.dp_t = t; X.dp_n = n; X.dp_mode = *bc; X.dp_fn = (unsigned long long)fn; } } };
+    bool by_columns_ = false;
+    DpT dpt_{X, n, fn_id, &by_columns_, (unsigned long long)wall_clock64()};
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     bool by_columns = false;
     u32 *xs_ = nullptr;
@@ -937,6 +943,9 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
         by_columns = tm->dup == 0;                               // (a column held the same anchor twice: the single-wave form below redoes the DP)
         if (!by_columns) { for (u32 i = threadIdx.x & 63; i < n; i += 64) { r.score[i] = 0; r.score2[i] = 0; r.len[i] = 0; r.p2[i] = 0; r.root[i] = 0; r.leaf[i] = 0; } WSYNC(); r.score[0] = 0; r.len[0] = 1; r.p2[0] = -1; }
     }
+#if defined(LNR_GAP_DEVPROF) && defined(__HIP_DEVICE_COMPILE__)
+    by_columns_ = by_columns;
+#endif
     if (by_columns) {}
     else if (X.coop) {
         // every lane runs the read's code with the same data; here the predecessors of anchor i are dealt over the lanes, 64 at a

@@ -151,6 +151,80 @@ template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp c
 #ifndef K_GAP_WAVES
 #define K_GAP_WAVES 4
 #endif
+// one read: mapGaps + reformCords on its cords in the per-read output slot, with the arena [mine, mine + arena_bytes).  Returns true when the read
+// could not be done here (arena, cord slot, deadline): its apxMap cords stay and gap_flag[r] = 1 + (the request that did not fit, KiB).
+// lvl: 0 first pass (one wave), 1 team with the middle arena, 2 team with the large one (statistics / profile only).
+// hands_off: the caller passes a read it could not do on to another workgroup OF THE SAME LAUNCH (k_gap_all), which then owns gap_flag[r]: two
+// workgroups may sit on different XCDs, whose L2s are written back in no particular order at the end of the kernel, so only one of them may
+// store to the word.
+__device__ bool gap_do_read(const GapArgs &A, u32 r, char *mine, u64 arena_bytes, GapTeam *tm, int team, bool flagged_only, int lvl, bool hands_off = false) {
+    u32 nc = A.nout[r];
+    u64 L = A.off[r + 1] - A.off[r];
+    if (L <= 200 || nc <= 1) { if (!flagged_only) A.gap_flag[r] = 0; return false; }
+    GArena all; all.init(mine, arena_bytes);
+    LeaderScratch *ls = (LeaderScratch *)all.get(sizeof(LeaderScratch));
+    u8 *rd = (u8 *)all.get(L + 64), *rc = (u8 *)all.get(L + 64);
+    u64 keep_bytes = ((u64)A.cords_cap[r] * 16 + (u64)nc * 64 + 8192) * 2;
+    char *kp = (char *)all.get(keep_bytes);
+    bool bad = all.ovf != 0;
+    u64 ar_want = 0;
+    if (!bad) {
+        const u8 *src = A.reads + A.off[r];
+        if (A.coop) {                                            // (the wave's lanes share the copy; every lane reads the arrays afterwards)
+            for (u64 k = threadIdx.x & 63; k < L; k += 64) { u8 b = src[k]; b = b > 4 ? 4 : b; rd[k] = b; rc[L - 1 - k] = b == 4 ? 4 : 3 - b; }
+            rd[L + (threadIdx.x & 63)] = 0; rc[L + (threadIdx.x & 63)] = 0;
+            WSYNC();
+        } else {
+            for (u64 k = 0; k < L; k++) { u8 b = src[k]; b = b > 4 ? 4 : b; rd[k] = b; rc[L - 1 - k] = b == 4 ? 4 : 3 - b; }
+            for (u32 k = 0; k < 64; k++) { rd[L + k] = 0; rc[L + k] = 0; }
+        }
+        GArena keep; keep.init(kp, keep_bytes);
+        GArena ar; ar.init(mine + all.off, arena_bytes - all.off);
+        GapCtx X;
+        X.ar = &ar; X.ls = ls; X.read.p = rd; X.read.len = L; X.com.p = rc; X.com.len = L;
+        X.g = A.g; X.seq_off = A.seq_off; X.seq_len = A.seq_len;
+        u32 nf = A.nf[r];
+        X.f1[0].p = A.f1 + A.f1_off[r]; X.f1[0].n = nf; X.f1[1].p = A.f1 + A.f1_off[r] + nf; X.f1[1].n = nf;
+        X.gf = A.gf;
+        X.gp.f_dup = A.f_dup; X.gp.thd_gap_len_min = A.gap_len_min;
+        const bool ext_in = r >= A.ext_from;
+        if (ext_in) X.gp.thd_cts_major_limit = 3;
+        X.coop = A.coop; X.work_cap = A.work_cap; X.team = team; X.tm = tm;
+        X.deadline = (A.cap_ticks && !flagged_only) ? wall_clock64() + A.cap_ticks : 0;
+        u64 *os = A.out_str + A.cords_off[r], *oe = A.out_end + A.cords_off[r];
+        GVec<u64> cs, ce; cs.init(&keep, nc * 2 + 64); ce.init(&keep, nc * 2 + 64);
+        for (u32 i = 0; i < nc; i++) { cs.push(os[i]); ce.push(oe[i]); }
+#ifdef LNR_GAP_DEVPROF
+        unsigned long long t_read = wall_clock64();
+#endif
+        int rc_ = gap_map_gaps(cs, ce, keep, X);
+        gap_reform_cords(cs, ce);
+#ifdef LNR_GAP_DEVPROF
+        if (A.prof && (A.coop ? (threadIdx.x & 63) == 0 : true)) {
+            unsigned long long *pp = A.prof + 16 * (lvl);
+            t_read = wall_clock64() - t_read;
+            for (int k = 0; k < 10; k++) atomicAdd(pp + k, X.prof[k]);
+            atomicAdd(pp + 11, t_read); atomicAdd(pp + 12, 1ULL);
+            A.prof[96 + r] = t_read | ((unsigned long long)(lvl) << 56);      // per-read time of the launch that did the read
+            if (!lvl) { A.prof[96 + A.n + r] = wall_clock64() - t_read; A.prof[96 + 2 * (unsigned long long)A.n + r] = wall_clock64(); }   // first launch: start and end tick of the read
+            if (atomicMax(pp + 15, t_read) < t_read) { unsigned long long *ps = A.prof + 48 + 16 * (lvl); for (int k = 0; k < 10; k++) ps[k] = X.prof[k]; ps[10] = r; ps[11] = L; ps[12] = nc; ps[13] = ar.hw; ps[14] = X.dp_t | (X.dp_mode << 60) | (X.dp_fn << 56); A.prof[90 + lvl] = X.dp_n; }
+        }
+#endif
+        bad = rc_ != 0 || ar.ovf || keep.ovf || cs.n > A.cords_cap[r] || cs.n != ce.n;
+        ar_want = ar.want > keep.want ? ar.want : keep.want;
+        if (!bad) {
+            if (!ext_in && X.gp.thd_cts_major_limit == 3 && (A.coop ? (threadIdx.x & 63) == 0 : true)) atomicMin(A.first_ext, r);
+            if (!A.probe) {
+                for (u32 i = 0; i < cs.n; i++) { os[i] = cs[i]; oe[i] = ce[i]; }
+                A.nout[r] = cs.n;
+            }
+        }
+    }
+    u64 wkib = (all.want > ar_want ? all.want : ar_want) >> 10;
+    if (!(bad && hands_off)) A.gap_flag[r] = bad ? 1u + (u32)(wkib < 0x3fffffffu ? wkib : 0x3fffffffu) : 0u;
+    if (A.last && bad) A.read_err[r] = 5;
+    return bad;
+}
 __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
     u32 worker = A.coop ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
 #ifdef LNR_GAP_DEVPROF
@@ -168,71 +242,7 @@ __device__ void gap_worker(const GapArgs &A, GapTeam *tm, int team) {
         if (r >= A.n) break;
         if (A.big && !A.gap_flag[r]) continue;
         if (A.big && threadIdx.x == 0) atomicAdd(A.next + 8, 1u);   // (statistics: reads of the second launch)
-        u32 nc = A.nout[r];
-        u64 L = A.off[r + 1] - A.off[r];
-        if (L <= 200 || nc <= 1) { if (!A.big) A.gap_flag[r] = 0; continue; }
-        GArena all; all.init(mine, A.arena_bytes);
-        LeaderScratch *ls = (LeaderScratch *)all.get(sizeof(LeaderScratch));
-        u8 *rd = (u8 *)all.get(L + 64), *rc = (u8 *)all.get(L + 64);
-        u64 keep_bytes = ((u64)A.cords_cap[r] * 16 + (u64)nc * 64 + 8192) * 2;
-        char *kp = (char *)all.get(keep_bytes);
-        bool bad = all.ovf != 0;
-        u64 ar_want = 0;
-        if (!bad) {
-            const u8 *src = A.reads + A.off[r];
-            if (A.coop) {                                            // (the wave's lanes share the copy; every lane reads the arrays afterwards)
-                for (u64 k = threadIdx.x & 63; k < L; k += 64) { u8 b = src[k]; b = b > 4 ? 4 : b; rd[k] = b; rc[L - 1 - k] = b == 4 ? 4 : 3 - b; }
-                rd[L + (threadIdx.x & 63)] = 0; rc[L + (threadIdx.x & 63)] = 0;
-                WSYNC();
-            } else {
-                for (u64 k = 0; k < L; k++) { u8 b = src[k]; b = b > 4 ? 4 : b; rd[k] = b; rc[L - 1 - k] = b == 4 ? 4 : 3 - b; }
-                for (u32 k = 0; k < 64; k++) { rd[L + k] = 0; rc[L + k] = 0; }
-            }
-            GArena keep; keep.init(kp, keep_bytes);
-            GArena ar; ar.init(mine + all.off, A.arena_bytes - all.off);
-            GapCtx X;
-            X.ar = &ar; X.ls = ls; X.read.p = rd; X.read.len = L; X.com.p = rc; X.com.len = L;
-            X.g = A.g; X.seq_off = A.seq_off; X.seq_len = A.seq_len;
-            u32 nf = A.nf[r];
-            X.f1[0].p = A.f1 + A.f1_off[r]; X.f1[0].n = nf; X.f1[1].p = A.f1 + A.f1_off[r] + nf; X.f1[1].n = nf;
-            X.gf = A.gf;
-            X.gp.f_dup = A.f_dup; X.gp.thd_gap_len_min = A.gap_len_min;
-            const bool ext_in = r >= A.ext_from;
-            if (ext_in) X.gp.thd_cts_major_limit = 3;
-            X.coop = A.coop; X.work_cap = A.work_cap; X.team = team; X.tm = tm;
-            X.deadline = A.cap_ticks ? wall_clock64() + A.cap_ticks : 0;
-            u64 *os = A.out_str + A.cords_off[r], *oe = A.out_end + A.cords_off[r];
-            GVec<u64> cs, ce; cs.init(&keep, nc * 2 + 64); ce.init(&keep, nc * 2 + 64);
-            for (u32 i = 0; i < nc; i++) { cs.push(os[i]); ce.push(oe[i]); }
-#ifdef LNR_GAP_DEVPROF
-            unsigned long long t_read = wall_clock64();
-#endif
-            int rc_ = gap_map_gaps(cs, ce, keep, X);
-            gap_reform_cords(cs, ce);
-#ifdef LNR_GAP_DEVPROF
-            if (A.prof && threadIdx.x == (A.coop ? 0u : threadIdx.x)) {
-                unsigned long long *pp = A.prof + 16 * (A.big + A.last);
-                t_read = wall_clock64() - t_read;
-                for (int k = 0; k < 10; k++) atomicAdd(pp + k, X.prof[k]);
-                atomicAdd(pp + 11, t_read); atomicAdd(pp + 12, 1ULL);
-                A.prof[96 + r] = t_read | ((unsigned long long)(A.big + A.last) << 56);      // per-read time of the launch that did the read
-                if (!A.big) { A.prof[96 + A.n + r] = wall_clock64() - t_read; A.prof[96 + 2 * (unsigned long long)A.n + r] = wall_clock64(); }   // first launch: start and end tick of the read
-                if (atomicMax(pp + 15, t_read) < t_read) { unsigned long long *ps = A.prof + 48 + 16 * (A.big + A.last); for (int k = 0; k < 10; k++) ps[k] = X.prof[k]; ps[10] = r; ps[11] = L; ps[12] = nc; ps[13] = ar.hw; }
-            }
-#endif
-            bad = rc_ != 0 || ar.ovf || keep.ovf || cs.n > A.cords_cap[r] || cs.n != ce.n;
-            ar_want = ar.want > keep.want ? ar.want : keep.want;
-            if (!bad) {
-                if (!ext_in && X.gp.thd_cts_major_limit == 3 && threadIdx.x == (A.coop ? 0u : threadIdx.x)) atomicMin(A.first_ext, r);
-                if (!A.probe) {
-                    for (u32 i = 0; i < cs.n; i++) { os[i] = cs[i]; oe[i] = ce[i]; }
-                    A.nout[r] = cs.n;
-                }
-            }
-        }
-        u64 wkib = (all.want > ar_want ? all.want : ar_want) >> 10;
-        A.gap_flag[r] = bad ? 1u + (u32)(wkib < 0x3fffffffu ? wkib : 0x3fffffffu) : 0u;
-        if (A.last && bad) A.read_err[r] = 5;
+        gap_do_read(A, r, mine, A.arena_bytes, tm, team, A.big != 0, A.big + A.last);
     }
 #ifdef LNR_GAP_DEVPROF
     if (A.prof && threadIdx.x == 0 && !A.big) atomicAdd(A.prof + 94, ~0ULL);
@@ -249,6 +259,71 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * K_GAP_TEAM, 64 *
     __syncthreads();                                             // (A) with the exit command: the helpers leave
 }
 
+
+// ---- the fused first stage.  One launch, workgroups of 16 waves: the first A.nteams are TEAMS (wave 0 runs reads, the others serve its DPs,
+// sorts and joins), every other workgroup is 16 independent single-wave workers.  Workgroups are placed in index order, so the teams hold their
+// CUs before the single waves flood the rest of the chip.  The reads come ordered by weight (k_gap_weight / k_gap_rank): teams start on the ones
+// expected to be heavy at once -- their critical path, not the work, is what the stage waits for -- while the single waves take the light end;
+// a single wave that cannot finish a read (arena, deadline) posts it in the queue and a team picks it up.  The stage ends when the single waves
+// are through and the queue is empty.  Which worker a read ends up with does not change its result.
+__global__ void __attribute__((amdgpu_flat_work_group_size(1024, 1024))) k_gap_all(GapArgs A) {
+    __shared__ GapTeam tm;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 *ctl = A.next;
+    const u32 m = A.n - A.lo;
+    u32 nheavy = *A.n_heavy;
+    if (nheavy > m) nheavy = m;
+    if (blockIdx.x < A.nteams) {
+        if (wave) { gap_team_helper_loop(&tm, (int)wave, 16); return; }
+        char *mine = A.arena + (u64)blockIdx.x * A.arena2_bytes;
+        for (;;) {                                                   // 1. the reads expected to be heavy, heaviest first
+            u32 k = lane == 0 ? atomicAdd(ctl + 1, 1u) : 0u;
+            k = (u32)__shfl((int)k, 0);
+            if (k >= nheavy) break;
+            if (lane == 0) atomicAdd(ctl + 16, 1u);
+            gap_do_read(A, A.order[k], mine, A.arena2_bytes, &tm, 16, false, 1);
+        }
+        for (;;) {                                                   // 2. what the single waves hand over, until they are all through
+            u32 k = lane == 0 ? atomicAdd(ctl + 3, 1u) : 0u;
+            k = (u32)__shfl((int)k, 0);
+            u32 v = 0;
+            for (;;) {
+                u32 done = 0, tail = 0;
+                if (lane == 0) { v = atomicAdd(A.q + k, 0u); if (!v) { done = atomicAdd(ctl + 5, 0u); tail = atomicAdd(ctl + 2, 0u); } }
+                v = (u32)__shfl((int)v, 0); done = (u32)__shfl((int)done, 0); tail = (u32)__shfl((int)tail, 0);
+                if (v || (done && k >= tail)) break;
+                __builtin_amdgcn_s_sleep(127);
+            }
+            if (!v) break;
+            if (lane == 0) atomicAdd(ctl + 16, 1u);
+            gap_do_read(A, v - 1, mine, A.arena2_bytes, &tm, 16, true, 1);
+        }
+        if (lane == 0) tm.cmd = 0;
+        __syncthreads();                                             // (A) with the exit command: the helpers leave
+    } else {
+        u32 worker = (blockIdx.x - A.nteams) * 16 + wave;
+        char *mine = A.arena + (u64)A.nteams * A.arena2_bytes + (u64)worker * A.arena_bytes;
+#ifdef LNR_GAP_DEVPROF
+        if (A.prof && lane == 0) { unsigned long long c = atomicAdd(A.prof + 94, 1ULL) + 1; atomicMax(A.prof + 95, c); }
+#endif
+        for (;;) {
+            u32 k = lane == 0 ? atomicAdd(ctl, 1u) : 0u;
+            k = (u32)__shfl((int)k, 0);
+            if (nheavy + k >= m) break;
+            u32 r = A.order[nheavy + k];
+            bool bad = gap_do_read(A, r, mine, A.arena_bytes, nullptr, 1, false, 0, true);
+            if (bad && lane == 0) { u32 slot = atomicAdd(ctl + 2, 1u); atomicExch(A.q + slot, r + 1); }
+        }
+        if (lane == 0) { u32 e = atomicAdd(ctl + 4, 1u) + 1; if (e == A.nbulk_waves) atomicExch(ctl + 5, 1u); }
+#ifdef LNR_GAP_DEVPROF
+        if (A.prof && lane == 0) atomicAdd(A.prof + 94, ~0ULL);
+#endif
+    }
+}
+hipError_t launch_gap_all(const GapArgs &A, unsigned grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gap_all, dim3(grid), dim3(1024), 0, stream, A);
+    return hipGetLastError();
+}
 
 // flagged reads of [lo, n) -> list, heaviest first: one workgroup collects them (ballot compaction, index order) and, up to GAP_LIST_SORT_MAX of
 // them, sorts (weight descending, index ascending) with a bitonic network in LDS
@@ -296,25 +371,70 @@ __global__ void __launch_bounds__(1024) k_gap_order(const u32 *gap_flag, u32 lo,
         }
     for (u32 i = tid; i < cnt; i += 1024) list[i] = (u32)key[i];
 }
-__global__ void __launch_bounds__(1024) k_gap_rank(const u32 *nout, const u64 *off, u32 lo, u32 n, u32 *order) {
+__global__ void __launch_bounds__(64) k_gap_weight(const u8 *reads, const u64 *off, const u64 *out_str, const u64 *cords_off, const u32 *nout, u32 lo, u32 n, u32 *weight) {
+    __shared__ u32 cov[1024];           // one bit per 32 bases of the read (reads of up to 2^20 bases: 32768 cells)
+    __shared__ unsigned short bin[4096];
+    const u32 r = lo + blockIdx.x, lane = threadIdx.x;
+    if (r >= n) return;
+    const u64 L = off[r + 1] - off[r];
+    const u32 nc = nout[r];
+    if (L <= 200 || nc <= 1 || L > (1u << 20)) { if (lane == 0) weight[r] = 0; return; }
+    const u32 ncell = (u32)((L + 31) >> 5), nw = (ncell + 31) >> 5;
+    for (u32 i = lane; i < nw; i += 64) cov[i] = 0;
+    for (u32 i = lane; i < 4096; i += 64) bin[i] = 0;
+    __syncthreads();
+    const u64 *c = out_str + cords_off[r];
+    for (u32 i = 1 + lane; i < nc; i += 64) {                    // a cord covers 96 bases of the read from its y (on the strand the cord is on)
+        u64 v = c[i];
+        u64 y = cord_y(v);
+        if (cord_strand(v)) y = L > y + 96 ? L - y - 96 : 0;
+        u32 c0 = (u32)(y >> 5), c1 = (u32)((y + 95) >> 5);
+        for (u32 q = c0; q <= c1 && q < ncell; q++) atomicOr(&cov[q >> 5], 1u << (q & 31));
+    }
+    __syncthreads();
+    const u8 *rd = reads + off[r];
+    u32 w = 0;
+    for (u64 p = lane; p + 9 <= L; p += 64) {
+        u32 cell = (u32)(p >> 5);
+        if ((cov[cell >> 5] >> (cell & 31)) & 1) continue;
+        u32 code = 0, bad = 0;
+        for (int k = 0; k < 9; k++) { u32 b = rd[p + k]; bad |= b > 3; code = code * 4 + (b & 3); }
+        if (bad) continue;
+        u32 h = (code ^ (code >> 7)) & 4095u;
+        u32 old = (u32)atomicAdd((unsigned int *)&bin[h & ~1u], (h & 1) ? 0x10000u : 1u);       // (two 16-bit counters per word)
+        old = (h & 1) ? old >> 16 : old & 0xffffu;
+        w += old < 60000u ? old : 60000u;
+    }
+    w = wave_sum(w);
+    if (lane == 0) weight[r] = w;
+}
+hipError_t launch_gap_weight(const u8 *reads, const u64 *off, const u64 *out_str, const u64 *cords_off, const u32 *nout, unsigned lo, unsigned n, u32 *weight, hipStream_t stream) {
+    if (n > lo) hipLaunchKernelGGL(k_gap_weight, dim3(n - lo), dim3(64), 0, stream, reads, off, out_str, cords_off, nout, lo, n, weight);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(1024) k_gap_rank(const u32 *weight, u32 lo, u32 n, u32 *order, u32 *n_heavy, u32 heavy_w) {
     __shared__ u32 bin[1024];
+    __shared__ u32 s_heavy;
     const u32 tid = threadIdx.x;
     bin[tid] = 0;
+    if (tid == 0) s_heavy = 0;
     __syncthreads();
-    auto key = [&](u32 r) -> u32 {
-        u64 L = off[r + 1] - off[r], cov = 96ULL * nout[r];
-        u64 unc = L > cov ? L - cov : 0;
-        u32 k = (u32)(unc >> 5);
-        return 1023u - (k < 1023u ? k : 1023u);              // bin 0 = the most uncovered
+    auto key = [&](u32 r) -> u32 {                            // 32 bins per power of two, bin 0 = the heaviest
+        u32 w = weight[r];
+        if (w == 0) return 1023u;
+        u32 lg = 31u - (u32)__builtin_clz(w);
+        u32 frac = lg >= 5 ? (w >> (lg - 5)) & 31u : (w << (5 - lg)) & 31u;
+        u32 k = lg * 32 + frac;
+        return 1023u - (k < 1022u ? k : 1022u);
     };
-    for (u32 r = lo + tid; r < n; r += 1024) atomicAdd(&bin[key(r)], 1u);
+    for (u32 r = lo + tid; r < n; r += 1024) { atomicAdd(&bin[key(r)], 1u); if (weight[r] >= heavy_w) atomicAdd(&s_heavy, 1u); }
     __syncthreads();
-    if (tid == 0) { u32 acc = 0; for (u32 b = 0; b < 1024; b++) { u32 c = bin[b]; bin[b] = acc; acc += c; } }
+    if (tid == 0) { u32 acc = 0; for (u32 b = 0; b < 1024; b++) { u32 c = bin[b]; bin[b] = acc; acc += c; } *n_heavy = s_heavy; }
     __syncthreads();
     for (u32 r = lo + tid; r < n; r += 1024) order[atomicAdd(&bin[key(r)], 1u)] = r;
 }
-hipError_t launch_gap_rank(const u32 *nout, const u64 *off, unsigned lo, unsigned n, u32 *order, hipStream_t stream) {
-    hipLaunchKernelGGL(k_gap_rank, dim3(1), dim3(1024), 0, stream, nout, off, lo, n, order);
+hipError_t launch_gap_rank(const u32 *weight, unsigned lo, unsigned n, u32 *order, u32 *n_heavy, u32 heavy_w, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gap_rank, dim3(1), dim3(1024), 0, stream, weight, lo, n, order, n_heavy, heavy_w);
     return hipGetLastError();
 }
 hipError_t launch_gap_order(const u32 *gap_flag, unsigned lo, unsigned n, u32 *list, u32 *list_n, hipStream_t stream) {

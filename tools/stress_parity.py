@@ -75,12 +75,13 @@ def main():
         jitter = float(rng.choice([0.0, 0.5]))
         # library options (read at lnr_create): exercise the other size classes and orchestration modes now and then
         opt = OPTION_SETS[int(rng.integers(0, len(OPTION_SETS)))]
+        gap_len, dup = 0, 0
+        if with_gap:                                  # (drawn before a configuration is skipped: LNR_STRESS_ONLY re-runs exactly the configuration of the full run)
+            gap_len, dup = int(rng.choice([1, 5, 50, 200])), int(rng.integers(0, 2))
         if only and k not in only:
             continue
         reads, off, _ = synth.sample_reads(refs, nreads, L, err, s + 7, "random", len_jitter=jitter)
-        gap_len, dup = 0, 0
         if with_gap:
-            gap_len, dup = int(rng.choice([1, 5, 50, 200])), int(rng.integers(0, 2))
             reads, off = plant_svs(reads, off, refs, np.random.default_rng(s + 11))
         for kv in ALL_KEYS:
             os.environ.pop(kv, None)
@@ -91,11 +92,17 @@ def main():
         t1 = time.time()
         for lib in libs:
             from linear_amd import api
+            lib, *envs = lib.split("@")                   # lib.so@KEY=VAL@KEY=VAL: library knobs for this one run
             api.SO = os.path.abspath(lib)
+            saved = {e.split("=")[0]: os.environ.get(e.split("=")[0]) for e in envs}
+            os.environ.update(dict(e.split("=", 1) for e in envs))
             f = Filter(device=0, index_type=itype, gap_len=gap_len, dup=dup)
             f.build_index(refs, T)
             coff, cs, ce = f.filter_batch(reads, off)
+            lib = lib + " " + " ".join(envs) + f" (second-pass reads {f.stats()['gap_second_pass']})"
             f.close()
+            for kk, vv in saved.items():
+                os.environ.pop(kk, None) if vv is None else os.environ.__setitem__(kk, vv)
             same = bool(np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce))
             nd = -1
             if not same and np.array_equal(coff, ooff):
@@ -110,6 +117,13 @@ def main():
         f.close()
         same = bool(np.array_equal(coff, ooff) and np.array_equal(cs, ocs) and np.array_equal(ce, oce))
         bad += 0 if same else 1
+        if not same:
+            nr = off.size - 1
+            diff = [i for i in range(nr) if not (int(coff[i + 1] - coff[i]) == int(ooff[i + 1] - ooff[i]) and np.array_equal(cs[int(coff[i]):int(coff[i + 1])], ocs[int(ooff[i]):int(ooff[i + 1])])
+                                                 and np.array_equal(ce[int(coff[i]):int(coff[i + 1])], oce[int(ooff[i]):int(ooff[i + 1])]))]
+            print(f"[stress] cfg {k}: reads that differ: {diff[:20]} ({len(diff)} of {nr})", flush=True)
+            if os.environ.get("LNR_STRESS_SAVE"):
+                np.savez_compressed(os.environ["LNR_STRESS_SAVE"], reads=reads, off=off, T=T, gap_len=gap_len, dup=dup, itype=itype, nrefs=len(refs), **{f"ref{q}": r for q, r in enumerate(refs)})
         print(f"[stress] cfg {k}: kind {kind} T {T} L {L} err {err} reads {nreads} opts {opt} -g {gap_len} -dup {dup} (second-pass reads {second}) cords {cs.size}: {'ok' if same else 'MISMATCH'} (oracle {t1 - t0:.1f}s)", flush=True)
     nrun = len(only) if only else ncfg
     print(f"[stress] {nrun - bad}/{nrun} configurations bit-exact (index type {itype})")
