@@ -80,6 +80,17 @@ LNR_HD inline void lnr_wave_sync() {
 // is shared between lanes).  The stage functions that differ take the mode as a template argument.
 template <bool COOP> LNR_HD inline bool lnr_leader() { return COOP ? lnr_is_leader() : true; }
 template <bool COOP> LNR_HD inline void lnr_sync() { if (COOP) lnr_wave_sync(); }
+// A value every lane of the wave holds identically, moved to scalar registers: what is computed from it afterwards runs on the scalar unit
+// instead of occupying the vector ALU for all 64 lanes (the SIMT-uniform phases are bound by VALU issue, not by memory).  Host: identity.
+LNR_HD inline u32 lnr_uni32(u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
+LNR_HD inline u64 lnr_uni64(u64 v) { return ((u64)lnr_uni32((u32)(v >> 32)) << 32) | (u64)lnr_uni32((u32)v); }
+template <bool COOP> LNR_HD inline u64 lnr_u64(u64 v) { return COOP ? lnr_uni64(v) : v; }
 // bounded vector view over caller-provided storage; overflow is recorded, never written past cap
 template <class T>
 struct Vec {
@@ -836,16 +847,28 @@ LNR_HD inline void prefilter_chains2(u64 *hits, u32 nhits, Vec<UP> &sep, u64 *cu
 }
 
 LNR_HD inline int block_score2(u64 c11, u64 c22) {   // getApxChainScore2 cluster_util.cpp:586-631
-    i64 dy = (i64)(cord_y(c11) - cord_y(c22));
-    i64 dx = (i64)(cord_x(c11) - cord_x(c22));
+    // 32-bit throughout: y has 20 bits, x 30, and past the range test dx, dy lie in [0, 20000], so every quotient of the reference's
+    // 64-bit arithmetic is a small unsigned one; floor(100 da / D) comes from a float estimate with an exact correction (as dp_pair_sderr)
+    i32 dy = (i32)((u32)c11 & 0xfffffu) - (i32)((u32)c22 & 0xfffffu);
+    i32 dx = (i32)((u32)(c11 >> 20) & 0x3fffffffu) - (i32)((u32)(c22 >> 20) & 0x3fffffffu);
     if (dx < 0 || dy < 0 || cord_strand(c11 ^ c22) || dx > 20000 || dy > 20000) return INT_MIN;
-    i64 da = labs64(dx - dy);
-    i64 derr = (100 * da) / max64(max64(labs64(dy), 100), labs64(dx));
-    if (da > 100 || derr > 50) {
-        if (dx < dy) return (int)(100 - 30 - dy / 1000 - dx / 100);
-        return (int)(100 - 30 - dy / 100 - dx / 1000);
+    u32 ux = (u32)dx, uy = (u32)dy;
+    u32 da = ux > uy ? ux - uy : uy - ux;
+    u32 D = uy > 100u ? uy : 100u; D = D > ux ? D : ux;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float inv = __builtin_amdgcn_rcpf((float)D);
+#else
+    float inv = 1.0f / (float)D;
+#endif
+    u32 n = 100u * da;                               // <= 2 000 000: exact in a float
+    u32 q = (u32)((float)n * inv);
+    i32 r = (i32)(n - q * D);                        // the true remainder lies in [-D, 2D)
+    q = r < 0 ? q - 1 : ((u32)r >= D ? q + 1 : q);
+    if (da > 100u || q > 50u) {
+        if (ux < uy) return (int)(100 - 30) - (int)(uy / 1000u) - (int)(ux / 100u);
+        return (int)(100 - 30) - (int)(uy / 100u) - (int)(ux / 1000u);
     }
-    return (int)(100 - dy / 95);
+    return 100 - (int)(uy / 95u);
 }
 LNR_HD inline int block_score3(u64 c11, u64 c12, u64 c21, u64 c22, u64 L, int strand) {   // getApxChainScore3 + getChainBlockDxDy cluster_util.cpp:774-863
     i64 dx, dy;
@@ -1029,16 +1052,27 @@ LNR_HD inline bool extend_window_serial(FeatView f1, FeatView f2, Vec<u64> &cord
 LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 &tail, u64 cordy_str, u64 cordy_end) {
     const int lane = (int)(threadIdx.x & 63);
     u32 p_str = cords.n - 1;
+    tail = lnr_uni64(tail); cordy_str = lnr_uni64(cordy_str); cordy_end = lnr_uni64(cordy_end);
+    // this lane's window inside the two frontiers
+    const int d = lane < 3 ? 1 : (lane < 11 ? 2 : (lane < 26 ? 3 : 4));
+    const int pre = d == 1 ? 0 : (d == 2 ? 3 : (d == 3 ? 11 : 26));
+    const int la = (lane - pre) / (d + 2), lu = (lane - pre) % (d + 2) - 1;
+    int s_ = 1;
+    while ((s_ + 1) * (s_ + 1) - 1 <= lane) s_++;          // lane -> step: s^2 - 1 <= lane < (s + 1)^2 - 1
+    const int off = lane - (s_ * s_ - 1);
+    // Both walks start at the cord just pushed (after the backward cords are reversed the tail is that cord again): the first frontier of the
+    // forward walk is loaded together with the backward one -- one memory round trip for the two.
+    u32 dvf0;
+    {
+        u64 x0 = cord_x(tail) >> 4, y0 = cord_y(tail) >> 4;
+        dvf0 = lane < 63 ? wdist_raw(f1, f2, y0 + 5 * (u64)s_, x0 + 3 * (u64)s_ + (u64)off) : 0xffffffffu;
+    }
     // ---- backward
     {
-        int d = lane < 3 ? 1 : (lane < 11 ? 2 : (lane < 26 ? 3 : 4));
-        int pre = d == 1 ? 0 : (d == 2 ? 3 : (d == 3 ? 11 : 26));
-        int idx = lane - pre;
-        int la = idx / (d + 2), lu = idx % (d + 2) - 1;
         bool stop = false;
         while (!stop) {
-            u64 gid = cord_id(tail), strand = cord_strand(tail);
-            i64 x0 = (i64)(cord_x(tail) >> 4), y0 = (i64)(cord_y(tail) >> 4);
+            const u64 gid = cord_id(tail), strand = cord_strand(tail);
+            const i64 x0 = (i64)(cord_x(tail) >> 4), y0 = (i64)(cord_y(tail) >> 4);
             i64 Y = y0 - 5 * d + la, X = x0 - 5 * d + lu;
             u32 dv = (lane < 50 && Y >= 0 && X >= 0) ? wdist_raw(f1, f2, (u64)Y, (u64)X) : 0xffffffffu;
             int a = 0, c = 0;
@@ -1047,7 +1081,7 @@ LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 
                 if (y < 5 || x < 6) { stop = true; break; }
                 int dd = k + 1;
                 int bl = (dd == 1 ? 0 : (dd == 2 ? 3 : (dd == 3 ? 11 : 26))) + a * (dd + 2) + c;
-                u32 t0 = __shfl(dv, bl), t1 = __shfl(dv, bl + 1), t2 = __shfl(dv, bl + 2);
+                u32 t0 = (u32)__builtin_amdgcn_readlane((int)dv, bl), t1 = (u32)__builtin_amdgcn_readlane((int)dv, bl + 1), t2 = (u32)__builtin_amdgcn_readlane((int)dv, bl + 2);
                 u32 mn = t0; int j = 0;
                 if (t1 < mn) { mn = t1; j = 1; }
                 if (t2 < mn) { mn = t2; j = 2; }
@@ -1067,23 +1101,21 @@ LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 
         if (lnr_is_leader())
             for (u32 k = p_str; k < (p_str + p_end) / 2; k++) rs_swap(cords[k], cords[cords.n - k + p_str - 1]);
         lnr_wave_sync();
-        tail = cords[cords.n - 1];
+        tail = lnr_uni64(cords[cords.n - 1]);
     }
     // ---- forward
     {
-        int s_ = 1;
-        while ((s_ + 1) * (s_ + 1) - 1 <= lane) s_++;          // lane -> step: s^2 - 1 <= lane < (s + 1)^2 - 1
-        int off = lane - (s_ * s_ - 1);
-        bool stop = false;
+        bool stop = false, have = true;
         while (!stop) {
-            u64 gid = cord_id(tail), strand = cord_strand(tail);
-            u64 x0 = cord_x(tail) >> 4, y0 = cord_y(tail) >> 4;
-            u32 dv = lane < 63 ? wdist_raw(f1, f2, y0 + 5 * (u64)s_, x0 + 3 * (u64)s_ + (u64)off) : 0xffffffffu;
+            const u64 gid = cord_id(tail), strand = cord_strand(tail);
+            const u64 x0 = cord_x(tail) >> 4, y0 = cord_y(tail) >> 4;
+            u32 dv = have ? dvf0 : (lane < 63 ? wdist_raw(f1, f2, y0 + 5 * (u64)s_, x0 + 3 * (u64)s_ + (u64)off) : 0xffffffffu);
+            have = false;
             u64 xc = x0, yc = y0;
             for (int k = 1; k <= 7; k++) {
                 if (yc + 12 > f1.n || xc + 12 > f2.n) { stop = true; break; }
                 int bl = k * k - 1 + (int)(xc - x0) - 3 * (k - 1);
-                u32 t0 = __shfl(dv, bl), t1 = __shfl(dv, bl + 1), t2 = __shfl(dv, bl + 2);
+                u32 t0 = (u32)__builtin_amdgcn_readlane((int)dv, bl), t1 = (u32)__builtin_amdgcn_readlane((int)dv, bl + 1), t2 = (u32)__builtin_amdgcn_readlane((int)dv, bl + 2);
                 u32 mn = t0; u64 x_min = xc + 3;
                 if (t1 < mn) { mn = t1; x_min = xc + 4; }
                 if (t2 < mn) { mn = t2; x_min = xc + 5; }
@@ -1134,20 +1166,21 @@ LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], 
     if (hitBegin >= hitEnd - 1) return;
     u64 tail;
     if (cords.n == 0) { cords.template push_m<COOP>(F_END); tail = F_END; }   // initCords
-    else tail = cords[cords.n - 1];
+    else tail = lnr_u64<COOP>(cords[cords.n - 1]);
     u64 ready_str, ready_end, cordy_str = 0, cordy_end = 0;
     bool f_sp_l, f_sp_r = false, f_block_end = false, f_append;
     i64 itt_next = hitBegin + 1, itt_first = hitBegin;
     for (i64 itt = hitBegin; itt < hitEnd; itt = itt_next++) {
-        u64 hi = hits[itt];
-        bool first_i = is_end(hits[itt - 1]);
+        const u64 hi = lnr_u64<COOP>(hits[itt]), hpv = lnr_u64<COOP>(hits[itt - 1]);
+        bool first_i = is_end(hpv);
         ready_str = cord_strand(hi) ? L - read_end : read_str;
         ready_end = cord_strand(hi) ? L - read_str + 1 : read_end;
-        i64 da_l = first_i ? 0 : labs64((i64)(cord_x(hi) - cord_x(hits[itt - 1]) - cord_y(hi) + cord_y(hits[itt - 1])));
-        f_sp_l = (da_l > 80) || cord_strand(hi ^ hits[itt - 1]);
+        i64 da_l = first_i ? 0 : labs64((i64)(cord_x(hi) - cord_x(hpv) - cord_y(hi) + cord_y(hpv)));
+        f_sp_l = (da_l > 80) || cord_strand(hi ^ hpv);
         while (1) {
-            if (itt_next >= hitEnd || is_end(hits[itt_next - 1])) { f_block_end = true; itt_first = itt_next; break; }
-            u64 hn = hits[itt_next], hp = hits[itt_next - 1];
+            if (itt_next >= hitEnd) { f_block_end = true; itt_first = itt_next; break; }
+            const u64 hn = lnr_u64<COOP>(hits[itt_next]), hp = lnr_u64<COOP>(hits[itt_next - 1]);
+            if (is_end(hp)) { f_block_end = true; itt_first = itt_next; break; }
             i64 da_r = labs64((i64)(cord_x(hn) - cord_x(hp) - cord_y(hn) + cord_y(hp)));
             f_sp_r = (da_r > 80) || cord_strand(hn ^ hp);
             if ((cord_y(hi) + 96 < cord_y(hn) && cord_x(hi) + 96 < cord_x(hn)) || f_sp_r) break;
@@ -1156,12 +1189,12 @@ LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], 
         f_append = false;
         if (!f_sp_r && !f_block_end) {
             cordy_str = f_sp_l ? hi : (first_i ? ready_str : cord_y(tail));
-            cordy_end = cord_y(hits[itt_next]);
+            cordy_end = cord_y(lnr_u64<COOP>(hits[itt_next]));
             if (cords.n >= cords.cap) { if (lnr_leader<COOP>()) *cords.ovf = 1; return; }
             cords.template push_m<COOP>(hi & ~F_END); tail = hi & ~F_END;
             f_append = true;
         } else {
-            u64 hl = hits[itt_next - 1];
+            const u64 hl = lnr_u64<COOP>(hits[itt_next - 1]);
             if (!f_sp_l && cord_y(hl) >= 96 && cord_x(hl) >= 96) {
                 u64 nc = shift_cord(hl, -96, -96);
                 cordy_str = first_i ? read_str : cord_y(nc);
@@ -1338,8 +1371,11 @@ LNR_HD inline bool job_carve(Arena &ar, u32 cap, JobScratch &S, int *ovf) {
     S.xs = ar.get<u32>(c2); S.ys = ar.get<u32>(c2);
     S.rec.score = ar.get<i32>(c2); S.rec.score2 = ar.get<i32>(c2); S.rec.len = ar.get<i32>(c2);
     S.rec.p2 = ar.get<i32>(c2); S.rec.root = ar.get<i32>(c2); S.rec.leaf = ar.get<i32>(c2);
-    S.hits.init(ar.get<u64>(c2), c2, ovf);
-    S.hscore.init(ar.get<i32>(c2), c2, ovf);
+    // hits / hscore: always behind the fast region (the kernels reuse the whole fast region once the anchor traceback has filled them)
+    Arena &far_ = ar.next ? *ar.next : ar;
+    S.hits.init(far_.get<u64>(c2), c2, ovf);
+    S.hscore.init(far_.get<i32>(c2), c2, ovf);
+    if (far_.ovf) ar.ovf = 1;
     S.cnt = ar.get<i32>(c2); S.chain = ar.get<i32>(c2); S.chain_sc = ar.get<i32>(c2);
     S.sep.init(ar.get<UP>(c2), c2, ovf);
     S.sep_score = ar.get<i32>(c2);

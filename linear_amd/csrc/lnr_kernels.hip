@@ -2113,6 +2113,113 @@ __device__ JOB_INLINE void traceback_anchor_wave(Rec r, u32 n, AnchorSink &sink,
     }
 }
 
+// ---- the small tie-sensitive sorts of the block phases (a11-a13).  The arrays live in the job's global scratch, where lane 0's serial
+// emulation of std::sort pays a memory round trip per comparison.  Up to 16 elements std::sort IS a plain insertion sort, i.e. stable: every
+// lane ranks its element by counting (elements before it in the order + equal ones with a smaller index).  Longer arrays are staged in the
+// LDS tree tables (idle between the tracebacks), sorted there by lane 0 with the exact emulation, and copied back.
+#define JOB_STAGE_CAP 192      // l_root .. l_leaf (256 words) + ranks (64 u64), contiguous in LeaderScratch
+__device__ __forceinline__ u64 *job_stage_of(LeaderScratch &ls) {
+    static_assert(offsetof(LeaderScratch, l_root) % 8 == 0 && offsetof(LeaderScratch, ranks) == offsetof(LeaderScratch, l_root) + 1024, "stage = tree tables + ranks");
+    return (u64 *)ls.l_root;
+}
+template <class Comp>
+__device__ JOB_INLINE void small_sort_u64_wave(u64 *keys, u32 n, Comp comp, LeaderScratch &ls) {
+    int lane = lane_id();
+    if (n < 2) return;
+    if (n <= 16) {
+        u64 mine = (u32)lane < n ? keys[lane] : 0;
+        u32 rank = 0;
+        for (u32 t = 0; t < n; t++) { u64 o = __shfl(mine, (int)t); rank += (comp(o, mine) || (!comp(mine, o) && t < (u32)lane)) ? 1u : 0u; }
+        WSYNC();
+        if ((u32)lane < n) keys[rank] = mine;
+        WSYNC();
+        return;
+    }
+    if (n <= JOB_STAGE_CAP) {
+        u64 *stage = job_stage_of(ls);
+        for (u32 i = lane; i < n; i += 64) stage[i] = keys[i];
+        WSYNC();
+        if (lane == 0) ref_sort(stage, (long)n, comp, ls.st);
+        WSYNC();
+        for (u32 i = lane; i < n; i += 64) keys[i] = stage[i];
+        WSYNC();
+        return;
+    }
+    if (lane == 0) ref_sort(keys, (long)n, comp, ls.st);
+    WSYNC();
+}
+// gather_blocks(hits, nh, nullptr, sep, 1, nh, L, 600, 0, 0) (pmpfinder.cpp:1484-1530) with all lanes: a block ends before hit i when hit i - 1
+// closes a chain or the two are not consecutive; boundaries are compacted in index order.  Returns the number of blocks.
+__device__ JOB_INLINE u32 gather_blocks_wave(const u64 *hits, u32 nh, UP *sep, u32 sep_cap, int *ovf) {
+    if (nh < 2) return 0;
+    int lane = lane_id();
+    u32 nbd = 0;
+    for (u32 base = 2; base < nh; base += 64) {
+        u32 i = base + (u32)lane;
+        bool b = false;
+        if (i < nh) { u64 c0 = hits[i - 1], c1 = hits[i]; b = is_end(c0) || !consecutive(c0, c1, 600); }
+        u64 m = __ballot(b);
+        if (b) {
+            u32 pos = nbd + (u32)__popcll(m & lanemask_lt());
+            if (pos < sep_cap) sep[pos].second = i;
+            if (pos + 1 < sep_cap) sep[pos + 1].first = i;
+        }
+        nbd += (u32)__popcll(m);
+    }
+    u32 nb = nbd + 1;
+    if (nb > sep_cap) { if (lane == 0) *ovf = 1; nb = sep_cap; }
+    if (lane == 0) { sep[0].first = 1; if (nbd < sep_cap) sep[nbd].second = nh; }
+    WSYNC();
+    return nb;
+}
+// chain_blocks_prepare (f_sort = 1) with all lanes: keys, the tie-sensitive sort, the two gathers
+__device__ JOB_INLINE void chain_blocks_prepare_wave(const u64 *records, const UP *sep, const i32 *sep_score, u32 nb, BlockScratch s) {
+    int lane = lane_id();
+    u64 *e = (u64 *)s.sep_tmp;
+    for (u32 i = lane; i < nb; i += 64) e[i] = (cord_x40(records[sep[i].first]) << 24) | (u64)i;
+    WSYNC();
+    small_sort_u64_wave(e, nb, [](const u64 &a, const u64 &b) { return (a >> 24) > (b >> 24); }, *s.ls);
+    for (u32 i = lane; i < nb; i += 64) s.ptr[i] = (u32)(e[i] & 0xffffffu);
+    WSYNC();
+    for (u32 i = lane; i < nb; i += 64) { u32 q = s.ptr[i]; s.sep_tmp[i] = sep[q]; s.score_tmp[i] = sep_score[q]; }
+    WSYNC();
+}
+// filter_blocks_hits (_filterBlocksHits cluster_util.cpp:633-719) with all lanes: the chains' block ranges are copied 64 hits at a time.
+// nchains = the sink's chain count (broadcast by the caller: the sink itself was filled by lane 0).
+__device__ JOB_INLINE u32 filter_blocks_hits_wave(const BlockSink &ch, u32 nchains, const u64 *hits, u64 *out) {
+    if (nchains == 0) return 0xffffffffu;   // untouched
+    int lane = lane_id();
+    u32 n = 0, major_n = 1;
+    float bound = 0.0f;
+    for (u32 c = 0; c < nchains; c++) {
+        i32 e0 = ch.off[c], e1 = ch.off[c + 1];
+        u64 len_current = 0;
+        for (i32 eb = e0; eb < e1; eb += 64) {
+            i32 e = eb + lane;
+            u32 l = e < e1 ? (u32)(ch.el[e].second - ch.el[e].first) : 0u;
+            len_current += wave_sum(l);
+        }
+        bool append = true;
+        if (c == 0) bound = 0.8 * len_current;
+        else { append = major_n < 5 && (float)len_current > bound; if (append) ++major_n; }
+        if (!append) continue;
+        for (i32 eb = e0; eb < e1; eb += 64) {
+            i32 e = eb + lane;
+            u64 qf = 0, qs = 0;
+            if (e < e1) { UP q = ch.el[e]; qf = q.first; qs = q.second; }
+            int cnt = e1 - eb < 64 ? e1 - eb : 64;
+            for (int t = 0; t < cnt; t++) {
+                u64 f = __shfl(qf, t), sd = __shfl(qs, t);
+                bool last_range = eb + t + 1 == e1;
+                for (u64 k = f + (u64)lane; k < sd; k += 64) out[n + (u32)(k - f)] = (hits[k] & ~F_END) | ((last_range && k + 1 == sd) ? F_END : 0);
+                n += (u32)(sd - f);
+            }
+        }
+    }
+    WSYNC();
+    return n;
+}
+
 // wave-parallel twin of prefilter_chains2 (pmpfinder.cpp:2366-2446).  Cuts are visited in their (tie-sensitive) sorted
 // order; for one cut the blocks are independent, so lanes take one block each.  The pieces are re-sorted by their unique
 // end position afterwards, so the order in which lanes append them does not matter.  The j-loop's early stop
@@ -2131,8 +2238,7 @@ __device__ JOB_INLINE u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &
         xy_strs[i] = f;
     }
     WSYNC();
-    if (lane == 0) ref_sort(cuts, (long)(2 * nb), [](const u64 &a, const u64 &b) { return (a >> 32) < (b >> 32); }, ls.st);
-    WSYNC();
+    small_sort_u64_wave(cuts, 2 * nb, [](const u64 &a, const u64 &b) { return (a >> 32) < (b >> 32); }, ls);
     UP *tp = tmp.p;
     u32 ntmp = 0, tcap = tmp.cap;
     if (nb <= 64) {
@@ -2151,15 +2257,18 @@ __device__ JOB_INLINE u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &
             bool emit = false;
             UP piece; piece.first = 0; piece.second = 0;
             if ((u32)lane < jstar && !(cuty < ylow)) {
-                for (u64 k = lower; k < kend; k++) {
-                    u64 ky = k == lower ? ylow : cord_y(hits[k]);
-                    u64 upper; bool c;
-                    if (is_end) { if (ky == cuty) { upper = k + 1; c = true; } else if (ky > cuty) { upper = k; c = true; } else c = false; }
-                    else { if (ky >= cuty) { upper = k; c = true; } else c = false; }
-                    if (c) {
-                        if (lower != upper) { emit = true; piece.first = lower; piece.second = upper; lower = upper; ylow = lower < nhits ? cord_y(hits[lower]) : 0; }
-                        break;
-                    }
+                // the reference scans k upwards for the first hit with y >= cuty; inside a block y never decreases (gather_blocks keeps
+                // consecutive() hits together), so that hit is a lower bound -- a bisection instead of a scan of the block per cut
+                u64 lo = lower, hi_ = kend;
+                while (lo < hi_) {
+                    u64 mid = (lo + hi_) >> 1;
+                    u64 ky = mid == lower ? ylow : cord_y(hits[mid]);
+                    if (ky >= cuty) hi_ = mid; else lo = mid + 1;
+                }
+                if (lo < kend) {
+                    u64 ky = lo == lower ? ylow : cord_y(hits[lo]);
+                    u64 upper = (is_end && ky == cuty) ? lo + 1 : lo;
+                    if (lower != upper) { emit = true; piece.first = lower; piece.second = upper; lower = upper; ylow = lower < nhits ? cord_y(hits[lower]) : 0; }
                 }
             }
             u64 em = __ballot(emit);
@@ -2188,15 +2297,11 @@ __device__ JOB_INLINE u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &
                 u64 lower = xy_strs[j];
                 if (!(cuty < cord_y(hits[lower]))) {
                     u64 kend = sp[j].second;
-                    for (u64 k = lower; k < kend; k++) {
-                        u64 ky = cord_y(hits[k]);
-                        u64 upper; bool c;
-                        if (is_end) { if (ky == cuty) { upper = k + 1; c = true; } else if (ky > cuty) { upper = k; c = true; } else c = false; }
-                        else { if (ky >= cuty) { upper = k; c = true; } else c = false; }
-                        if (c) {
-                            if (lower != upper) { emit = true; piece.first = lower; piece.second = upper; xy_strs[j] = upper; }
-                            break;
-                        }
+                    u64 lo = lower, hi_ = kend;          // (bisection for the first hit with y >= cuty, as above)
+                    while (lo < hi_) { u64 mid = (lo + hi_) >> 1; if (cord_y(hits[mid]) >= cuty) hi_ = mid; else lo = mid + 1; }
+                    if (lo < kend) {
+                        u64 upper = (is_end && cord_y(hits[lo]) == cuty) ? lo + 1 : lo;
+                        if (lower != upper) { emit = true; piece.first = lower; piece.second = upper; xy_strs[j] = upper; }
                     }
                 }
             }
@@ -2207,20 +2312,35 @@ __device__ JOB_INLINE u32 prefilter_chains2_wave(u64 *hits, u32 nhits, Vec<UP> &
         WSYNC();
     }
     }
-    if (ntmp > tcap) { if (lane == 0) *tmp.ovf = 1; ntmp = tcap; }
-    for (u32 i = lane; i < ntmp; i += 64) sp[i] = tp[i];
-    WSYNC();
-    if (lane == 0) ref_sort(sp, (long)ntmp, [](const UP &a, const UP &b) { return a.second < b.second; }, ls.st);
-    WSYNC();
+    if (ntmp > tcap) { if (lane == 0) *tmp.ovf = 1; WSYNC(); return 0; }   // (nothing of hits / sep is rewritten: the caller gives up or retries with larger arrays)
+    if (ntmp <= 64) {
+        // the pieces end at distinct positions: any correct sort gives the reference's order -- ranks by counting
+        UP q; q.first = 0; q.second = ~0ULL;
+        if ((u32)lane < ntmp) q = tp[lane];
+        u32 rank = 0;
+        for (u32 t = 0; t < ntmp; t++) { u64 o = __shfl(q.second, (int)t); rank += o < q.second ? 1u : 0u; }
+        if ((u32)lane < ntmp) sp[rank] = q;
+        WSYNC();
+    } else {
+        for (u32 i = lane; i < ntmp; i += 64) sp[i] = tp[i];
+        WSYNC();
+        if (lane == 0) ref_sort(sp, (long)ntmp, [](const UP &a, const UP &b) { return a.second < b.second; }, ls.st);
+        WSYNC();
+    }
     for (u32 i = lane; i < ntmp; i += 64) hits[sp[i].second - 1] |= F_END;
     WSYNC();
     return ntmp;
 }
 // wave-parallel twin of best_chains2 with getApxChainScore2 (cluster_util.cpp:469-526,586-631): serial over blocks, lanes
 // over the <= 20 predecessors; among equal totals the LAST predecessor wins (ascending scan with >=).
-__device__ void best_chains2_wave(const u64 *hits, const UP *sep, const i32 *sep_score, u32 nb, Rec r) {
+__device__ void best_chains2_wave(const u64 *hits, const UP *sep, const i32 *sep_score, u32 nb, Rec r, unsigned long long *dbg = nullptr) {
     int lane = lane_id();
+    unsigned long long ta = 0, tb = 0, tc = 0, t0_ = 0, t1_ = 0, t2_ = 0;
+    (void)ta; (void)tb; (void)tc; (void)t0_; (void)t1_; (void)t2_;
     for (u32 i = 0; i < nb; i++) {
+#ifdef LNR_PROF
+        t0_ = clock64();
+#endif
         int j_str = (int)i - 20 < 0 ? 0 : (int)i - 20;
         int j = j_str + lane;
         i64 best = -1;
@@ -2229,7 +2349,13 @@ __device__ void best_chains2_wave(const u64 *hits, const UP *sep, const i32 *sep
             int sc = block_score2(hits[sep[j].first], hits[sep[i].second - 1]);
             if (sc > 0) best = ((i64)(sc + r.score[j] + si) << 32) | (i64)(u32)j;   // larger j wins ties
         }
+#ifdef LNR_PROF
+        t1_ = clock64(); ta += t1_ - t0_;
+#endif
         best = wave_max_i64(best);
+#ifdef LNR_PROF
+        t2_ = clock64(); tb += t2_ - t1_;
+#endif
         if (lane == 0) {
             int tot = best >= 0 ? (int)(best >> 32) : -1;
             i32 li = (i32)(sep[i].second - sep[i].first);
@@ -2242,7 +2368,13 @@ __device__ void best_chains2_wave(const u64 *hits, const UP *sep, const i32 *sep
             }
         }
         WSYNC();
+#ifdef LNR_PROF
+        tc += clock64() - t2_;
+#endif
     }
+#ifdef LNR_PROF
+    if (dbg) { atomicAdd(&dbg[26], ta); atomicAdd(&dbg[29], tb); atomicAdd(&dbg[30 - 3], tc); }
+#endif
 }
 
 // Workgroup form of the tiled DP for the multi-wave kernels: the before-tile chunks are dealt out over the NW waves,
@@ -2580,32 +2712,94 @@ __device__ void job_group_run(const JobArgs &A, u32 grp, u32 *dyn_lds) {
             c.g = A.g; c.bins = nullptr; c.nbins = 0; c.pair_evals = nullptr; c.prof = prof;
             // hit blocks: gather (leader) -> prefilter (lanes over blocks) -> scores -> block DP (lanes over predecessors)
             // -> traceback + rewrite (leader)
-            if (lane == 0) { job_blocks_gather(S, c); s_nH = S.sep.n; s_nhits = S.hits.n; }
+            if (lane == 0) s_nhits = S.hits.n;
             WSYNC();
-            u32 nb = s_nH;
             S.hits.n = s_nhits;   // the leader filled hits during the traceback: every lane now agrees on the count
-            nb = prefilter_chains2_wave(S.hits.p, S.hits.n, S.sep, nb, S.cuts, S.xy_strs, S.tmp, s_ls);
+            // The stages behind the anchor traceback (a11-a16) are short dependent steps on a hundred hits and a few dozen blocks; in the job's
+            // global scratch every step pays a memory round trip.  Everything the anchor DP kept in the LDS arena is dead now (job_carve puts
+            // hits / hscore in global memory), so the hits and the block arrays move INTO the arena when they fit: the hits, the rewritten hits,
+            // the keep flags (20 B per hit) and 100 B per block for as many blocks as the rest holds.  A read with more blocks than that (seen
+            // only when the counts are known) falls back to the arrays carved before -- same code, other pointers.
+            u64 *hits2 = a;   // output of the block filter: the anchors are dead by now and hits never outnumber them (job_blocks_finish)
+            const JobScratch S0 = S;
+            u32 nb = 0;
+            bool in_lds = false;
+            if (PHASE != 2 && A.arena_lds) {
+                Arena pl; pl.init((void *)dyn_lds, A.arena_lds);
+                const u32 nh = S.hits.n;
+                u64 *lh = pl.get<u64>((u64)nh + 2), *lH = pl.get<u64>((u64)nh + 2);
+                i32 *lcnt = pl.get<i32>((u64)nh + 2);
+                u64 rest = pl.ovf ? 0 : A.arena_lds - pl.off;
+                u32 C = rest > 14 * 16 + 2 * 100 ? (u32)((rest - 14 * 16) / 100) - 2 : 0;
+                if (C >= 16) {
+                    if (C > nh) C = nh;       // (never more blocks or pieces than hits)
+                    if (lane == 0) s_flag[1] = 0;
+                    for (u32 i = lane; i < nh; i += 64) lh[i] = S.hits.p[i];
+                    S.hits.p = lh;
+                    S.sep.init(pl.get<UP>((u64)C + 2), C, &s_flag[1]);
+                    S.tmp.init(pl.get<UP>((u64)C + 2), C, &s_flag[1]);
+                    S.cuts = pl.get<u64>(2 * (u64)C + 4); S.xy_strs = pl.get<u64>((u64)C + 2);
+                    S.sep_score = pl.get<i32>((u64)C + 2);
+                    S.xs = pl.get<u32>((u64)C + 2); S.ys = pl.get<u32>((u64)C + 2);
+                    S.rec.score = pl.get<i32>((u64)C + 2); S.rec.score2 = pl.get<i32>((u64)C + 2); S.rec.len = pl.get<i32>((u64)C + 2);
+                    S.rec.p2 = pl.get<i32>((u64)C + 2); S.rec.root = pl.get<i32>((u64)C + 2); S.rec.leaf = pl.get<i32>((u64)C + 2);
+                    S.chain = pl.get<i32>((u64)C + 2); S.chain_sc = pl.get<i32>((u64)C + 2);
+                    S.cnt = lcnt;
+                    WSYNC();
+                    if (!pl.ovf) {
+                        nb = gather_blocks_wave(S.hits.p, nh, S.sep.p, S.sep.cap, S.sep.ovf);
+                        bool fits = !s_flag[1];
+                        if (fits) {
+                            S.sep.n = nb;
+                            nb = prefilter_chains2_wave(S.hits.p, nh, S.sep, nb, S.cuts, S.xy_strs, S.tmp, s_ls);
+                            fits = !s_flag[1];
+                        }
+                        if (fits) { in_lds = true; hits2 = lH; }
+                    }
+                    if (!in_lds) { WSYNC(); S = S0; }
+                }
+            }
+            if (!in_lds) {
+                S.tmp.n = 0;
+                nb = gather_blocks_wave(S.hits.p, S.hits.n, S.sep.p, S.sep.cap, S.sep.ovf);
+                S.sep.n = nb;
+                nb = prefilter_chains2_wave(S.hits.p, S.hits.n, S.sep, nb, S.cuts, S.xy_strs, S.tmp, s_ls);
+            }
             S.sep.n = nb;
             LNR_TICK(prof, 6, tk_);
+#ifdef LNR_PROF
+            (void)in_lds;
+            unsigned long long tsub_ = clock64();
+#endif
             if (NW == 1 && A.stop_after == 7) break;
             job_blocks_scores(S, (u32)lane, 64);
             WSYNC();
             BlockScratch bsx = job_block_scratch(S, s_ls);
             if (nb >= 2) {
-                if (lane == 0) chain_blocks_prepare(S.hits.p, S.sep.p, S.sep_score, nb, 1, bsx);
-                WSYNC();
+                chain_blocks_prepare_wave(S.hits.p, S.sep.p, S.sep_score, nb, bsx);
                 if (NW == 1 && A.stop_after == 10) break;
-                best_chains2_wave(S.hits.p, bsx.sep_tmp, bsx.score_tmp, nb, bsx.rec);
+#ifdef LNR_PROF
+                unsigned long long tdp_ = clock64();
+#endif
+                best_chains2_wave(S.hits.p, bsx.sep_tmp, bsx.score_tmp, nb, bsx.rec, prof);
+#ifdef LNR_PROF
+                if (prof) atomicAdd(&prof[28], clock64() - tdp_);
+#endif
                 if (NW == 1 && A.stop_after == 11) break;
             }
-            if (lane == 0) {
+#ifdef LNR_PROF
+            tsub_ = clock64();
+#endif
+            {
                 BlockSink bs = job_block_sink(S);
-                if (nb >= 2) chain_blocks_trace(bs, nb, bsx);
-                u64 *H = nullptr; u32 nH = 0;
-                if (A.stop_after != 12 && job_blocks_finish(a, S, bs, nullptr, H, nH)) s_ovf = 1;
-                s_H = H; s_nH = nH;
+                if (lane == 0) { if (nb >= 2) chain_blocks_trace(bs, nb, bsx); s_flag[2] = (int)bs.nchains; }
+                WSYNC();
+#ifdef LNR_PROF
+#endif
+                if (NW == 1 && A.stop_after == 12) break;
+                u32 nh2 = filter_blocks_hits_wave(bs, (u32)s_flag[2], S.hits.p, hits2);
+                if (lane == 0) { if (nh2 == 0xffffffffu) { s_H = S.hits.p; s_nH = S.hits.n; } else { s_H = hits2; s_nH = nh2; } }
             }
-            if (NW == 1 && A.stop_after == 12) break;
             WSYNC();
             LNR_TICK(prof, 7, tk_);
             if (NW == 1 && A.stop_after == 8) break;

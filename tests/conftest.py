@@ -32,3 +32,13 @@ def case_inputs():
             _case_cache[name] = (cases.CASES[name][0] if name in cases.CASES else cases.CASES_I2[name][0] if name in cases.CASES_I2 else cases.CASES_G50[name][0])()
         return _case_cache[name]
     return get
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_sees_the_gpu_first(request):
+    """GPU runs: torch initialises its HIP context before the first test creates a library context (a test that hands device blobs to torch
+    must not depend on an earlier test having done so)."""
+    if any(item.get_closest_marker("gpu") for item in request.session.items):
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()

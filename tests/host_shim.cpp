@@ -470,6 +470,41 @@ void hs_std_sort_hi32(u64 *a, u64 n, int desc) {
     if (desc) std::sort(a, a + n, [](const u64 &x, const u64 &y) { return (x >> 32) > (y >> 32); });
     else std::sort(a, a + n, [](const u64 &x, const u64 &y) { return (x >> 32) < (y >> 32); });
 }
+// fuzz hook: the 32-bit block_score2 against the literal 64-bit getApxChainScore2 (cluster_util.cpp:586-631); returns mismatches
+static int block_score2_literal(u64 c11, u64 c22) {
+    i64 dy = (i64)(cord_y(c11) - cord_y(c22));
+    i64 dx = (i64)(cord_x(c11) - cord_x(c22));
+    if (dx < 0 || dy < 0 || cord_strand(c11 ^ c22) || dx > 20000 || dy > 20000) return INT_MIN;
+    i64 da = labs64(dx - dy);
+    i64 derr = (100 * da) / max64(max64(labs64(dy), 100), labs64(dx));
+    if (da > 100 || derr > 50) {
+        if (dx < dy) return (int)(100 - 30 - dy / 1000 - dx / 100);
+        return (int)(100 - 30 - dy / 100 - dx / 1000);
+    }
+    return (int)(100 - dy / 95);
+}
+u64 hs_block_score2_fuzz(u64 seed, u64 n) {
+    u64 bad = 0, st = seed * 0x9E3779B97F4A7C15ULL + 1;
+    auto rnd = [&st]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    for (u64 it = 0; it < n; it++) {
+        u64 a = rnd(), b = rnd(), c = rnd();
+        u64 x2 = a & 0x3fffffff, y2 = (a >> 32) & 0xfffff, id = (a >> 52) & 3, x1, y1;
+        switch (c & 7) {
+        case 0: x1 = b & 0x3fffffff; y1 = (b >> 32) & 0xfffff; break;
+        case 1: x1 = x2 + b % 20002; y1 = y2 + (b >> 32) % 20002; break;                                  // the whole accepted range
+        case 2: { u64 d = b % 20001; x1 = x2 + d; y1 = y2 + d + (b >> 40) % 241 - 120; break; }            // around da = 100
+        case 3: x1 = x2 + b % 300; y1 = y2 + (b >> 32) % 300; break;
+        case 4: { u64 d = b % 20001; x1 = x2 + d; y1 = y2 + d / 2 + (b >> 40) % 7 - 3; break; }            // around derr = 50
+        case 5: { u64 d = b % 20001; y1 = y2 + d; x1 = x2 + d / 2 + (b >> 40) % 7 - 3; break; }
+        case 6: x1 = x2 + b % 20002 - 1; y1 = y2 + (b >> 32) % 3 - 1; break;
+        default: x1 = x2 + (b >> 32) % 3 - 1; y1 = y2 + b % 20002 - 1; break;
+        }
+        x1 &= 0x3fffffff; y1 &= 0xfffff;
+        u64 c11 = mk_cord((id << 30) + x1, y1, (c >> 8) & 1), c22 = mk_cord((id << 30) + x2, y2, (c >> 9) & 1 & ((c >> 10) & 1));
+        if (block_score2(c11, c22) != block_score2_literal(c11, c22)) bad++;
+    }
+    return bad;
+}
 // fuzz hook: branch-free chain scores (what the lane-parallel DP evaluates) against the literal ones; returns mismatches
 u64 hs_chain_score_fuzz(u64 seed, u64 n) {
     u64 bad = 0, st = seed * 0x9E3779B97F4A7C15ULL + 1;

@@ -47,6 +47,17 @@ def test_branch_free_chain_scores_equal_the_literal_ones():
         assert lib.hs_chain_score_fuzz(seed, 5_000_000) == 0
 
 
+def test_block_score2_in_32_bits_equals_the_literal_one():
+    """The block DP scores with a 32-bit getApxChainScore2 (float quotient estimate + exact correction); it must agree with the
+    literal 64-bit restatement on every pair of cords."""
+    shimlib.build()
+    lib = C.CDLL(shimlib.SO)
+    lib.hs_block_score2_fuzz.restype = C.c_uint64
+    lib.hs_block_score2_fuzz.argtypes = [C.c_uint64, C.c_uint64]
+    for seed in range(4):
+        assert lib.hs_block_score2_fuzz(seed, 5_000_000) == 0
+
+
 @pytest.mark.parametrize("name,T", PARAMS)
 def test_stage_logic_matches_golden(case_inputs, name, T):
     refs, reads, off = case_inputs(name)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: builds the library with -DLNR_PROF (in-kernel cycle stamps, see lnr_hd.h LNR_TICK) into
-gpurun_out/liblinear_amd_prof.so and prints the share of k_job's lane-0 time spent per phase.  Not a timing build."""
+"""Diagnostic: builds the library with -DLNR_PROF (in-kernel cycle stamps, see lnr_hd.h LNR_TICK) as the variant
+tools/_variants/jobprof.so (linear_amd.build, the same helper tools/build_variant.sh uses) and prints the share of k_job's lane-0
+time spent per phase.  Not a timing build."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,8 +9,10 @@ import numpy as np, torch
 from linear_amd import build as lb, api, synth
 from linear_amd.synth_torch import sample_reads_cuda
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-so = os.path.join(ROOT, "gpurun_out", "liblinear_amd_prof.so")
-subprocess.check_call([lb.hipcc_path()] + lb.FLAGS + ["-DLNR_PROF", "-o", so, os.path.join(lb.CSRC, "lnr_api.hip")])
+os.makedirs(os.path.join(ROOT, "tools", "_variants"), exist_ok=True)
+so = os.path.join(ROOT, "tools", "_variants", "jobprof.so")
+if not os.path.exists(so) or os.environ.get("LNR_PROF_REBUILD"):
+    lb.build(force=False, defines=["-DLNR_PROF"], out=so)
 api.SO = so
 f = api.Filter(device=0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
@@ -36,6 +39,7 @@ for cls, cname in enumerate(["k_job round 0", "k_job round 1 (re-map)", "k_job_h
     print(f"== {cname}: {o[10]} jobs, anchors in {o[13] / jobs:.0f}/job, anchors in DP {o[11] / jobs:.0f}/job, pairs {o[12] / jobs:.0f}/job (window {o[12] / max(o[11], 1):.1f}); lane-0 cycles/job {tot / jobs:.0f}")
     for i, nm in enumerate(names):
         print(f"   {nm:42s} {o[i] / 1e6:10.1f} Mcyc {100.0 * o[i] / max(tot, 1):5.1f} %  per job {o[i] / jobs:9.0f}  max {o[16 + i] / 1e6:8.2f} Mcyc")
+    print(f"   block DP {o[28] / jobs:.0f} cyc/job: scores {o[26] / jobs:.0f}, reduction {o[29] / jobs:.0f}, record + sync {o[27] / jobs:.0f}")
     mp = out[128 + 16 * cls: 128 + 16 * cls + 16]
     print(f"   biggest job of the class: {mp[12]} anchors in, {mp[10]} in the DP, {mp[11]} pairs; Mcyc per phase: " + " ".join(f"{mp[i] / 1e6:.2f}" for i in range(10)) + f"  (sum {sum(mp[:10]) / 1e6:.1f}); list filter {mp[14] / 1e6:.2f}, introsort {mp[15] / 1e6:.2f} (phase 3 column = carve + x/y fill)")
 
