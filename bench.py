@@ -86,16 +86,17 @@ def spawn_ranks(args) -> int:
 
 
 def recorded_traffic(workload_key: dict, launches_per_step: float):
-    """HBM-side bytes per seed-lookup launch from the committed rocprofv3 PMC passes (profiles/r02/pmc_seed.json, made by
-    tools/pmc_summary.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  Counters cannot be read
-    from inside the process, so the figure is only reported when the workload is the one the passes were taken on."""
-    p = os.path.join(ROOT, "profiles", "r02", "pmc_seed.json")
-    if not os.path.exists(p):
+    """HBM-side bytes per seed-lookup launch from the committed rocprofv3 PMC passes (profiles/rNN/pmc_seed.json of the latest round that has
+    one, made by tools/pmc_seed_r02.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  Counters cannot be
+    read from inside the process, so the figure is only reported when the workload is the one the passes were taken on."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_seed.json")))
+    if not found:
         return None
-    rec = json.load(open(p))
+    rec = json.load(open(found[-1]))
     if rec.get("workload") != workload_key or abs(rec.get("launches_per_step", 0) - launches_per_step) > 1e-9:
         return None
-    return {"bytes_per_launch": rec["traffic_bytes_per_launch"], "source": rec["source"]}
+    return {"bytes_per_launch": rec["traffic_bytes_per_launch"], "source": rec["source"] + " [" + os.path.relpath(found[-1], ROOT) + "]"}
 
 
 def padded_layout(seq_len):
@@ -124,6 +125,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cli", action="store_true", help="skip the front-end's end-to-end measurement (FASTA files in -> SAM out)")
+    ap.add_argument("--no-gap50", action="store_true", help="skip the -g 50 leg (counter passes: only the headline path's kernels run)")
     ap.add_argument("--seed-only", action="store_true", help="time only stage a7 (seed lookup) -- used for the roofline profile")
     ap.add_argument("--gap", type=int, default=0, help="the reference's -g: 0 = apxMap only (the headline configuration); > 0 = cords go through the gap re-mapper (SURVEY 8 f1)")
     ap.add_argument("--dup", type=int, default=0, help="the reference's -dup (with --gap)")
@@ -404,7 +406,7 @@ def main():
 
     # ---- the reference's DEFAULT mode in the same line: -g 1 (gaps of 50 and more re-mapped, mapper.cpp:207-231), same batches, same context
     gap50 = None
-    if args.gap == 0 and not args.seed_only and not double and world == 1 and rank == 0 and args.workload in ("grch38", "chr22"):
+    if args.gap == 0 and not args.no_gap50 and not args.seed_only and not double and world == 1 and rank == 0 and args.workload in ("grch38", "chr22"):
         flt.set_gap(1, 0)
         step(0)                                   # (also takes the stream through its first extension: the timed steps run in the steady state)
         sync()

@@ -51,7 +51,7 @@ def main():
         "rdreq_x_128B_per_launch": rdreq_b,
         "traffic_bytes_per_launch": 2.0 * fetch_b + write_b,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_EA0_RDREQ_sum (three separate passes, KiB x 1024) of `python3 bench.py --steps %d --warmup %d "
-                  "--no-cpu-baseline`, mean over the timed launches of lnr::k_seed_fused (two per step); FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64 B, "
+                  "--no-cpu-baseline --no-cli --no-gap50`, mean over the timed launches of lnr::k_seed_fused (two per step); FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64 B, "
                   "MI355X_MICROARCH.md HBM section; the request counter x 128 B of the third pass gives %.3f of that), WRITE_SIZE exact" % (a.steps, a.warmup, rdreq_b / (2.0 * fetch_b)),
         "launches_seen": {"fetch": len(fe), "write": len(wr), "rdreq": len(rq)},
         "per_launch_KiB_fetch": f_t, "per_launch_KiB_write": w_t,
