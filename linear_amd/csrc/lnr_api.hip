@@ -1217,6 +1217,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
                         (double)(w[14] & ((1ULL << 56) - 1)) / 1e5, hp[90 + L], (w[14] >> 56) & 15, (w[14] >> 60) ? "by columns" : "single wave");
                 for (int k = 0; k < 10; k++) fprintf(stderr, "[gap prof]    %-26s %10.1f ms  %5.1f %%   slowest read: %8.1f ms\n", nm[k], q[k] / 1e5, q[11] ? 100.0 * q[k] / q[11] : 0.0, w[k] / 1e5);
             }
+            fprintf(stderr, "[gap prof] map along chain, all launches: streams + join + anchor sort %.1f ms, chain DP + traceback + tiles %.1f ms\n", hp[63] / 1e5, hp[79] / 1e5);
             fprintf(stderr, "[gap prof] first launch: at most %llu workers (waves) alive at once\n", hp[95]);
             {   // how well the weight predicts: weights of the reads the team launch did, and of the slowest / all reads of the first launch
                 std::vector<u32> wt(n); std::vector<unsigned long long> pr0(n);

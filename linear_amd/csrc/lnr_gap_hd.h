@@ -138,8 +138,10 @@ LNR_HD inline bool gap_late(GapCtx &X) {
 #if defined(LNR_GAP_DEVPROF) && defined(__HIP_DEVICE_COMPILE__)
 struct GpScope { GapCtx &X; int i; unsigned long long t0; __device__ GpScope(GapCtx &x, int k) : X(x), i(k), t0(wall_clock64()) {} __device__ ~GpScope() { X.prof[i] += wall_clock64() - t0; } };
 #define GP(X, k) GpScope _gp_scope(X, k)
+#define GP2(X, k) GpScope _gp_scope2(X, k)
 #else
 #define GP(X, k) do {} while (0)
+#define GP2(X, k) do {} while (0)
 #endif
 
 // the comparators of the gap path's sorts as ONE type (the team form of the sort hands it to the helper waves through LDS)
@@ -160,8 +162,41 @@ struct GapCmp {
 #if defined(__HIPCC__)
 template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp comp, GapCtx &X);
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// Short arrays in the wave-per-read form: every lane ranks the (up to two) elements it holds by counting -- the elements before it in the
+// order plus the equivalent ones with a smaller index, i.e. the STABLE order.  That is what std::sort produces up to 16 elements (a plain
+// insertion sort there) for any comparator, and for any length when equivalent elements are identical words (no tie to break: every sort
+// gives the same array).  The serial emulation these arrays went through before pays a memory round trip per comparison.
+template <class Comp> __device__ inline void gap_rank_sort(u64 *a, u32 n, Comp comp) {       // n <= 128
+    const u32 lane = threadIdx.x & 63;
+    u64 e0 = lane < n ? a[lane] : 0, e1 = lane + 64 < n ? a[lane + 64] : 0;
+    u32 r0 = 0, r1 = 0;
+    const u32 n0 = n < 64 ? n : 64;
+    for (u32 t = 0; t < n0; t++) {
+        u64 v = __shfl(e0, (int)t);
+        r0 += (comp(v, e0) || (!comp(e0, v) && t < lane)) ? 1u : 0u;
+        r1 += (comp(v, e1) || !comp(e1, v)) ? 1u : 0u;                 // (t < lane + 64 always)
+    }
+    for (u32 t = 64; t < n; t++) {
+        u64 v = __shfl(e1, (int)(t - 64));
+        r0 += comp(v, e0) ? 1u : 0u;                                   // (t > lane always)
+        r1 += (comp(v, e1) || (!comp(e1, v) && t - 64 < lane)) ? 1u : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane < n) a[r0] = e0;
+    if (lane + 64 < n) a[r1] = e1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#endif
 template <class T, class Comp> LNR_HD inline void gap_sort(T *a, long n, Comp comp, GapCtx &X) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (X.coop && n > 96) { gap_sort_wave(a, (u32)n, comp, X); return; }
+#endif
+    ref_sort(a, n, comp, X.ls->st);
+}
+inline LNR_HD void gap_sort(u64 *a, long n, GapCmp comp, GapCtx &X) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (X.coop && n >= 2 && (n <= 16 || (comp.kind == 4 && n <= 128))) { gap_rank_sort(a, (u32)n, comp); return; }
     if (X.coop && n > 96) { gap_sort_wave(a, (u32)n, comp, X); return; }
 #endif
     ref_sort(a, n, comp, X.ls->st);
@@ -571,7 +606,8 @@ struct GStage { u32 x, y, z, w; };
 struct GapTeam { const u64 *anchors; const i32 *score; u64 ai, dx_depth; int i, j_str, fn, cmd; u64 part[16]; Rec rec; u32 n, depth; int dup; u32 ncols; u32 *xs, *ys;
                  u64 *s_a; u32 *s_L, *s_R; u64 *s_tasks; const u64 *s_queue; u32 s_nq, s_next; GapCmp s_cmp;     // cmd 3: the ranges of a big sort dealt over the waves
                  const u64 *j_hs; u64 *j_out; u32 j_p1, j_p2, j_k; int j_kind, j_pass; u64 j_rvcp; i64 j_lower, j_upper; GAncBand j_band;   // cmd 4: the pairs of a big k-mer block
-                 GStage stage[16][128]; };   // cmd: 0 exit, 1 one long row, 2 a whole DP by columns; xs / ys: x and y | strand << 24 of the anchors; stage: per wave, the pairs that passed the cheap tests
+                 GStage stage[16][128];
+                 unsigned long long *tw; u32 tw_mask; };   // cmd 2: open-addressed set of the anchor words (the check for identical anchors)   // cmd: 0 exit, 1 one long row, 2 a whole DP by columns; xs / ys: x and y | strand << 24 of the anchors; stage: per wave, the pairs that passed the cheap tests
 #ifndef K_GAP_COL_MEAN
 #define K_GAP_COL_MEAN 12     // mean anchors per column from which the column form pays (one workgroup barrier per column)
 #endif
@@ -626,16 +662,38 @@ __device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 dept
     GStage *stage = tm->stage[w];
     // x and y | strand << 24 of every anchor, once: the scan below then costs a dozen 32-bit instructions per predecessor, and only the pairs
     // inside the box of the score function (a few per cent) are staged in LDS and scored, 64 at a time
+    // Identical anchor words (they would share a column) are looked for ONCE, with an open-addressed set of the words: the check per row
+    // against the rows before it in its column is quadratic in the column, and a satellite repeat has columns of thousands of anchors (one
+    // reference k-mer against every copy in the read) -- that check, not the scoring, was most of such a DP's time.
+    unsigned long long *TW = tm->tw;
+    const u32 twm = tm->tw_mask;
+    const unsigned long long TW_EMPTY = ~0ULL;                   // (no anchor word has all bits set)
+    if (TW) {
+        for (u32 i = (u32)w * 64 + (u32)lane; i <= twm; i += (u32)nw * 64) TW[i] = TW_EMPTY;
+        __syncthreads();
+    }
     u32 myc = 0;
+    bool twin_any = false;
     for (u32 i = (u32)w * 64 + (u32)lane; i < n; i += (u32)nw * 64) {
         u64 a = anchors[i];
         u32 x = (u32)ganc_x(a);
         XS[i] = x; YS[i] = (u32)ganc_y(a) | ((u32)ganc_strand(a) << 24);
         myc += (i == 0 || (u32)ganc_x(anchors[i - 1]) != x) ? 1u : 0u;
+        if (TW) {
+            u32 h = (u32)((a * 0x9E3779B97F4A7C15ULL) >> 32) & twm;
+            for (;;) {
+                unsigned long long old = atomicCAS(&TW[h], TW_EMPTY, (unsigned long long)a);
+                if (old == TW_EMPTY) break;
+                if (old == (unsigned long long)a) { twin_any = true; break; }
+                h = (h + 1) & twm;
+            }
+        }
     }
     myc = wave_sum(myc);
     if (lane == 0 && myc) atomicAdd(&tm->ncols, myc);
+    if (__any(twin_any) && lane == 0) tm->dup = 1;
     __syncthreads();
+    if (tm->dup == 1) return;                                    // (uniform: the caller redoes the DP in the single-wave form)
     // columns of a few anchors each would be one workgroup barrier per few rows: the single-wave form (the last 64 records in registers) is the
     // better one there -- every wave sees the same count and leaves; wave 0 then runs that form (dup = 2: not a duplicate, just "not by columns")
     if ((u64)tm->ncols * K_GAP_COL_MEAN > (u64)n) { if (w == 0 && lane == 0) tm->dup = 2; __syncthreads(); return; }
@@ -655,9 +713,11 @@ __device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 dept
             const u64 ai = anchors[i];
             const u32 ysi = YS[i];
             const int j_str = (int)i - (int)depth < 0 ? 0 : (int)i - (int)depth;
-            bool twin = false;
-            for (u32 jb = c0; jb < i; jb += 64) { u32 j = jb + (u32)lane; twin = twin || (j < i && anchors[j] == ai); }
-            if (__any(twin)) { if (lane == 0) tm->dup = 1; }
+            if (!TW) {                                           // (no room for the set: the check per row)
+                bool twin = false;
+                for (u32 jb = c0; jb < i; jb += 64) { u32 j = jb + (u32)lane; twin = twin || (j < i && anchors[j] == ai); }
+                if (__any(twin)) { if (lane == 0) tm->dup = 1; }
+            }
             u64 key = 0;
             {   // the last `depth` predecessors whatever their distance (those of this column cannot score): the anchor form of the score
                 int j = (int)c0 - 1 - lane;
@@ -935,9 +995,14 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
     bool by_columns = false;
     u32 *xs_ = nullptr;
     if (X.coop && X.team > 1 && fn_id && n >= K_GAP_COL_MIN) { xs_ = (u32 *)X.ar->get((u64)n * 8); if (X.ar->ovf) return; }
+    unsigned long long *tw_ = nullptr; u32 tw_cap = 64;
+    if (xs_) {
+        while (tw_cap < 2 * n) tw_cap <<= 1;
+        if (X.ar->off + (u64)tw_cap * 8 + 64 <= X.ar->cap) tw_ = (unsigned long long *)X.ar->get((u64)tw_cap * 8);   // (only when it fits)
+    }
     if (xs_) {
         GapTeam *tm = X.tm;
-        if ((threadIdx.x & 63) == 0) { tm->anchors = anchors; tm->rec = r; tm->n = n; tm->depth = depth; tm->dx_depth = dx_depth; tm->fn = fn_id; tm->dup = 0; tm->ncols = 0; tm->xs = xs_; tm->ys = xs_ + n; tm->cmd = 2; }
+        if ((threadIdx.x & 63) == 0) { tm->tw = tw_; tm->tw_mask = tw_cap - 1; tm->anchors = anchors; tm->rec = r; tm->n = n; tm->depth = depth; tm->dx_depth = dx_depth; tm->fn = fn_id; tm->dup = 0; tm->ncols = 0; tm->xs = xs_; tm->ys = xs_ + n; tm->cmd = 2; }
         __syncthreads();                                         // (A)
         gap_dp_columns(anchors, n, r, depth, dx_depth, GapDpFn{fn_id}, fn_id, 0, X.team, tm);
         by_columns = tm->dup == 0;                               // (a column held the same anchor twice: the single-wave form below redoes the DP)
@@ -1450,10 +1515,14 @@ LNR_HD inline int gap_map_along_chain(const GSeq &ref, const GSeq &seq2, const G
     GVec<u64> hs, anc; hs.init(X.ar, 1024); anc.init(X.ar, 1024);
     u64 a = ch[(u32)i_str], b = ch[(u32)i_end - 1];
     i64 as = (i64)(cord_x(a) - cord_y(a)), ae = (i64)(cord_x(b) - cord_y(b));
-    c_stream(ref, hs, cord_x(a), cord_x(b), step1, shape_len, 0, X.coop);
-    c_stream(seq2, hs, cord_y(a), cord_y(b), step2, shape_len, 1, X.coop);
-    c_create_anchors2(hs, anc, (as < ae ? as : ae) - 30, (as > ae ? as : ae) + 30, X.ls->st, &X);
-    gap_sort(anc.p, (long)anc.n, GapCmp{2, 0}, X);
+    {
+        GP(X, 10);
+        c_stream(ref, hs, cord_x(a), cord_x(b), step1, shape_len, 0, X.coop);
+        c_stream(seq2, hs, cord_y(a), cord_y(b), step2, shape_len, 1, X.coop);
+        c_create_anchors2(hs, anc, (as < ae ? as : ae) - 30, (as > ae ? as : ae) + 30, X.ls->st, &X);
+        gap_sort(anc.p, (long)anc.n, GapCmp{2, 0}, X);
+    }
+    GP2(X, 11);
     stick_main_chain(anc, ch, X.gp.thd_smcn_danchor);
     GVec<u64> first; first.init(X.ar, anc.n + 16);
     // bestn 1: only the first chain is wanted; it is collected as anchors and turned into tiles below (chn_ext_clip_metric1: min length 1, abort 0)

@@ -204,6 +204,7 @@ __device__ bool gap_do_read(const GapArgs &A, u32 r, char *mine, u64 arena_bytes
             unsigned long long *pp = A.prof + 16 * (lvl);
             t_read = wall_clock64() - t_read;
             for (int k = 0; k < 10; k++) atomicAdd(pp + k, X.prof[k]);
+            atomicAdd(A.prof + 63, X.prof[10]); atomicAdd(A.prof + 79, X.prof[11]);      // map along chain, split: streams + join + anchor sort | chain DP + traceback (all launches)
             atomicAdd(pp + 11, t_read); atomicAdd(pp + 12, 1ULL);
             A.prof[96 + r] = t_read | ((unsigned long long)(lvl) << 56);      // per-read time of the launch that did the read
             if (!lvl) { A.prof[96 + A.n + r] = wall_clock64() - t_read; A.prof[96 + 2 * (unsigned long long)A.n + r] = wall_clock64(); }   // first launch: start and end tick of the read
