@@ -547,17 +547,29 @@ LNR_HD inline int gap_block_score3(u64 c11, u64 c12, u64 c21, u64 c22, u64 L, in
 // gap_anchor_score1_pos / gap_anchor_score2_pos / gap_clip_score compute behind their rejections (da = |dx - dy| because the strands are equal).
 // fn 1: dx >= 0, 0 <= dy < 245, da < 64;  fn 2: 0 <= dy < 128, da < 64, dx < 4096;  fn 5: 1 <= dy < 31, da < 59.  tests/test_gap_shim_cpu.py
 // compares them with the anchor forms over those boxes.
+// floor(100 da / m) for da < 64, 50 <= m < 4096: a float estimate with an exact correction instead of the integer division sequence
+LNR_HD inline u32 gap_derr_q(u32 da, u32 m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float inv = __builtin_amdgcn_rcpf((float)m);
+#else
+    float inv = 1.0f / (float)m;
+#endif
+    u32 nn = 100u * da;
+    u32 q = (u32)((float)nn * inv);
+    i32 r = (i32)(nn - q * m);                      // the true remainder lies in [-m, 2m)
+    return r < 0 ? q - 1 : ((u32)r >= m ? q + 1 : q);
+}
 LNR_HD inline int gap_score_delta(int fn, u32 dx, u32 dy) {
     u32 da = dx > dy ? dx - dy : dy - dx;
     if (fn == 1) {
-        u32 m = dy > 50 ? dy : 50, derr = (100u * da) / m;
+        u32 m = dy > 50 ? dy : 50, derr = gap_derr_q(da, m);
         i32 s_derr = derr < 10 ? 0 : (derr < 15 ? (i32)(10 + 2 * derr) : (i32)(derr * derr / 10 + 40));
         i32 s_dy = dy < 100 ? (i32)(dy / 4) : (dy < 200 ? (i32)(dy / 3) - 9 : (i32)dy - 145);
         return 100 - s_dy - s_derr;
     }
     if (fn == 2) {
         u32 m = dx > dy ? dx : dy; if (m < 50) m = 50;
-        u32 derr = (100u * da) / m;
+        u32 derr = gap_derr_q(da, m);
         i32 s_derr = derr < 5 ? (i32)(4 * derr) : (derr < 10 ? (i32)(6 * derr) - 10 : (i32)(derr * derr - 5 * derr));
         return 100 - (i32)(dy * (dy + 300) / 300) - s_derr;
     }
@@ -603,11 +615,18 @@ LNR_HD inline int gap_dp_score(int fn, u64 a, u64 b) { return fn == 2 ? gap_anch
 #define K_GAP_TEAM_ROW 2048   // predecessors of the previous row from which a row is dealt over the team (two barriers per row)
 #endif
 struct GStage { u32 x, y, z, w; };
+#ifndef K_GAP_YB_MAX
+#define K_GAP_YB_MAX 1024     // y buckets (64 wide, both strands) the column DP keeps cursors for in LDS
+#endif
+#ifndef K_GAP_YB_MIN
+#define K_GAP_YB_MIN 4096     // anchors from which the column DP takes its predecessors from y buckets instead of scanning the x window
+#endif
 struct GapTeam { const u64 *anchors; const i32 *score; u64 ai, dx_depth; int i, j_str, fn, cmd; u64 part[16]; Rec rec; u32 n, depth; int dup; u32 ncols; u32 *xs, *ys;
                  u64 *s_a; u32 *s_L, *s_R; u64 *s_tasks; const u64 *s_queue; u32 s_nq, s_next; GapCmp s_cmp;     // cmd 3: the ranges of a big sort dealt over the waves
                  const u64 *j_hs; u64 *j_out; u32 j_p1, j_p2, j_k; int j_kind, j_pass; u64 j_rvcp; i64 j_lower, j_upper; GAncBand j_band;   // cmd 4: the pairs of a big k-mer block
                  GStage stage[16][128];
-                 unsigned long long *tw; u32 tw_mask; };   // cmd 2: open-addressed set of the anchor words (the check for identical anchors)   // cmd: 0 exit, 1 one long row, 2 a whole DP by columns; xs / ys: x and y | strand << 24 of the anchors; stage: per wave, the pairs that passed the cheap tests
+                 unsigned long long *tw; u32 tw_mask;
+                 GStage *yb_list; u32 yb_ymin, yb_ymax, yb_start[K_GAP_YB_MAX + 1], yb_head[K_GAP_YB_MAX], yb_tail[K_GAP_YB_MAX]; };   // cmd 2 on many anchors: the rows of the columns done so far, listed per y bucket (gap_dp_columns)   // cmd 2: open-addressed set of the anchor words (the check for identical anchors)   // cmd: 0 exit, 1 one long row, 2 a whole DP by columns; xs / ys: x and y | strand << 24 of the anchors; stage: per wave, the pairs that passed the cheap tests
 #ifndef K_GAP_COL_MEAN
 #define K_GAP_COL_MEAN 12     // mean anchors per column from which the column form pays (one workgroup barrier per column)
 #endif
@@ -672,13 +691,15 @@ __device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 dept
         for (u32 i = (u32)w * 64 + (u32)lane; i <= twm; i += (u32)nw * 64) TW[i] = TW_EMPTY;
         __syncthreads();
     }
-    u32 myc = 0;
+    u32 myc = 0, my_lo = 0xffffffffu, my_hi = 0;
     bool twin_any = false;
+    GStage *YL = tm->yb_list;
     for (u32 i = (u32)w * 64 + (u32)lane; i < n; i += (u32)nw * 64) {
         u64 a = anchors[i];
-        u32 x = (u32)ganc_x(a);
-        XS[i] = x; YS[i] = (u32)ganc_y(a) | ((u32)ganc_strand(a) << 24);
+        u32 x = (u32)ganc_x(a), y = (u32)ganc_y(a);
+        XS[i] = x; YS[i] = y | ((u32)ganc_strand(a) << 24);
         myc += (i == 0 || (u32)ganc_x(anchors[i - 1]) != x) ? 1u : 0u;
+        my_lo = y < my_lo ? y : my_lo; my_hi = y > my_hi ? y : my_hi;
         if (TW) {
             u32 h = (u32)((a * 0x9E3779B97F4A7C15ULL) >> 32) & twm;
             for (;;) {
@@ -692,12 +713,54 @@ __device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 dept
     myc = wave_sum(myc);
     if (lane == 0 && myc) atomicAdd(&tm->ncols, myc);
     if (__any(twin_any) && lane == 0) tm->dup = 1;
+    if (YL) {
+        my_lo = wave_min_u32(my_lo); my_hi = wave_max_u32(my_hi);
+        if (lane == 0) { atomicMin(&tm->yb_ymin, my_lo); atomicMax(&tm->yb_ymax, my_hi); }
+    }
     __syncthreads();
     if (tm->dup == 1) return;                                    // (uniform: the caller redoes the DP in the single-wave form)
     // columns of a few anchors each would be one workgroup barrier per few rows: the single-wave form (the last 64 records in registers) is the
     // better one there -- every wave sees the same count and leaves; wave 0 then runs that form (dup = 2: not a duplicate, just "not by columns")
     if ((u64)tm->ncols * K_GAP_COL_MEAN > (u64)n) { if (w == 0 && lane == 0) tm->dup = 2; __syncthreads(); return; }
     const u32 dxd = (u32)dx_depth;
+    // ---- Many anchors.  In a satellite repeat one reference k-mer matches hundreds of read positions: the x window of a row (dx < 80) then
+    // holds ten thousand predecessors, the scan of it is the DP's time (VALU-bound), and only those with 0 <= dy < H (245 / 128 / 31) can
+    // score.  So the rows of the columns done so far are kept in one list per (strand, y >> 6), appended when their column is finished WITH
+    // what a later row needs of them -- x, y | strand, final score, index: 16 bytes, read back coalesced.  A list is in column order, i.e.
+    // x-descending: what has left the x window leaves at its front (head cursor, advanced by whoever sees it).  A row looks at the <= 5
+    // buckets its box covers; the same pairs pass the same tests and reach the same scoring as in the scan below.
+    const u32 ymin = tm->yb_ymin;
+    const u32 nby = YL ? ((tm->yb_ymax - ymin) >> 6) + 1 : 0;
+    const bool by_y = YL != nullptr && 2 * nby <= K_GAP_YB_MAX;
+    const u32 boxh = fn == 1 ? 245u : (fn == 2 ? 128u : 31u);
+    if (by_y) {
+        const u32 nbk = 2 * nby;
+        for (u32 b = (u32)w * 64 + (u32)lane; b < nbk; b += (u32)nw * 64) tm->yb_tail[b] = 0;
+        __syncthreads();
+        for (u32 i = (u32)w * 64 + (u32)lane; i < n; i += (u32)nw * 64) { u32 ys = YS[i]; atomicAdd(&tm->yb_tail[(((ys & 0xffffffu) - ymin) >> 6) + (ys >> 24) * nby], 1u); }
+        __syncthreads();
+        if (w == 0) {
+            u32 run = 0;
+            for (u32 b0 = 0; b0 < nbk; b0 += 64) {
+                u32 b = b0 + (u32)lane;
+                u32 c = b < nbk ? tm->yb_tail[b] : 0u;
+                u32 inc = wave_incl_scan(c);
+                if (b < nbk) tm->yb_start[b] = run + inc - c;
+                run += (u32)__shfl((int)inc, 63);
+            }
+            if (lane == 0) tm->yb_start[nbk] = run;
+        }
+        __syncthreads();
+        for (u32 b = (u32)w * 64 + (u32)lane; b < nbk; b += (u32)nw * 64) { tm->yb_tail[b] = 0; tm->yb_head[b] = 0; }
+        for (u32 i = (u32)w * 64 + (u32)lane; i < n; i += (u32)nw * 64) { GStage e_; e_.x = 0; e_.y = 0; e_.z = 0; e_.w = 0xffffffffu; YL[i] = e_; }   // (a slot reads as "no row" until its store has landed)
+        __syncthreads();
+    }
+#ifdef LNR_GAP_DEVPROF
+    unsigned long long tp_[6] = {0, 0, 0, 0, 0, 0}, tq_ = wall_clock64(), tr_; u32 ncol_ = 0; unsigned long long ncand_ = 0;
+#define TP_(k) do { tr_ = wall_clock64(); tp_[k] += tr_ - tq_; tq_ = tr_; } while (0)
+#else
+#define TP_(k) do {} while (0)
+#endif
     u32 c0 = 0;
     while (c0 < n) {
         const u32 x0 = XS[c0];
@@ -709,6 +772,10 @@ __device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 dept
             if (m) { c1 += (u32)__builtin_ctzll(m); break; }
             c1 += 64;
         }
+        TP_(0);
+#ifdef LNR_GAP_DEVPROF
+        ncol_++;
+#endif
         for (u32 i = c0 + (u32)w; i < c1; i += (u32)nw) {
             const u64 ai = anchors[i];
             const u32 ysi = YS[i];
@@ -726,6 +793,7 @@ __device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 dept
                     if (sc > 0) key = ((u64)(u32)(sc + r.score[j]) << 32) | (u64)(0xffffffffu - (u32)j);
                 }
             }
+            TP_(1);
             u32 nst = 0;
             auto flush = [&](u32 cnt) {                        // the first cnt (<= 64) staged pairs are scored
                 WLDS();
@@ -738,6 +806,66 @@ __device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 dept
                 nst -= cnt;
                 WLDS();
             };
+            if (by_y) {
+                const u32 yi = ysi & 0xffffffu, sb = (ysi >> 24) * nby;
+                const u32 b_lo = (yi - ymin) >> 6;
+                u32 b_hi = (yi + boxh - 1 - ymin) >> 6;
+                b_hi = b_hi < nby ? b_hi : nby - 1;
+                const u32 nq = b_hi - b_lo + 1;                       // <= 5 buckets
+                u32 q_start = 0, q_head = 0, q_len = 0;
+                if ((u32)lane < nq) {
+                    u32 b = sb + b_lo + (u32)lane;
+                    q_start = tm->yb_start[b]; q_head = tm->yb_head[b];
+                    q_len = tm->yb_tail[b] - q_head;
+                }
+                u32 pre_incl = wave_incl_scan(q_len);
+                const u32 total = (u32)__shfl((int)pre_incl, 63);
+#ifdef LNR_GAP_DEVPROF
+                ncand_ += total;
+#endif
+                u32 pre[6], qb[5], qh[5];                              // first candidate index of every bucket, where its live part starts in the list, its head
+                pre[0] = 0;
+#pragma unroll
+                for (int q = 0; q < 5; q++) { pre[q + 1] = (u32)__shfl((int)pre_incl, q); qb[q] = (u32)__shfl((int)(q_start + q_head), q); qh[q] = (u32)__shfl((int)q_head, q); }
+                // bucket by bucket (the bucket is then wave-uniform: no per-lane bookkeeping), 256 entries per step, four loads in flight per lane
+                for (u32 t = 0; t < nq; t++) {
+                    u32 base_ = 0, len_ = 0, head_ = 0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) if ((u32)k == t) { base_ = qb[k]; len_ = pre[k + 1] - pre[k]; head_ = qh[k]; }
+                    u32 gone = 0; bool lead = true;                    // leading entries found outside the x window
+                    for (u32 o = 0; o < len_; o += 256) {
+                        GStage cv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            u32 g = o + 64u * (u32)u + (u32)lane;
+                            GStage c_; c_.x = 0; c_.y = 0; c_.z = 0; c_.w = 0xffffffffu;
+                            if (g < len_) c_ = YL[base_ + g];
+                            cv[u] = c_;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (o + 64u * (u32)u >= len_) break;
+                            const GStage c_ = cv[u];
+                            bool in = c_.w < c0;                       // (0xffffffff: past the end, or a slot a wave of THIS column is filling: not a predecessor)
+                            u32 dx = c_.x - x0;
+                            bool live = in && dx < dxd;
+                            if (lead) {                                // the front of the list that has left the window
+                                u64 mq = __ballot(in), ml = __ballot(live);
+                                if (ml) { gone += (u32)__popcll(mq & ((1ULL << __builtin_ctzll(ml)) - 1)); lead = false; }
+                                else gone += (u32)__popcll(mq);
+                            }
+                            i32 dy = (i32)(c_.y - ysi);
+                            bool pass = live && gap_score_box(fn, dx, dy);
+                            // (entries that came through a y bucket pass the box often: scored in place, not compacted through LDS)
+                            if (__any(pass)) {
+                                int sc = pass ? gap_score_delta(fn, dx, (u32)dy) : 0;
+                                if (sc > 0) { u64 k = ((u64)(u32)(sc + (i32)c_.z) << 32) | (u64)(0xffffffffu - c_.w); key = k > key ? k : key; }
+                            }
+                        }
+                    }
+                    if (gone && lane == 0) atomicMax(&tm->yb_head[sb + b_lo + t], head_ + gone);
+                }
+            } else
             for (int jb = (int)c0 - 1; jb >= 0; jb -= 256) {
                 u32 xv[4], yv[4]; i32 sv[4];
 #pragma unroll
@@ -764,17 +892,30 @@ __device__ inline void gap_dp_columns(const u64 *anchors, u32 n, Rec r, u32 dept
                 if (__any(stop)) break;
             }
             if (nst) flush(nst);
-            for (int m = 32; m; m >>= 1) { u64 o = __shfl_xor(key, m); key = o > key ? o : key; }
+            TP_(2);
+            key = (u64)wave_max_i64((i64)key);                 // (keys are below 2^63: a DPP reduction instead of six bpermute round trips)
             if (lane == 0) {
                 if (key) {
                     int best = (int)(key >> 32), max_j = (int)(0xffffffffu - (u32)key);
                     r.p2[i] = max_j; r.score[i] = best; r.len[i] = r.len[max_j] + 1; r.score2[i] = best; r.root[i] = r.root[max_j]; r.leaf[i] = 1; r.leaf[max_j] = 0;
                 } else { r.p2[i] = -1; r.score[i] = 0; r.len[i] = 1; r.score2[i] = 0; r.root[i] = (i32)i; r.leaf[i] = 1; }
+                if (by_y) {                                      // the row joins its bucket's list (rows of one column in any order: they share one x)
+                    u32 b = (((ysi & 0xffffffu) - ymin) >> 6) + (ysi >> 24) * nby;
+                    GStage e_; e_.x = x0; e_.y = ysi; e_.z = key ? (u32)(key >> 32) : 0u; e_.w = i;
+                    YL[tm->yb_start[b] + atomicAdd(&tm->yb_tail[b], 1u)] = e_;
+                }
             }
+            TP_(3);
         }
         __syncthreads();                                         // the column's records are written: the next column reads them
+        TP_(4);
         c0 = c1;
     }
+#ifdef LNR_GAP_DEVPROF
+    if (n > 50000 && w == 0 && lane == 0)
+        printf("[gap prof] column DP of %u anchors, fn %d, by_y %d: %u columns; wave 0 (x10 ns): column start %llu, depth clause %llu, window %llu (candidates %llu), reduce + record %llu, barrier %llu\n",
+               n, fn, (int)by_y, ncol_, tp_[0], tp_[1], tp_[2], ncand_, tp_[3], tp_[4]);
+#endif
 }
 // ---- the (reference k-mer, read k-mer) pairs of one big block on the team (cmd 4): wave w takes the w-th contiguous share of the pair indices
 // (i major, as the serial loops), pass 1 counts the pairs it keeps, pass 2 writes them behind the shares before it -- the output is in pair order
@@ -1000,9 +1141,11 @@ LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, 
         while (tw_cap < 2 * n) tw_cap <<= 1;
         if (X.ar->off + (u64)tw_cap * 8 + 64 <= X.ar->cap) tw_ = (unsigned long long *)X.ar->get((u64)tw_cap * 8);   // (only when it fits)
     }
+    GStage *yl_ = nullptr;
+    if (xs_ && n >= K_GAP_YB_MIN && X.ar->off + (u64)n * 16 + 64 <= X.ar->cap) yl_ = (GStage *)X.ar->get((u64)n * 16);   // (only when it fits: the scan form needs no list)
     if (xs_) {
         GapTeam *tm = X.tm;
-        if ((threadIdx.x & 63) == 0) { tm->tw = tw_; tm->tw_mask = tw_cap - 1; tm->anchors = anchors; tm->rec = r; tm->n = n; tm->depth = depth; tm->dx_depth = dx_depth; tm->fn = fn_id; tm->dup = 0; tm->ncols = 0; tm->xs = xs_; tm->ys = xs_ + n; tm->cmd = 2; }
+        if ((threadIdx.x & 63) == 0) { tm->yb_list = yl_; tm->yb_ymin = 0xffffffffu; tm->yb_ymax = 0; tm->tw = tw_; tm->tw_mask = tw_cap - 1; tm->anchors = anchors; tm->rec = r; tm->n = n; tm->depth = depth; tm->dx_depth = dx_depth; tm->fn = fn_id; tm->dup = 0; tm->ncols = 0; tm->xs = xs_; tm->ys = xs_ + n; tm->cmd = 2; }
         __syncthreads();                                         // (A)
         gap_dp_columns(anchors, n, r, depth, dx_depth, GapDpFn{fn_id}, fn_id, 0, X.team, tm);
         by_columns = tm->dup == 0;                               // (a column held the same anchor twice: the single-wave form below redoes the DP)
