@@ -119,6 +119,7 @@ struct GapCtx {                                           // one read
     u64 deadline = 0;                                     // device, first launch: wall_clock64() after which the read is given up and left to the team launch (ovf = 2); 0 = none
     int coop = 0;                                         // device: all 64 lanes of the wave run this read together (k_gap, second launch)
     int team = 0; struct GapTeam *tm = nullptr;           // device: helper waves of the workgroup for the long rows of the chain DP (k_gap_team)
+    int hand = 0;                                         // device: a single wave of the first stage -- a later stage (teams, larger arenas) redoes what it gives up
 #ifdef LNR_GAP_DEVPROF
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ticks per phase (diagnostic build, tools/measure/gap_prof.sh)
     unsigned long long dp_t = 0, dp_n = 0, dp_mode = 0, dp_fn = 0;          // the read's longest chain DP: ticks, anchors, 1 = by columns, score function
@@ -615,6 +616,9 @@ LNR_HD inline int gap_dp_score(int fn, u64 a, u64 b) { return fn == 2 ? gap_anch
 #define K_GAP_TEAM_ROW 2048   // predecessors of the previous row from which a row is dealt over the team (two barriers per row)
 #endif
 struct GStage { u32 x, y, z, w; };
+#ifndef K_GAP_SINGLE_MAX
+#define K_GAP_SINGLE_MAX 8192    // elements of one sort / anchors of one chain DP from which a single wave hands its read to a team (4096: too many hand-offs, 577 ms; 16384: 332 ms; 8192: 328 ms)
+#endif
 #ifndef K_GAP_YB_MAX
 #define K_GAP_YB_MAX 1024     // y buckets (64 wide, both strands) the column DP keeps cursors for in LDS
 #endif
@@ -1111,6 +1115,9 @@ struct TileSink {
 template <class Score>
 LNR_HD inline void gap_chain_anchors(const u64 *anchors, u32 n, GVec<u64> &out, bool to_tiles, u32 depth, u64 dx_depth, int bestn, int min_len, int abort_score, Score score, GapCtx &X, int fn_id = 0) {
     if (n < 2 || X.ar->ovf) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (X.hand && n >= K_GAP_SINGLE_MAX) { X.ar->ovf = 2; return; }   // (a chain DP this long: the read goes to a team, see gap_sort_wave)
+#endif
     u64 m0 = X.ar->mark();
     Rec r;
     i32 *blk = (i32 *)X.ar->get((u64)n * 9 * sizeof(i32));
@@ -1889,36 +1896,60 @@ LNR_HD inline void gap_filter_anchors(GVec<u64> &a, GapCtx &X) {                
             // the walk over the sorted anchors, 64 elements per step.  Inside a block that started at b the running "median" anchor the serial
             // loop compares element i with is a[(b + i - 1) >> 1] -- set by the step before, which was a continuation or the block's start -- so
             // the continuation test of every element of the block is known from (b, i) alone; the block ends at the first element that fails it.
+            // Noise anchors make blocks of one or two elements: the walk then must not pay a memory round trip per block.  A step holds its 64
+            // elements and the 64 before them in registers; the blocks inside the step are closed one after the other from those (the median
+            // anchor of a short block lies in the window: a shuffle; of a long one: a load, which long blocks amortise).
             const u32 n = a.n, lane = threadIdx.x & 63;
             u64 b = 1, count = 1, min_y = ganc_y(a[1]), max_y = min_y;        // (the serial loop's first step: element 1 opens a block, nothing is listed)
             u32 i0 = 2;
-            while (i0 < n) {
-                u32 i = i0 + lane;
-                bool in = i < n;
-                u64 ai = in ? a.p[i] : 0, ak = in ? a.p[(u32)((b + i - 1) >> 1)] : 0;
-                u64 y = ganc_y(ai);
-                u64 dy2 = (u64)gabs((i64)(y - ganc_y(ak)));
-                bool cont = in && ganc_stranchor(ai) - ganc_stranchor(ak) < dy2;
-                u64 mfail = __ballot(in && !cont);
-                u32 nin = n - i0 < 64 ? n - i0 : 64;
-                u32 f = mfail ? (u32)__builtin_ctzll(mfail) : nin;          // elements of this step before f continue the block
-                u64 ly = lane < f ? y : min_y, hy = lane < f ? y : max_y;
-                for (int m = 32; m; m >>= 1) { u64 o1 = __shfl_xor(ly, m), o2 = __shfl_xor(hy, m); ly = o1 < ly ? o1 : ly; hy = o2 > hy ? o2 : hy; }
-                if (ly < min_y) min_y = ly;
-                if (hy > max_y) max_y = hy;
-                count += f;
-                bool last_cont = !mfail && i0 + nin == n;                    // the array ends inside the block: the serial loop closes it at i = n - 1
-                if (mfail || last_cont) {
-                    u64 iend = mfail ? (u64)i0 + f : (u64)n - 1;
-                    u64 acc = ((max_y - min_y) * 20) >> 10; if (acc < 20) acc = 20;
-                    if (count > acc) { UP e; e.first = b; e.second = iend; list.push(e); }
-                    if (!mfail) break;
-                    b = iend; count = 1;
-                    u64 yf = ganc_y(a.p[(u32)iend]);
-                    min_y = yf; max_y = yf;
-                    i0 = (u32)iend + 1;
-                    if (i0 >= n) break;                                      // (the failing element was the last one: it opened a block of its own, count 1)
-                } else i0 += nin;
+            u64 w_lo = lane < 2 ? a.p[lane] : 0;                              // elements i0 - 64 + lane (only those >= 0 are ever asked for)
+            {   // align: w_lo holds elements [i0 - 64, i0): for i0 = 2 that is lanes 62, 63 = elements 0, 1
+                u64 t = __shfl(w_lo, (int)((lane + 2) & 63));
+                w_lo = lane >= 62 ? t : 0;
+            }
+            bool done = false;
+            while (i0 < n && !done) {
+                const u32 nin = n - i0 < 64 ? n - i0 : 64;
+                const u32 i = i0 + lane;
+                const bool in = lane < nin;
+                const u64 ai = in ? a.p[i] : 0;
+                const u64 y = ganc_y(ai);
+                u32 cur = 0;                                                   // lanes below cur are dealt with
+                while (cur < nin) {
+                    // the median anchor of every remaining element, for the block that starts at b
+                    u64 k = (b + i - 1) >> 1;
+                    u64 ak;
+                    {
+                        u64 from_hi = __shfl(ai, (int)((u32)(k - i0) & 63)), from_lo = __shfl(w_lo, (int)((u32)(k + 64 - i0) & 63));
+                        bool far = in && lane >= cur && k + 64 < (u64)i0;
+                        ak = k >= (u64)i0 ? from_hi : from_lo;
+                        if (__any(far)) { if (far) ak = a.p[(u32)k]; }
+                    }
+                    u64 dy2 = (u64)gabs((i64)(y - ganc_y(ak)));
+                    bool cont = in && lane >= cur && ganc_stranchor(ai) - ganc_stranchor(ak) < dy2;
+                    u64 mfail = __ballot(in && lane >= cur && !cont);
+                    u32 f = mfail ? (u32)__builtin_ctzll(mfail) : nin;          // elements [cur, f) continue the block
+                    bool mine = lane >= cur && lane < f;
+                    u64 ly = mine ? y : min_y, hy = mine ? y : max_y;
+                    for (int m = 32; m; m >>= 1) { u64 o1 = __shfl_xor(ly, m), o2 = __shfl_xor(hy, m); ly = o1 < ly ? o1 : ly; hy = o2 > hy ? o2 : hy; }
+                    if (ly < min_y) min_y = ly;
+                    if (hy > max_y) max_y = hy;
+                    count += f - cur;
+                    bool last_cont = !mfail && i0 + nin == n;                    // the array ends inside the block: the serial loop closes it at i = n - 1
+                    if (mfail || last_cont) {
+                        u64 iend = mfail ? (u64)i0 + f : (u64)n - 1;
+                        u64 acc = ((max_y - min_y) * 20) >> 10; if (acc < 20) acc = 20;
+                        if (count > acc) { UP e; e.first = b; e.second = iend; list.push(e); }
+                        if (!mfail) { done = true; break; }
+                        b = iend; count = 1;
+                        u64 yf = __shfl(y, (int)f);
+                        min_y = yf; max_y = yf;
+                        cur = f + 1;
+                        if (i0 + cur >= n) { done = true; break; }             // (the failing element was the last one: it opened a block of its own, count 1)
+                    } else cur = nin;
+                }
+                w_lo = ai;                                                     // (a full step: the next window's lower half; a partial one ends the walk)
+                i0 += nin;
             }
         } else
 #endif

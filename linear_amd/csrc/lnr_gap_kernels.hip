@@ -112,7 +112,7 @@ __device__ void gap_sort_team_share(GapTeam *tm) {
     }
 }
 #ifndef K_GAP_SORT_TEAM_MIN
-#define K_GAP_SORT_TEAM_MIN 16384
+#define K_GAP_SORT_TEAM_MIN 4096
 #endif
 template <class T, class Comp> struct GapSortTeam { static __device__ bool run(T *, u32, Comp, GapCtx &, u32 *, u32 *, u64 *, int) { return false; } };
 template <> struct GapSortTeam<u64, GapCmp> {
@@ -133,6 +133,9 @@ template <> struct GapSortTeam<u64, GapCmp> {
     }
 };
 template <class T, class Comp> __device__ void gap_sort_wave(T *a, u32 n, Comp comp, GapCtx &X) {
+    // a single wave that meets a sort this long has a read no cost predictor announced: given up here (like an arena overflow) and redone by
+    // a team, whose 16 waves share the sort -- the stage waits for its slowest worker, not for the sum
+    if (X.hand && n >= K_GAP_SINGLE_MAX) { if (!X.ar->ovf) X.ar->ovf = 2; return; }
     u64 m0 = X.ar->mark();
     u32 *Lbuf = (u32 *)X.ar->get((u64)n * 4), *Rbuf = (u32 *)X.ar->get((u64)n * 4);
     u64 *tasks = (u64 *)X.ar->get(((u64)n + 64) * 8);
@@ -189,7 +192,7 @@ __device__ bool gap_do_read(const GapArgs &A, u32 r, char *mine, u64 arena_bytes
         X.gp.f_dup = A.f_dup; X.gp.thd_gap_len_min = A.gap_len_min;
         const bool ext_in = r >= A.ext_from;
         if (ext_in) X.gp.thd_cts_major_limit = 3;
-        X.coop = A.coop; X.work_cap = A.work_cap; X.team = team; X.tm = tm;
+        X.coop = A.coop; X.work_cap = A.work_cap; X.team = team; X.tm = tm; X.hand = (A.coop && !A.big && team <= 1) ? 1 : 0;
         X.deadline = (A.cap_ticks && !flagged_only) ? wall_clock64() + A.cap_ticks : 0;
         u64 *os = A.out_str + A.cords_off[r], *oe = A.out_end + A.cords_off[r];
         GVec<u64> cs, ce; cs.init(&keep, nc * 2 + 64); ce.init(&keep, nc * 2 + 64);
