@@ -10,8 +10,14 @@ chromosome lengths, 3.09 Gb, N runs, repeat families, tandem repeats, segmental 
 resident; 1 M reads = 10 steps).  `--workload chr22` is configs[1] (the round-1 line), `--workload small` a plumbing check.
 
 One step = one pass of the whole hot path (read prep + features + seed lookup + filter / chain / extend + block chaining ->
-cords) over one batch already resident in HBM.  Index build (and, for N > 1, its RCCL broadcast) happens once before the
-timed region and is reported in `config`.
+cords) over one batch.  Two timed regions run over the same batches: the batch already resident in HBM
+(`config.device_resident_reads_per_s`), and -- the line's `value`, SURVEY 8(d)'s metric -- host read blocks in -> host cords out
+through `lnr_filter_submit` / `lnr_filter_wait` with three batches in flight (reads up, cords down inside the clock).  The
+default line also measures the reference's DEFAULT mode on the same batches and context (`config.gap50`: `-g 1` = gaps of 50 and
+more re-mapped, with its own reference baseline and parity check; `--no-gap50` skips it) and the front-end binary end to end on
+FASTA files (`config.cli_end_to_end_reads_per_s`; `--no-cli`).  `--gap 50 [--dup 1]` makes the gap path the line itself;
+`--workload ccs_sv` is BASELINE configs[4] on one GPU (15 kb CCS-profile reads, SVs planted on the device, `-g 50 -dup 1`).
+Index build (and, for N > 1, its RCCL broadcast) happens once before the timed region and is reported in `config`.
 
 N > 1: one process per GPU.  Launched either by the driver through torch.distributed.run, or by `python bench.py --gpus N`
 itself: with no WORLD_SIZE in the environment this script starts the N ranks as a child torch.distributed.run BEFORE any GPU
@@ -95,6 +101,7 @@ def recorded_traffic(workload_key: dict, launches_per_step: float):
         return None
     rec = json.load(open(found[-1]))
     if rec.get("workload") != workload_key or abs(rec.get("launches_per_step", 0) - launches_per_step) > 1e-9:
+        print(f"[bench] roofline.traffic: the counter passes in {os.path.relpath(found[-1], ROOT)} were taken on another workload ({rec.get('workload')}): not reported", file=sys.stderr, flush=True)
         return None
     return {"bytes_per_launch": rec["traffic_bytes_per_launch"], "source": rec["source"] + " [" + os.path.relpath(found[-1], ROOT) + "]"}
 
