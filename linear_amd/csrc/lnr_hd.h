@@ -1049,9 +1049,29 @@ LNR_HD inline bool extend_window_serial(FeatView f1, FeatView f2, Vec<u64> &cord
 //   forward : step s looks at y0 + 5s and x in [x0 + 3s, x0 + 5s]                        -> 7 steps, 63 windows
 //   backward: after d steps the state is (x0 - 5d + c, y0 - 5d + a), a + c <= d; step d looks at y0 - 5d + a (a < d) and
 //             x0 - 5d + u (-1 <= u <= d)                                                   -> 4 steps, 50 windows
-LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 &tail, u64 cordy_str, u64 cordy_end) {
+#if defined(LNR_PROF)
+#define PD_CNT(k, v) do { lnr_pd_cnt[k] += (v); } while (0)
+#define PD_T0() unsigned long long pd_t0_ = clock64()
+#define PD_T(k) do { unsigned long long t_ = clock64(); lnr_pd_cnt[k] += t_ - pd_t0_; pd_t0_ = t_; } while (0)
+static __device__ __attribute__((unused)) int lnr_pd_dummy;
+#else
+#define PD_CNT(k, v) do {} while (0)
+#define PD_T0() do {} while (0)
+#define PD_T(k) do {} while (0)
+#endif
+LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 &tail, u64 cordy_str, u64 cordy_end, unsigned long long *lnr_pd_cnt = nullptr) {
     const int lane = (int)(threadIdx.x & 63);
-    u32 p_str = cords.n - 1;
+    (void)lnr_pd_cnt;
+    PD_T0();
+    // What every lane holds identically goes to scalar registers: the kernel runs at its VGPR cap, and a uniform pointer kept in (spilled)
+    // vector registers cost a scratch reload and a wait for ALL outstanding memory traffic before every store of a cord -- a memory round
+    // trip per cord pushed.  Scalar registers spill to VGPR lanes, which is a v_readlane.
+    u64 *const cp = (u64 *)lnr_uni64((u64)cords.p);
+    const u32 ccap = lnr_uni32(cords.cap);
+    u32 cn = lnr_uni32(cords.n);
+    f1.p = (const F96 *)lnr_uni64((u64)f1.p); f1.n = lnr_uni32(f1.n);
+    f2.p = (const F96 *)lnr_uni64((u64)f2.p); f2.n = lnr_uni32(f2.n);
+    const u32 p_str = cn - 1;
     tail = lnr_uni64(tail); cordy_str = lnr_uni64(cordy_str); cordy_end = lnr_uni64(cordy_end);
     // this lane's window inside the two frontiers
     const int d = lane < 3 ? 1 : (lane < 11 ? 2 : (lane < 26 ? 3 : 4));
@@ -1075,6 +1095,7 @@ LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 
             const i64 x0 = (i64)(cord_x(tail) >> 4), y0 = (i64)(cord_y(tail) >> 4);
             i64 Y = y0 - 5 * d + la, X = x0 - 5 * d + lu;
             u32 dv = (lane < 50 && Y >= 0 && X >= 0) ? wdist_raw(f1, f2, (u64)Y, (u64)X) : 0xffffffffu;
+            PD_CNT(1, 1);
             int a = 0, c = 0;
             for (int k = 0; k < 4; k++) {
                 i64 x = x0 - 5 * k + c, y = y0 - 5 * k + a;       // state before step k + 1
@@ -1090,19 +1111,24 @@ LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 
                 if (j == 0) { nc = mk_cord((gid << 30) + ((u64)(x - 5) << 4), (u64)(y - 4) << 4, strand); a++; }
                 else { nc = mk_cord((gid << 30) + ((u64)(x - 6 + j) << 4), (u64)(y - 5) << 4, strand); if (j == 2) c++; }
                 if (!(cord_y(nc) >= cordy_str)) { stop = true; break; }
-                if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return false; }
-                cords.push_u(nc); tail = nc;
+                if (cn >= ccap) { if (lnr_is_leader()) *cords.ovf = 1; cords.n = cn; return false; }
+                if (lnr_is_leader()) cp[cn] = nc;
+                cn++; tail = nc;
             }
         }
     }
-    u32 p_end = cords.n;
+    u32 p_end = cn;
+    PD_T(6);
+    PD_CNT(3, p_end - p_str - 1);
     if (p_end - p_str > 1) {
+        PD_CNT(5, 1);
         lnr_wave_sync();
         if (lnr_is_leader())
-            for (u32 k = p_str; k < (p_str + p_end) / 2; k++) rs_swap(cords[k], cords[cords.n - k + p_str - 1]);
+            for (u32 k = p_str; k < (p_str + p_end) / 2; k++) rs_swap(cp[k], cp[cn - k + p_str - 1]);
         lnr_wave_sync();
-        tail = lnr_uni64(cords[cords.n - 1]);
+        tail = lnr_uni64(cp[cn - 1]);
     }
+    PD_T(7);
     // ---- forward
     {
         bool stop = false, have = true;
@@ -1111,6 +1137,7 @@ LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 
             const u64 x0 = cord_x(tail) >> 4, y0 = cord_y(tail) >> 4;
             u32 dv = have ? dvf0 : (lane < 63 ? wdist_raw(f1, f2, y0 + 5 * (u64)s_, x0 + 3 * (u64)s_ + (u64)off) : 0xffffffffu);
             have = false;
+            PD_CNT(2, 1);
             u64 xc = x0, yc = y0;
             for (int k = 1; k <= 7; k++) {
                 if (yc + 12 > f1.n || xc + 12 > f2.n) { stop = true; break; }
@@ -1122,12 +1149,16 @@ LNR_HD inline bool extend_window(FeatView f1, FeatView f2, Vec<u64> &cords, u64 
                 if (mn > 36) { stop = true; break; }
                 u64 nc = mk_cord((gid << 30) + (x_min << 4), (yc + 5) << 4, strand);   // x_min - xc <= 5: the reference's other branch cannot be taken
                 if (!(cord_y(nc) + 96 < cordy_end)) { stop = true; break; }
-                if (cords.n >= cords.cap) { if (lnr_is_leader()) *cords.ovf = 1; return false; }
-                cords.push_u(nc); tail = nc;
+                if (cn >= ccap) { if (lnr_is_leader()) *cords.ovf = 1; cords.n = cn; return false; }
+                if (lnr_is_leader()) cp[cn] = nc;
+                cn++; tail = nc;
                 xc = x_min; yc += 5;
+                PD_CNT(4, 1);
             }
         }
     }
+    PD_T(8);
+    cords.n = cn;
     return true;
 }
 #else
@@ -1161,17 +1192,56 @@ LNR_HD inline u32 filter_hits_apply(u64 *hits, u32 nhits, const i32 *keep) {
 }
 // SIMT-uniform (all lanes execute it together on the device; hits are read-only, cords are written by the leader).
 template <bool COOP = true>
-LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], GenomeFeat g, Vec<u64> &cords, u64 read_str, u64 read_end, u64 L) {   // pmpfinder.cpp:1309-1410
+LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1_[2], GenomeFeat g, Vec<u64> &cords_, u64 read_str, u64 read_end, u64 L) {   // pmpfinder.cpp:1309-1410
     i64 hitBegin = 1, hitEnd = (i64)nhits;
     if (hitBegin >= hitEnd - 1) return;
+    // (wave form: the uniform state in scalar registers, see extend_window; the count goes back to the caller's vector on every way out)
+    Vec<u64> cords = cords_;
+    struct NBack { Vec<u64> &dst; Vec<u64> &src; LNR_HD ~NBack() { dst.n = src.n; } } nback_{cords_, cords};
+    FeatView f1[2] = {f1_[0], f1_[1]};
+    if (COOP) {
+        cords.p = (u64 *)lnr_uni64((u64)cords.p); cords.n = lnr_uni32(cords.n); cords.cap = lnr_uni32(cords.cap); cords.ovf = (int *)lnr_uni64((u64)cords.ovf);
+        for (int k = 0; k < 2; k++) { f1[k].p = (const F96 *)lnr_uni64((u64)f1[k].p); f1[k].n = lnr_uni32(f1[k].n); }
+        g.base = (const F96 *)lnr_uni64((u64)g.base); g.off = (const u64 *)lnr_uni64((u64)g.off); g.nseq = lnr_uni32(g.nseq);
+        read_str = lnr_uni64(read_str); read_end = lnr_uni64(read_end); L = lnr_uni64(L);
+        hitEnd = (i64)lnr_uni32(nhits);
+    }
     u64 tail;
     if (cords.n == 0) { cords.template push_m<COOP>(F_END); tail = F_END; }   // initCords
     else tail = lnr_u64<COOP>(cords[cords.n - 1]);
     u64 ready_str, ready_end, cordy_str = 0, cordy_end = 0;
     bool f_sp_l, f_sp_r = false, f_block_end = false, f_append;
     i64 itt_next = hitBegin + 1, itt_first = hitBegin;
+#if defined(LNR_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long pdc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pdt_ = clock64();
+    struct PdPrint { unsigned long long *c; u32 nh; __device__ ~PdPrint() { if ((blockIdx.x % 9973) == 777 && (threadIdx.x & 63) == 0)
+        printf("[pd2] block %u: hits %u, visited %llu, extensions %llu, backward frontiers %llu (cords %llu, reversals %llu), forward frontiers %llu (cords %llu); cycles: hit walk %llu, backward %llu, reversal %llu, forward %llu\n",
+               blockIdx.x, nh, c[10], c[0], c[1], c[3], c[5], c[2], c[4], c[9], c[6], c[7], c[8]); } } pdp_{pdc_, nhits};
+#endif
+    // The hit walk reads every hit two or three times, each time as a dependent load (thousands of cycles under the load of the job kernels): on
+    // the device the first 128 hits live in two registers per lane and are read with v_readlane (the index is wave-uniform); longer lists fall
+    // back to memory beyond that.  The genome-feature view (two dependent loads of the offset table) is kept while the sequence id stays.
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 hreg0 = 0, hreg1 = 0;
+    if (COOP) {
+        const u32 ln_ = threadIdx.x & 63;
+        hreg0 = ln_ < nhits ? hits[ln_] : 0; hreg1 = ln_ + 64 < nhits ? hits[ln_ + 64] : 0;
+    }
+    auto HIT = [&](i64 i) -> u64 {
+        if (!COOP) return hits[i];
+        if (i < 128) {
+            const u64 r = i < 64 ? hreg0 : hreg1;
+            const int l_ = (int)(i & 63);
+            return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(r >> 32), l_) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)r, l_);
+        }
+        return lnr_uni64(hits[i]);
+    };
+#else
+    auto HIT = [&](i64 i) -> u64 { return hits[i]; };
+#endif
+    u64 view_id = ~0ULL; FeatView view_f2; view_f2.p = g.base; view_f2.n = 0;
     for (i64 itt = hitBegin; itt < hitEnd; itt = itt_next++) {
-        const u64 hi = lnr_u64<COOP>(hits[itt]), hpv = lnr_u64<COOP>(hits[itt - 1]);
+        const u64 hi = HIT(itt), hpv = HIT(itt - 1);
         bool first_i = is_end(hpv);
         ready_str = cord_strand(hi) ? L - read_end : read_str;
         ready_end = cord_strand(hi) ? L - read_str + 1 : read_end;
@@ -1179,7 +1249,7 @@ LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], 
         f_sp_l = (da_l > 80) || cord_strand(hi ^ hpv);
         while (1) {
             if (itt_next >= hitEnd) { f_block_end = true; itt_first = itt_next; break; }
-            const u64 hn = lnr_u64<COOP>(hits[itt_next]), hp = lnr_u64<COOP>(hits[itt_next - 1]);
+            const u64 hn = HIT(itt_next), hp = HIT(itt_next - 1);
             if (is_end(hp)) { f_block_end = true; itt_first = itt_next; break; }
             i64 da_r = labs64((i64)(cord_x(hn) - cord_x(hp) - cord_y(hn) + cord_y(hp)));
             f_sp_r = (da_r > 80) || cord_strand(hn ^ hp);
@@ -1189,12 +1259,12 @@ LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], 
         f_append = false;
         if (!f_sp_r && !f_block_end) {
             cordy_str = f_sp_l ? hi : (first_i ? ready_str : cord_y(tail));
-            cordy_end = cord_y(lnr_u64<COOP>(hits[itt_next]));
+            cordy_end = cord_y(HIT(itt_next));
             if (cords.n >= cords.cap) { if (lnr_leader<COOP>()) *cords.ovf = 1; return; }
             cords.template push_m<COOP>(hi & ~F_END); tail = hi & ~F_END;
             f_append = true;
         } else {
-            const u64 hl = lnr_u64<COOP>(hits[itt_next - 1]);
+            const u64 hl = HIT(itt_next - 1);
             if (!f_sp_l && cord_y(hl) >= 96 && cord_x(hl) >= 96) {
                 u64 nc = shift_cord(hl, -96, -96);
                 cordy_str = first_i ? read_str : cord_y(nc);
@@ -1205,8 +1275,16 @@ LNR_HD inline void path_dst_2(const u64 *hits, u32 nhits, const FeatView f1[2], 
             }
         }
         if (is_end(hi) || f_block_end) { f_block_end = true; cordy_end = ready_end; }
-        if (f_append && !(COOP ? extend_window(f1[cord_strand(hi)], f2_view(g, cord_id(hi)), cords, tail, cordy_str, cordy_end)
-                               : extend_window_serial<false>(f1[cord_strand(hi)], f2_view(g, cord_id(hi)), cords, tail, cordy_str, cordy_end))) return;
+        if (f_append && cord_id(hi) != view_id) { view_id = cord_id(hi); view_f2 = f2_view(g, view_id); }
+#if defined(LNR_PROF) && defined(__HIP_DEVICE_COMPILE__)
+        { unsigned long long t_ = clock64(); pdc_[9] += t_ - pdt_; pdt_ = t_; pdc_[0] += f_append ? 1 : 0; pdc_[10]++; }
+        if (f_append && !(COOP ? extend_window(f1[cord_strand(hi)], view_f2, cords, tail, cordy_str, cordy_end, pdc_)
+                               : extend_window_serial<false>(f1[cord_strand(hi)], view_f2, cords, tail, cordy_str, cordy_end))) return;
+        pdt_ = clock64();
+        if (0)
+#endif
+        if (f_append && !(COOP ? extend_window(f1[cord_strand(hi)], view_f2, cords, tail, cordy_str, cordy_end)
+                               : extend_window_serial<false>(f1[cord_strand(hi)], view_f2, cords, tail, cordy_str, cordy_end))) return;
         if (f_block_end) { tail |= F_END; if (lnr_leader<COOP>()) cords[cords.n - 1] = tail; }
         itt_next = f_block_end ? itt_first : itt_next;
         f_sp_r = false; f_block_end = false;
