@@ -1121,7 +1121,7 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
         u32 w3 = (u32)std::min<u64>(n, std::max<u64>(1, (budget / 2) / arena3));
         const bool fused = ctx->gap_fused && ctx->gap_mode && ctx->gap_team;
         const u32 ncu = ctx->ncu ? ctx->ncu : 256, nteams = std::min<u32>(ctx->gap_teams, ncu / 2);
-        u64 fused_bytes = fused ? (u64)nteams * arena2 + (u64)ncu * 16 * arena1 : 0;     // (a small chunk runs fewer teams and more single waves: bounded by every CU full of single waves)
+        u64 fused_bytes = fused ? (u64)nteams * arena2 + (u64)ncu * K_GAP_TEAM * arena1 : 0;     // (a small chunk runs fewer teams and more single waves: bounded by every CU full of single waves)
         ENSURE(ctx->gap_arena, std::max(std::max(std::max((u64)w1 * arena1, (u64)w2 * arena2), (u64)w3 * arena3), fused_bytes));
         ENSURE(ctx->gap_flag, (size_t)n * 4);
         ENSURE(ctx->gap_next, 256);
@@ -1165,8 +1165,8 @@ lnr_status filter_dev(lnr_ctx *ctx, const u8 *d_reads, const u64 *d_off, u32 n, 
                 // one launch: teams on the reads expected to be heavy + on what the single waves hand over, single waves on the rest
                 if ((e = hipMemsetAsync(ctx->gap_list.p, 0, ((size_t)n + 16) * 4, ctx->stream)) != hipSuccess) return e;
                 G.nteams = std::min<u32>(nteams, std::max<u32>(1, m / 8));
-                u32 bulk_wg = std::min<u32>(ncu > G.nteams ? ncu - G.nteams : 1, (m + 15) / 16);
-                G.nbulk_waves = bulk_wg * 16; G.arena_bytes = arena1; G.arena2_bytes = arena2;
+                u32 bulk_wg = std::min<u32>(ncu > G.nteams ? ncu - G.nteams : 1, (m + K_GAP_TEAM - 1) / K_GAP_TEAM);
+                G.nbulk_waves = bulk_wg * K_GAP_TEAM; G.arena_bytes = arena1; G.arena2_bytes = arena2;
                 G.n_heavy = ctx->gap_rank.as<u32>(); G.q = ctx->gap_list.as<u32>() + 16;
                 G.coop = 1;
                 if ((e = launch_gap_all(G, G.nteams + bulk_wg, ctx->stream)) != hipSuccess) return e;

@@ -270,7 +270,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64 * K_GAP_TEAM, 64 *
 // expected to be heavy at once -- their critical path, not the work, is what the stage waits for -- while the single waves take the light end;
 // a single wave that cannot finish a read (arena, deadline) posts it in the queue and a team picks it up.  The stage ends when the single waves
 // are through and the queue is empty.  Which worker a read ends up with does not change its result.
-__global__ void __attribute__((amdgpu_flat_work_group_size(1024, 1024))) k_gap_all(GapArgs A) {
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * K_GAP_TEAM, 64 * K_GAP_TEAM))) k_gap_all(GapArgs A) {
     __shared__ GapTeam tm;
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 *ctl = A.next;
@@ -278,14 +278,14 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(1024, 1024))) k_gap_a
     u32 nheavy = *A.n_heavy;
     if (nheavy > m) nheavy = m;
     if (blockIdx.x < A.nteams) {
-        if (wave) { gap_team_helper_loop(&tm, (int)wave, 16); return; }
+        if (wave) { gap_team_helper_loop(&tm, (int)wave, K_GAP_TEAM); return; }
         char *mine = A.arena + (u64)blockIdx.x * A.arena2_bytes;
         for (;;) {                                                   // 1. the reads expected to be heavy, heaviest first
             u32 k = lane == 0 ? atomicAdd(ctl + 1, 1u) : 0u;
             k = (u32)__shfl((int)k, 0);
             if (k >= nheavy) break;
             if (lane == 0) atomicAdd(ctl + 16, 1u);
-            gap_do_read(A, A.order[k], mine, A.arena2_bytes, &tm, 16, false, 1);
+            gap_do_read(A, A.order[k], mine, A.arena2_bytes, &tm, K_GAP_TEAM, false, 1);
         }
         for (;;) {                                                   // 2. what the single waves hand over, until they are all through
             u32 k = lane == 0 ? atomicAdd(ctl + 3, 1u) : 0u;
@@ -300,12 +300,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(1024, 1024))) k_gap_a
             }
             if (!v) break;
             if (lane == 0) atomicAdd(ctl + 16, 1u);
-            gap_do_read(A, v - 1, mine, A.arena2_bytes, &tm, 16, true, 1);
+            gap_do_read(A, v - 1, mine, A.arena2_bytes, &tm, K_GAP_TEAM, true, 1);
         }
         if (lane == 0) tm.cmd = 0;
         __syncthreads();                                             // (A) with the exit command: the helpers leave
     } else {
-        u32 worker = (blockIdx.x - A.nteams) * 16 + wave;
+        u32 worker = (blockIdx.x - A.nteams) * K_GAP_TEAM + wave;
         char *mine = A.arena + (u64)A.nteams * A.arena2_bytes + (u64)worker * A.arena_bytes;
 #ifdef LNR_GAP_DEVPROF
         if (A.prof && lane == 0) { unsigned long long c = atomicAdd(A.prof + 94, 1ULL) + 1; atomicMax(A.prof + 95, c); }
@@ -325,7 +325,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(1024, 1024))) k_gap_a
     }
 }
 hipError_t launch_gap_all(const GapArgs &A, unsigned grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_gap_all, dim3(grid), dim3(1024), 0, stream, A);
+    hipLaunchKernelGGL(k_gap_all, dim3(grid), dim3(64 * K_GAP_TEAM), 0, stream, A);
     return hipGetLastError();
 }
 
