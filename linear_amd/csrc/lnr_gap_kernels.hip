@@ -164,6 +164,12 @@ __device__ bool gap_do_read(const GapArgs &A, u32 r, char *mine, u64 arena_bytes
     u32 nc = A.nout[r];
     u64 L = A.off[r + 1] - A.off[r];
     if (L <= 200 || nc <= 1) { if (!flagged_only) A.gap_flag[r] = 0; return false; }
+#ifdef LNR_GAP_POISON
+    // diagnostic build: the worker's whole arena is filled with a byte pattern before every read (a result that depends on what an earlier read
+    // left in the arena shows up as a dependence on the pattern)
+    { const u64 pat = 0x0101010101010101ULL * (u64)(LNR_GAP_POISON & 0xff);
+      for (u64 o_ = (u64)(threadIdx.x & 63) * 8; o_ + 8 <= arena_bytes; o_ += 512) *(u64 *)(mine + o_) = pat; WSYNC(); }
+#endif
     GArena all; all.init(mine, arena_bytes);
     LeaderScratch *ls = (LeaderScratch *)all.get(sizeof(LeaderScratch));
     u8 *rd = (u8 *)all.get(L + 64), *rc = (u8 *)all.get(L + 64);
